@@ -1,0 +1,170 @@
+"""Generate the committed golden vectors in tests/golden/ from the REAL reference.
+
+Run:  python oracle/make_golden.py       (build container only; needs /root/reference)
+
+Outputs (all float32 unless noted, produced by /root/reference code on torch CPU):
+  tests/golden/net_<name>.npz   small skip() nets: state_dict, input z, target, mask,
+                                out, loss, every gradient, parameters after 1 and after 3
+                                optimize('adam') iterations (utils/common_utils.py:223-230)
+  tests/golden/downsampler.npz  Downsampler(3,4,'lanczos2',0.5,preserve_size) taps, fwd, bwd
+  tests/golden/get_noise.npz    get_noise() draws for fixed seeds
+  tests/golden/default64_digest.json  digests of the FULL default net (2 217 831 params,
+                                torch.manual_seed(0) construction) at 64x64: pins parameter
+                                RNG order + state_dict naming + forward/backward numerics
+"""
+import copy
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _refload  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+NETS = {
+    # tiny but structurally complete variants of the BASELINE configs
+    "tiny_default": dict(args=(8, 3), hw=(32, 48), seed=1,
+                         kw=dict(num_channels_down=[16, 32, 32], num_channels_up=[16, 32, 32],
+                                 num_channels_skip=[4, 4, 4], upsample_mode="bilinear",
+                                 need_sigmoid=True, need_bias=True, pad="reflection")),
+    "tiny_kate": dict(args=(8, 3), hw=(32, 32), seed=2,
+                      kw=dict(num_channels_down=[16, 16, 16], num_channels_up=[16, 16, 16],
+                              num_channels_skip=[16, 16, 16], upsample_mode="nearest",
+                              need_sigmoid=True, need_bias=True, pad="reflection")),
+    "tiny_library": dict(args=(1, 3), hw=(64, 48), seed=3,
+                         kw=dict(num_channels_down=[8, 16, 32], num_channels_up=[8, 16, 32],
+                                 num_channels_skip=[0, 0, 0], filter_size_up=3, filter_size_down=5,
+                                 upsample_mode="nearest", need1x1_up=False,
+                                 need_sigmoid=True, need_bias=True, pad="reflection")),
+    "tiny_snail": dict(args=(3, 3), hw=(32, 48), seed=4,
+                       kw=dict(num_channels_down=[8, 16, 32], num_channels_up=[8, 16, 32],
+                               num_channels_skip=[0, 4, 4], upsample_mode="bilinear",
+                               need_sigmoid=True, need_bias=True, pad="reflection")),
+    "tiny_zero": dict(args=(2, 1), hw=(32, 32), seed=5,
+                      kw=dict(num_channels_down=[8, 16], num_channels_up=[8, 16],
+                              num_channels_skip=[4, 4], need_sigmoid=True, need_bias=True)),
+}
+
+
+def gen_net(name, cfg):
+    rm = _refload.load_ref_models()
+    cu = _refload.load_ref_common_utils()
+    torch.manual_seed(cfg["seed"])
+    net = rm.skip(*cfg["args"], **cfg["kw"])
+    H, W = cfg["hw"]
+    cin, cout = cfg["args"]
+    z = cu.get_noise(cin, "meshgrid" if cin == 2 else "noise", (H, W)).float()
+    target = torch.rand(1, cout, H, W)
+    mask = (torch.rand(1, 1, H, W) > 0.3).float()
+    rec = {"z": z.numpy(), "target": target.numpy(), "mask": mask.numpy()}
+    for k, v in net.state_dict().items():
+        rec["sd/" + k] = v.detach().numpy().copy()
+
+    out = net(z)
+    loss = torch.nn.functional.mse_loss(out * mask, target * mask)   # inpainting.ipynb:310 form
+    loss.backward()
+    rec["out"] = out.detach().numpy().copy()
+    rec["loss"] = np.array(loss.item(), dtype=np.float64)
+    for k, p in net.named_parameters():
+        rec["grad/" + k] = p.grad.numpy().copy()
+    for p in net.parameters():
+        p.grad = None
+
+    # optimize('adam') trajectory, utils/common_utils.py:223-230, closure in the notebook style
+    mse = torch.nn.MSELoss()
+    # optimize() creates a fresh Adam every call, so run it once for 1 step on a clone and once for 3
+    for nsteps in (1, 3):
+        net2 = copy.deepcopy(net)
+
+        def closure2():
+            o = net2(z)
+            l = mse(o * mask, target * mask)
+            l.backward()
+            return l
+
+        cu.optimize("adam", cu.get_params("net", net2, z), closure2, 0.01, nsteps)
+        for k, p in net2.named_parameters():
+            rec[f"adam{nsteps}/" + k] = p.detach().numpy().copy()
+        if nsteps == 3:
+            rec["out_after3"] = net2(z).detach().numpy().copy()
+    np.savez_compressed(os.path.join(OUT, f"net_{name}.npz"), **rec)
+    print(f"net_{name}.npz: {sum(v.size for v in rec.values())} values")
+    return cfg
+
+
+def gen_downsampler():
+    rm = _refload.load_ref_models()
+    rec = {}
+    for factor, kt in ((4, "lanczos2"), (2, "lanczos2"), (8, "lanczos2")):
+        d = rm.downsampler.Downsampler(n_planes=3, factor=factor, kernel_type=kt, phase=0.5, preserve_size=True)
+        torch.manual_seed(factor)
+        x = torch.rand(1, 3, 64, 96, requires_grad=True)
+        y = d(x)
+        g = torch.rand_like(y)
+        (y * g).sum().backward()
+        tag = f"{kt}_f{factor}"
+        rec[tag + "/kernel"] = d.kernel
+        rec[tag + "/x"] = x.detach().numpy()
+        rec[tag + "/y"] = y.detach().numpy()
+        rec[tag + "/gy"] = g.numpy()
+        rec[tag + "/gx"] = x.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "downsampler.npz"), **rec)
+    print("downsampler.npz")
+
+
+def gen_get_noise():
+    cu = _refload.load_ref_common_utils()
+    rec = {}
+    torch.manual_seed(0); rec["u_s0_32x16x24"] = cu.get_noise(32, "noise", (16, 24)).numpy()
+    torch.manual_seed(7); rec["n_s7_3x8x8"] = cu.get_noise(3, "noise", 8, noise_type="n", var=0.5).numpy()
+    rec["mesh_8x12"] = cu.get_noise(2, "meshgrid", (8, 12)).numpy()
+    np.savez_compressed(os.path.join(OUT, "get_noise.npz"), **rec)
+    print("get_noise.npz")
+
+
+def digest(t: torch.Tensor):
+    d = t.detach().double().flatten()
+    idx = torch.linspace(0, d.numel() - 1, 5).long()
+    return {"shape": list(t.shape), "sum": d.sum().item(), "abssum": d.abs().sum().item(),
+            "sq": (d * d).sum().item(), "samples": d[idx].tolist()}
+
+
+def gen_default_digest():
+    rm = _refload.load_ref_models()
+    cu = _refload.load_ref_common_utils()
+    torch.manual_seed(0)
+    net = rm.get_net(32, "skip", "reflection", skip_n33d=128, skip_n33u=128, skip_n11=4,
+                     num_scales=5, upsample_mode="bilinear")
+    z = cu.get_noise(32, "noise", (64, 64))
+    np.random.seed(0)
+    target = torch.from_numpy(np.random.rand(1, 3, 64, 64).astype(np.float32))
+    out = net(z)
+    loss = torch.nn.functional.mse_loss(out, target)
+    loss.backward()
+    rec = {"config": "get_net(32,'skip','reflection',skip_n33d=128,skip_n33u=128,skip_n11=4,num_scales=5,"
+                     "upsample_mode='bilinear'); torch.manual_seed(0) before construction; "
+                     "z=get_noise(32,'noise',(64,64)) drawn right after; target=np.random.seed(0) rand(1,3,64,64)",
+           "n_params": sum(p.numel() for p in net.parameters()),
+           "keys": list(net.state_dict().keys()),
+           "z": digest(z), "out": digest(out), "loss": loss.item(),
+           "params": {k: digest(p) for k, p in net.named_parameters()},
+           "grads": {k: digest(p.grad) for k, p in net.named_parameters()}}
+    with open(os.path.join(OUT, "default64_digest.json"), "w") as f:
+        json.dump(rec, f)
+    print("default64_digest.json", rec["n_params"], "params", len(rec["keys"]), "state_dict keys")
+
+
+if __name__ == "__main__":
+    assert _refload.available(), "reference checkout not found"
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(1)          # fixed reduction order for the committed vectors
+    for n, c in NETS.items():
+        gen_net(n, c)
+    gen_downsampler()
+    gen_get_noise()
+    gen_default_digest()
