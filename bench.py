@@ -1,0 +1,281 @@
+"""Benchmark of the deep-image-prior hot path on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one optimisation iteration (reg-noise perturbation, skip-net forward, MSE, backward,
+fused Adam) of ONE 512x512 denoising fit with the default net
+  get_net(32,'skip','reflection',skip_n33d=128,skip_n33u=128,skip_n11=4,num_scales=5,'bilinear')
+(BASELINE.json configs[1]/[4] at the size the metric is quoted on; SURVEY.md section 8d "M1").
+With N GPUs every rank optimises its own independent image (no collective on the data path:
+train-mode BatchNorm forbids batching images, so images shard one-per-GPU) -> "scaling": "weak",
+value = N * K / max-over-ranks time.
+
+The JSON line also carries
+  roofline     : the dominant kernel (3x3 stride-1 implicit-GEMM conv, 128-wide N block: forward
+                 and data-gradient launches) -- algorithmic FLOPs / HIP-event time, vs the
+                 157.3 TFLOP/s fp32 MFMA peak (MI355X_MICROARCH.md chip table);
+  cpu_baseline : the CPU oracle (oracle/dip_oracle.py, a bitwise-verified restatement of the
+                 reference's PyTorch-CPU path) timed on this box's host cores on the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP32 (matrix)
+SIZE = 512
+
+
+def shard_images(n_images: int, rank: int, world: int):
+    """Static round-robin partition of independent image fits over ranks (no data exchange)."""
+    return [i for i in range(n_images) if i % world == rank]
+
+
+def reduce_max_time(t: float, device) -> float:
+    """max over ranks of a wall-time (the only collective in the benchmark; not on the data path)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return t
+    x = torch.tensor([t], dtype=torch.float64, device=device)
+    dist.all_reduce(x, op=dist.ReduceOp.MAX)
+    return float(x.item())
+
+
+def make_problem(seed: int, size: int = SIZE):
+    """Synthetic denoising problem of the reference's shape: clean = 5x5 box-blur
+    of U(0,1) noise, target = clip(clean + N(0,(25/255)^2)), z = get_noise(32,'noise') ~ U(0,0.1)."""
+    from utils.common_utils import get_noise
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    z = get_noise(32, 'noise', (size, size))
+    clean = torch.nn.functional.avg_pool2d(torch.rand(1, 3, size + 4, size + 4), 5, stride=1)
+    noisy = np.clip(clean.numpy() + np.random.normal(scale=25 / 255., size=clean.shape), 0, 1).astype(np.float32)
+    return z, torch.from_numpy(noisy)
+
+
+def build_fit(seed: int, dev, size: int = SIZE):
+    from models import get_net
+    torch.manual_seed(seed)
+    net = get_net(32, 'skip', 'reflection', skip_n33d=128, skip_n33u=128, skip_n11=4, num_scales=5,
+                  upsample_mode='bilinear').to(dev)
+    z, target = make_problem(seed, size)
+    return net, z.to(dev), target.to(dev)
+
+
+def make_closure(net, z, target, reg_noise_std=1. / 30., exp_weight=0.99):
+    """The denoising notebook's closure (reference denoising.ipynb:204-221) minus the per-iteration
+    host syncs (PSNR prints / plots / CPU parameter snapshots), which are not the hot path."""
+    mse = torch.nn.MSELoss()
+    st = {"saved": z.detach().clone(), "noise": z.detach().clone(), "avg": None, "loss": None, "i": 0}
+
+    def closure():
+        net_input = st["saved"] + (st["noise"].normal_() * reg_noise_std)
+        out = net(net_input)
+        st["avg"] = out.detach() if st["avg"] is None else st["avg"] * exp_weight + out.detach() * (1 - exp_weight)
+        total_loss = mse(out, target)
+        total_loss.backward()
+        st["loss"] = total_loss.detach()
+        st["i"] += 1
+        return total_loss
+
+    return closure, st
+
+
+def conv_flops(eng):
+    """Algorithmic conv FLOPs per iteration, per op name: 2*Cout*Ho*Wo*Cin*k*k for forward,
+    weight-gradient and (where the input needs it) data-gradient."""
+    fl = {}
+
+    def dims(r, H, W):
+        Ho, Wo = (H + 2 * r.P - r.ks) // r.stride + 1, (W + 2 * r.P - r.ks) // r.stride + 1
+        return 2.0 * r.Cout * Ho * Wo * r.Cin * r.ks * r.ks
+
+    for i, s in enumerate(eng.sc):
+        st = s.st
+        H, W = st["H"], st["W"]
+        for attr, (h, w) in (("skip_conv", (H, W)), ("down_a", (H, W)), ("down_b", (H // 2, W // 2)), ("up", (H, W)),
+                             ("up1", (H, W))):
+            r = getattr(s, attr)
+            if r is not None:
+                f = dims(r, h, w)
+                fl["conv_fwd:" + r.name] = f
+                fl["wgrad:" + r.name] = f
+                fl["dgrad:" + r.name] = f
+                fl["dgrad+:" + r.name] = f
+    r = eng.out_conv
+    f = dims(r, eng.H, eng.W)
+    fl["conv_fwd:out"] = fl["wgrad:out"] = fl["dgrad:out"] = f
+    return fl
+
+
+def profile_ops(eng, reps=3):
+    """HIP-event time of every launch of one iteration, in sequence on the engine's own stream
+    (torch's current stream), averaged over `reps` instrumented iterations."""
+    stream = torch.cuda.current_stream(eng.device)
+    sptr = stream.cuda_stream
+    acc = {}
+    for rep in range(reps):
+        for ops in (eng.fwd_ops, eng.bwd_ops):
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(ops) + 1)]
+            evs[0].record(stream)
+            for k, (fn, args, name) in enumerate(ops):
+                fn(*args, sptr)
+                evs[k + 1].record(stream)
+            torch.cuda.synchronize()
+            for k, (_, _, name) in enumerate(ops):
+                acc.setdefault(name, []).append(evs[k].elapsed_time(evs[k + 1]))
+    return {k: float(np.mean(v)) for k, v in acc.items()}
+
+
+def roofline(eng, per_op_ms):
+    """Dominant kernel = conv_igemm_kernel<3,1,32,128>: every 3x3 stride-1 forward conv and every
+    data-gradient launch of a 3x3 conv (the stride-2 ones run as a dilated stride-1 gather)."""
+    fl = conv_flops(eng)
+    tot_f = tot_ms = 0.0
+    n = 0
+    by_name = {r.name: r for r in eng.convs}
+    for name, ms in per_op_ms.items():
+        kind, _, lname = name.partition(":")
+        r = by_name.get(lname)
+        if r is None or r.ks != 3:
+            continue
+        if (kind == "conv_fwd" and r.stride == 1) or kind == "dgrad":
+            tot_f += fl[name]
+            tot_ms += ms
+            n += 1
+    ach = tot_f / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+    big = per_op_ms.get("conv_fwd:s0.up")
+    return {"bound": "mfma", "kernel": "conv_igemm_kernel<3,1,32,128> (3x3 s1 fwd + 3x3 dgrad, all scales)",
+            "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+            "launches_per_step": n, "avg_launch_us": round(1e3 * tot_ms / max(n, 1), 1),
+            "algorithmic_gflop_per_step": round(tot_f / 1e9, 2),
+            "largest_layer": {"name": "3.1 (132->128 3x3 @512^2) forward", "gflop": round(fl["conv_fwd:s0.up"] / 1e9, 2),
+                              "us": round(1e3 * big, 1) if big else None,
+                              "tflops": round(fl["conv_fwd:s0.up"] / (big * 1e-3) / 1e12, 2) if big else None}}
+
+
+def cpu_baseline(seed=0, budget_s=25.0):
+    """The CPU oracle on this box's host cores: same net, same 512x512 workload, same closure;
+    1 warm-up + up to 2 timed iterations (bounded: ~10 s each on 8 cores)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import dip_oracle as O
+    from models import get_net
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(seed)
+    net = get_net(32, 'skip', 'reflection', skip_n33d=128, skip_n33u=128, skip_n11=4, num_scales=5,
+                  upsample_mode='bilinear')
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items() if k in O.param_shapes(O.default_spec())}
+    onet = O.OracleNet(O.default_spec(), sd)
+    z, target = make_problem(seed)
+    closure, st = make_closure(onet, z, target)
+    opt = torch.optim.Adam(onet.params, lr=0.01)
+    times = []
+    t_start = time.time()
+    for it in range(3):
+        t0 = time.time()
+        opt.zero_grad()
+        closure()
+        opt.step()
+        times.append(time.time() - t0)
+        if it >= 1 and time.time() - t_start > budget_s:
+            break
+    timed = times[1:] if len(times) > 1 else times
+    return {"value": round(1.0 / float(np.median(timed)), 4), "unit": "it/s", "cores": cores, "kind": "port",
+            "sample": f"default skip-net 512x512, 1 warm-up + {len(timed)} timed Adam iterations of the CPU oracle "
+                      f"(torch {torch.__version__} CPU, {cores} threads), median"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dump-ops", default=None, help="write the per-launch HIP-event table (JSON) here")
+    args = ap.parse_args()
+
+    ge.build()
+    from utils.common_utils import get_params
+    from dip_optim import FusedAdam
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
+
+    my_images = shard_images(world, rank, world)            # one independent fit per rank
+    fits = []
+    for img in my_images:
+        net, z, target = build_fit(img, dev)
+        closure, st = make_closure(net, z, target)
+        opt = FusedAdam(get_params('net', net, z), lr=0.01)   # == optimize('adam', ...) unrolled for timing
+        fits.append((net, closure, st, opt))
+
+    def step():
+        for net, closure, st, opt in fits:
+            opt.zero_grad()
+            closure()
+            opt.step()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    t = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+    t = reduce_max_time(t, dev)
+    final_loss = float(fits[0][2]["loss"].item())
+
+    if rank == 0:
+        eng = fits[0][0].__dict__["_dip_engine"]
+        rl = None
+        if not args.no_roofline:
+            per_op = profile_ops(eng)
+            rl = roofline(eng, per_op)
+            if args.dump_ops:
+                fl = conv_flops(eng)
+                with open(args.dump_ops, "w") as f:
+                    json.dump({k: {"ms": v, "gflop": fl.get(k, 0) / 1e9} for k, v in per_op.items()}, f, indent=1)
+        cb = None if (args.no_cpu_baseline or world > 1) else cpu_baseline()
+        its = world * len(my_images) * args.steps / t
+        line = {
+            "metric": "optimisation iters/sec per image (skip-net 512x512 denoising)", "value": round(its, 3),
+            "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * t / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "default skip-net (2 217 831 params) 512x512 denoising fit: reg-noise + forward "
+                                   "+ MSE + backward + fused Adam, one independent image per GPU",
+                       "images": world, "final_loss": round(final_loss, 6)},
+            "roofline": rl, "cpu_baseline": cb,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,271 @@
+// BatchNorm2d (train mode, N=1) statistics finalisation and the three backward phases, fused with
+// LeakyReLU backward and the adjoint of ReflectionPad2d.  All HBM-bound: float4 per lane, NHWC.
+#include "dip_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// forward finalise: Chan-combine per-tile {count, mean, M2} partials (fp64) -> state + running
+// grid.x = ceil(C/16); block = 256 = 16 tile-rows x 16 channels
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partials, int ntiles,
+                                                          int Cstride, int C, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps, float momentum,
+                                                          float* state, int Cs, float* running_mean,
+                                                          float* running_var) {
+    __shared__ double sh[16][16][3];
+    const int cl = threadIdx.x & 15, row = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    double n = 0.0, mean = 0.0, M2 = 0.0;
+    if (c < C) {
+        for (int t = row; t < ntiles; t += 16) {
+            const float* p = partials + (size_t)t * 3 * Cstride + c;
+            dip_chan_d(n, mean, M2, (double)p[0], (double)p[Cstride], (double)p[2 * Cstride]);
+        }
+    }
+    sh[row][cl][0] = n; sh[row][cl][1] = mean; sh[row][cl][2] = M2;
+    __syncthreads();
+    if (row == 0 && c < C) {
+        for (int r = 1; r < 16; ++r) dip_chan_d(n, mean, M2, sh[r][cl][0], sh[r][cl][1], sh[r][cl][2]);
+        const double var = M2 / n;                       // biased (normalisation)
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float a = gamma[c] * rstd;
+        const float fm = (float)mean;
+        state[c] = fm;
+        state[Cs + c] = rstd;
+        state[2 * Cs + c] = a;
+        state[3 * Cs + c] = beta[c] - fm * a;
+        if (running_mean != nullptr) {
+            const double unb = n > 1.0 ? M2 / (n - 1.0) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * fm;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// thread layout shared by the NHWC streaming kernels: a block walks a pixel range; thread
+// (prow, cg) handles 4 channels [4cg, 4cg+4) of pixels prow, prow+RPI, ...   (RPI = 256 / NC4)
+// ------------------------------------------------------------------------------------------
+struct RowLayout {
+    int nc4, rpi, prow, cg;
+    bool active;
+};
+__device__ __forceinline__ RowLayout row_layout(int C) {
+    RowLayout L;
+    L.nc4 = (C + 3) >> 2;
+    L.rpi = 256 / L.nc4;
+    if (L.rpi < 1) L.rpi = 1;
+    L.prow = threadIdx.x / L.nc4;
+    L.cg = threadIdx.x - L.prow * L.nc4;
+    L.active = (int)threadIdx.x < L.rpi * L.nc4;
+    return L;
+}
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// incoming gradient for pixel (r,c), channels [ch, ch+4): padded source with optional reflection fold
+__device__ __forceinline__ f32x4 grad_src4(const DipGradSrc& s, int r, int c, int H, int W, int ch) {
+    const int P = s.pad;
+    const int Wg = W + 2 * P;
+    const float* base = s.g + s.choff + ch;
+    if (!s.fold || P == 0) return ld4(base + ((size_t)(r + P) * Wg + (c + P)) * s.Cg);
+    // rows of the padded domain that reflect onto r: r+P itself, P-r (top), 2(H-1)-r+P (bottom)
+    int rr[3], nr = 0, cc[3], ncn = 0;
+    rr[nr++] = r + P;
+    if (r >= 1 && r <= P) rr[nr++] = P - r;
+    if (r <= H - 2 && r >= H - 1 - P) rr[nr++] = 2 * (H - 1) - r + P;
+    cc[ncn++] = c + P;
+    if (c >= 1 && c <= P) cc[ncn++] = P - c;
+    if (c <= W - 2 && c >= W - 1 - P) cc[ncn++] = 2 * (W - 1) - c + P;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < nr; ++i)
+        for (int j = 0; j < ncn; ++j) acc += ld4(base + ((size_t)rr[i] * Wg + cc[j]) * s.Cg);
+    return acc;
+}
+
+// block-level reduction of per-thread (s1, s2) float4 pairs over prow, written as [blk][2][Cs]
+__device__ __forceinline__ void block_reduce_2(const RowLayout& L, f32x4 s1, f32x4 s2, float* partials, int Cs,
+                                               float* sh /* 256*8 floats */) {
+    st4(sh + threadIdx.x * 8, s1);
+    st4(sh + threadIdx.x * 8 + 4, s2);
+    __syncthreads();
+    if (L.active && L.prow == 0) {
+        for (int r = 1; r < L.rpi; ++r) {
+            s1 += ld4(sh + (r * L.nc4 + L.cg) * 8);
+            s2 += ld4(sh + (r * L.nc4 + L.cg) * 8 + 4);
+        }
+        float* o = partials + (size_t)blockIdx.x * 2 * Cs + L.cg * 4;
+        st4(o, s1);
+        st4(o + Cs, s2);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward phase 1: dz = du * lrelu'(a*y+b); partial sums S1 = sum dz, S2 = sum dz*xhat
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const DipGradSrc src, const float* __restrict__ y, int H,
+                                                           int W, int Cy, int C, const float* __restrict__ state,
+                                                           int Cs, float slope, float* dz, int Cdz, float* partials,
+                                                           int ppb /*pixels per block*/) {
+    __shared__ __attribute__((aligned(16))) float sh[256 * 8];
+    const RowLayout L = row_layout(C);
+    f32x4 s1 = f32x4{0.f, 0.f, 0.f, 0.f}, s2 = s1;
+    if (L.active) {
+        const int ch = L.cg * 4;
+        const f32x4 mean = ld4(state + ch), rstd = ld4(state + Cs + ch), a = ld4(state + 2 * Cs + ch),
+                    b = ld4(state + 3 * Cs + ch);
+        const int npix = H * W;
+        const int p0 = blockIdx.x * ppb;
+        const int p1 = min(p0 + ppb, npix);
+        for (int p = p0 + L.prow; p < p1; p += L.rpi) {
+            const int r = p / W, c = p - r * W;
+            const f32x4 du = grad_src4(src, r, c, H, W, ch);
+            const f32x4 yv = ld4(y + (size_t)p * Cy + ch);
+            f32x4 g;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float z = fmaf(a[e], yv[e], b[e]);
+                g[e] = z > 0.f ? du[e] : du[e] * slope;
+                const float xh = (yv[e] - mean[e]) * rstd[e];
+                s1[e] += g[e];
+                s2[e] += g[e] * xh;
+            }
+            st4(dz + (size_t)p * Cdz + ch, g);
+        }
+    }
+    block_reduce_2(L, s1, s2, partials, Cs, sh);
+}
+
+// ------------------------------------------------------------------------------------------
+// backward phase 2: reduce partials (fp64, fixed order) -> dgamma, dbeta, k1 = S1/N, k2 = S2/N
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nblk, int Cs,
+                                                              int C, int npix, float* dgamma, float* dbeta,
+                                                              float* coef) {
+    __shared__ double sh[16][16][2];
+    const int cl = threadIdx.x & 15, row = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C) {
+        for (int t = row; t < nblk; t += 16) {
+            const float* p = partials + (size_t)t * 2 * Cs + c;
+            s1 += (double)p[0];
+            s2 += (double)p[Cs];
+        }
+    }
+    sh[row][cl][0] = s1; sh[row][cl][1] = s2;
+    __syncthreads();
+    if (row == 0 && c < C) {
+        for (int r = 1; r < 16; ++r) { s1 += sh[r][cl][0]; s2 += sh[r][cl][1]; }
+        if (dbeta != nullptr) dbeta[c] = (float)s1;
+        if (dgamma != nullptr) dgamma[c] = (float)s2;
+        coef[c] = (float)(s1 / npix);
+        coef[Cs + c] = (float)(s2 / npix);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward phase 3 (in place): dy = a * (dz - k1 - xhat * k2)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* dz, int Cdz, const float* __restrict__ y, int Cy,
+                                                           int npix, int C, const float* __restrict__ state, int Cs,
+                                                           const float* __restrict__ coef, int ppb) {
+    const RowLayout L = row_layout(C);
+    if (!L.active) return;
+    const int ch = L.cg * 4;
+    const f32x4 mean = ld4(state + ch), rstd = ld4(state + Cs + ch), a = ld4(state + 2 * Cs + ch);
+    const f32x4 k1 = ld4(coef + ch), k2 = ld4(coef + Cs + ch);
+    const int p0 = blockIdx.x * ppb;
+    const int p1 = min(p0 + ppb, npix);
+    for (int p = p0 + L.prow; p < p1; p += L.rpi) {
+        f32x4 g = ld4(dz + (size_t)p * Cdz + ch);
+        const f32x4 yv = ld4(y + (size_t)p * Cy + ch);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xh = (yv[e] - mean[e]) * rstd[e];
+            g[e] = a[e] * (g[e] - k1[e] - xh * k2[e]);
+        }
+        st4(dz + (size_t)p * Cdz + ch, g);
+    }
+}
+
+// fold a padded gradient onto the image, NHWC -> NCHW
+__global__ __launch_bounds__(256) void fold_to_nchw_kernel(const DipGradSrc src, int H, int W, int C, float* dst) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= H * W) return;
+    const int r = p / W, c = p - r * W;
+    for (int ch = 0; ch < C; ch += 4) {
+        const f32x4 g = grad_src4(src, r, c, H, W, ch);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (ch + e < C) dst[(size_t)(ch + e) * H * W + p] = g[e];
+    }
+}
+
+__host__ int pixels_per_block(int npix, int C, int* nblk) {
+    // ~1024 blocks, at least 8 row-iterations each
+    const int nc4 = (C + 3) / 4;
+    int rpi = 256 / nc4;
+    if (rpi < 1) rpi = 1;
+    int ppb = dip_cdiv(npix, 1024);
+    if (ppb < rpi * 8) ppb = rpi * 8;
+    *nblk = dip_cdiv(npix, ppb);
+    return ppb;
+}
+
+}  // namespace
+
+extern "C" int dip_bn_finalize(const float* partials, int ntiles, int Cstride, int C, const float* gamma,
+                               const float* beta, float eps, float momentum, float* state, int Cs,
+                               float* running_mean, float* running_var, void* stream) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(dip_cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, partials,
+                       ntiles, Cstride, C, gamma, beta, eps, momentum, state, Cs, running_mean, running_var);
+    DIP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dip_bn_bwd_nblk(int H, int W, int C) {
+    int nblk;
+    pixels_per_block(H * W, C, &nblk);
+    return nblk;
+}
+
+extern "C" int dip_bn_bwd_stats(const DipGradSrc* src, const float* y, int H, int W, int Cy, int C,
+                                const float* state, int Cs, float slope, float* dz, int Cdz, float* partials,
+                                int nblk, void* stream) {
+    if (C > 1024) DIP_FAIL("bn_bwd_stats: C > 1024 unsupported");
+    int nb;
+    const int ppb = pixels_per_block(H * W, C, &nb);
+    if (nb != nblk) DIP_FAIL("bn_bwd_stats: nblk mismatch (use dip_bn_bwd_nblk)");
+    hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *src, y, H, W, Cy, C,
+                       state, Cs, slope, dz, Cdz, partials, ppb);
+    DIP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dip_bn_bwd_finalize(const float* partials, int nblk, int Cs, int C, int npix, float* dgamma,
+                                   float* dbeta, float* coef, void* stream) {
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(dip_cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, partials,
+                       nblk, Cs, C, npix, dgamma, dbeta, coef);
+    DIP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dip_bn_bwd_apply(float* dz, int Cdz, const float* y, int Cy, int npix, int C, const float* state,
+                                int Cs, const float* coef, void* stream) {
+    int nb;
+    const int ppb = pixels_per_block(npix, C, &nb);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dz, Cdz, y, Cy, npix, C,
+                       state, Cs, coef, ppb);
+    DIP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dip_fold_to_nchw(const DipGradSrc* src, int H, int W, int C, float* dst, void* stream) {
+    hipLaunchKernelGGL(fold_to_nchw_kernel, dim3(dip_cdiv(H * W, 256)), dim3(256), 0, (hipStream_t)stream, *src, H,
+                       W, C, dst);
+    DIP_CHECK_LAUNCH();
+    return 0;
+}

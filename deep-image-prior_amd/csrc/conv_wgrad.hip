@@ -1,0 +1,223 @@
+// Convolution weight gradient on the gfx950 fp32 matrix core.
+//
+//   dW[tap][c][o] = sum_q  u[src(q,tap)][c] * dy[q][o]          (u = transform(x), as in the forward)
+//
+// GEMM view per tap: M = input channels (32 per workgroup), N = output channels (128 per
+// workgroup, 32 per wave), K = output pixels.  A workgroup owns a [NT taps][32 c][128 o]
+// accumulator block (NT 32x32 MFMA accumulators per wave) and walks a strided list of 4x16-pixel
+// tiles ("split-K" over pixels): per tile the input halo (32 channels, producer BN+LeakyReLU
+// applied on load) and the dy tile are staged in LDS once and serve all taps.  Both MFMA operands
+// are pixel-major in LDS ([pixel][channel]), so each ds_read_b32 has the 32 lanes of a half-wave
+// on consecutive banks: conflict-free without padding.
+// Each workgroup finally writes ONE partial slab; dip_wgrad_reduce sums the slabs in a fixed
+// order (deterministic, no float atomics) straight into the OIHW gradient arena.
+#include "dip_common.h"
+
+namespace {
+
+template <int KS, int S, int NT>
+struct WCfg {
+    static constexpr int TH = 4, TW = 16, NPX = TH * TW;   // 64 output pixels per step
+    static constexpr int HTH = (TH - 1) * S + KS, HTW = (TW - 1) * S + KS;
+    static constexpr int NPIX = HTH * HTW;
+    static constexpr int U_FLOATS = NPIX * 32;
+    static constexpr int DY_FLOATS = NPX * 128;
+    static constexpr int U_SLOTS = (NPIX * 8 + 255) / 256;
+    static constexpr int LDS_BYTES = (U_FLOATS + DY_FLOATS) * 4;
+    static constexpr int NGROUPS = (KS * KS + NT - 1) / NT;
+};
+
+__device__ __forceinline__ int wmap_src(int v, int n_in, int reflect) {
+    if (reflect) v = dip_reflect(v, n_in);
+    return (v < 0 || v >= n_in) ? -1 : v;
+}
+
+template <int KS, int S, int NT>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d, const int ntx, const int ntiles,
+                                                            const int CinP, const int CoutP) {
+    using C = WCfg<KS, S, NT>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Us = smem;
+    float* Ds = smem + C::U_FLOATS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int l31 = lane & 31;
+    const int half = lane >> 5;
+
+    const int split = blockIdx.x;
+    const int cchunk = blockIdx.y;                 // 32 input channels
+    const int group = blockIdx.z % C::NGROUPS;     // tap group
+    const int nblk = blockIdx.z / C::NGROUPS;      // 128 output channels
+    const int tap0 = group * NT;
+    const int c0 = cchunk * 32;
+    const int o0 = nblk * 128;
+    const bool wave_active = (o0 + wave * 32) < CoutP;
+    const bool do_bias = (d.bias_partial != nullptr) && cchunk == 0 && group == 0;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float bsum = 0.f;
+
+    const bool has_tr = d.tr.a != nullptr;
+    const float slope = d.tr.slope;
+    const int c4 = tid & 7;                        // this thread's 4-channel group in the staging
+    const bool cvalid = (c0 + c4 * 4) < d.Cin;
+    f32x4 ta = f32x4{1.f, 1.f, 1.f, 1.f}, tb = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (has_tr && cvalid) {
+        ta = *reinterpret_cast<const f32x4*>(d.tr.a + c0 + c4 * 4);
+        tb = *reinterpret_cast<const f32x4*>(d.tr.b + c0 + c4 * 4);
+    }
+
+    for (int tile = split; tile < ntiles; tile += d.nsplit) {
+        const int ty = tile / ntx, tx = tile - ty * ntx;
+        __syncthreads();
+        // ---- stage the input halo (32 channels) ----
+#pragma unroll
+        for (int i = 0; i < C::U_SLOTS; ++i) {
+            const int f = tid + i * 256;
+            if (f < C::NPIX * 8) {
+                const int hp = f >> 3;
+                const int hr = hp / C::HTW, hc = hp - hr * C::HTW;
+                const int sr = wmap_src(ty * C::TH * S + hr - d.off, d.Hin, d.pad_mode);
+                const int sc = wmap_src(tx * C::TW * S + hc - d.off, d.Win, d.pad_mode);
+                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (sr >= 0 && sc >= 0 && cvalid) {
+                    v = *reinterpret_cast<const f32x4*>(d.x + ((size_t)sr * d.Win + sc) * d.Cx + c0 + c4 * 4);
+                    if (has_tr) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = dip_act(fmaf(ta[e], v[e], tb[e]), slope);
+                    }
+                }
+                *reinterpret_cast<f32x4*>(Us + f * 4) = v;
+            }
+        }
+        // ---- stage the dy tile: 64 pixels x 128 channels ----
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int f = tid + i * 256;           // float4 index: pixel = f >> 5, o4 = f & 31
+            const int px = f >> 5, o4 = f & 31;
+            const int oy = ty * C::TH + (px >> 4), ox = tx * C::TW + (px & 15);
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int o = o0 + o4 * 4;
+            if (oy < d.Hout && ox < d.Wout && o < d.Cdy)
+                v = *reinterpret_cast<const f32x4*>(d.dy + ((size_t)oy * d.Wout + ox) * d.Cdy + o);
+            *reinterpret_cast<f32x4*>(Ds + f * 4) = v;
+        }
+        __syncthreads();
+        if (wave_active) {
+            for (int s = 0; s < C::NPX / 2; ++s) {
+                const int px = 2 * s + half;
+                const int r = px >> 4, c = px & 15;
+                const float b = Ds[px * 128 + wave * 32 + l31];
+                bsum += b;
+                const float* ub = Us + ((r * S) * C::HTW + c * S) * 32 + l31;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int tap = tap0 + t;
+                    if (tap < KS * KS) {
+                        const int ky = tap / KS, kx = tap - ky * KS;
+                        const float a = ub[(ky * C::HTW + kx) * 32];
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- write this workgroup's partial slab ----
+    if (wave_active) {
+        const int o = o0 + wave * 32 + l31;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int tap = tap0 + t;
+            if (tap < KS * KS) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (c < CinP)
+                        d.partial[(((size_t)split * (KS * KS) + tap) * CinP + c) * CoutP + o] = acc[t][r];
+                }
+            }
+        }
+        if (do_bias) {
+            const float tot = bsum + __shfl_xor(bsum, 32);
+            if (half == 0) d.bias_partial[(size_t)split * CoutP + o] = tot;
+        }
+    }
+}
+
+template <int KS, int S, int NT>
+int launch(const DipWgradDesc& d, hipStream_t st) {
+    using C = WCfg<KS, S, NT>;
+    static bool attr_set = false;
+    auto kern = conv_wgrad_kernel<KS, S, NT>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e != hipSuccess) { dip_set_error(hipGetErrorString(e)); return (int)e; }
+        attr_set = true;
+    }
+    const int ntx = dip_cdiv(d.Wout, C::TW), nty = dip_cdiv(d.Hout, C::TH);
+    const int ntiles = ntx * nty;
+    const int CinP = dip_round_up(d.Cin, 32), CoutP = dip_round_up(d.Cout, 32);
+    if (d.nsplit < 1 || d.nsplit > ntiles) DIP_FAIL("conv_wgrad: nsplit out of range");
+    dim3 grid(d.nsplit, CinP / 32, C::NGROUPS * dip_cdiv(CoutP, 128));
+    hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, st, d, ntx, ntiles, CinP, CoutP);
+    DIP_CHECK_LAUNCH();
+    return 0;
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bias_partial,
+                                    int nsplit, int KK, int Cin, int Cout, int CinP, int CoutP, float* dw,
+                                    float* dbias) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = KK * Cin * Cout;
+    if (id < total) {
+        const int o = id % Cout;
+        const int c = (id / Cout) % Cin;
+        const int tap = id / (Cout * Cin);
+        const size_t slab = (size_t)KK * CinP * CoutP;
+        const float* p = partial + ((size_t)tap * CinP + c) * CoutP + o;
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += p[k * slab];
+        dw[((size_t)o * Cin + c) * KK + tap] = s;
+    } else if (dbias != nullptr && id < total + Cout) {
+        const int o = id - total;
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += bias_partial[(size_t)k * CoutP + o];
+        dbias[o] = s;
+    }
+}
+
+}  // namespace
+
+extern "C" int dip_conv_wgrad_ntiles(int Hout, int Wout) { return dip_cdiv(Wout, 16) * dip_cdiv(Hout, 4); }
+
+extern "C" int dip_conv_wgrad(const DipWgradDesc* dp, void* stream) {
+    const DipWgradDesc& d = *dp;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if ((d.Cx & 3) || (d.Cdy & 3)) DIP_FAIL("conv_wgrad: channel strides must be multiples of 4");
+    if (d.ks == 1 && d.stride == 1) return launch<1, 1, 1>(d, st);
+    if (d.ks == 3 && d.stride == 1) return launch<3, 1, 9>(d, st);
+    if (d.ks == 3 && d.stride == 2) return launch<3, 2, 9>(d, st);
+    if (d.ks == 5 && d.stride == 1) return launch<5, 1, 5>(d, st);
+    if (d.ks == 5 && d.stride == 2) return launch<5, 2, 5>(d, st);
+    DIP_FAIL("conv_wgrad: unsupported kernel size / stride");
+}
+
+extern "C" int dip_wgrad_reduce(const float* partial, const float* bias_partial, int nsplit, int ks, int Cin,
+                                int Cout, float* dw, float* dbias, void* stream) {
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int KK = ks * ks;
+    const int CinP = dip_round_up(Cin, 32), CoutP = dip_round_up(Cout, 32);
+    const int total = KK * Cin * Cout + (dbias ? Cout : 0);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dip_cdiv(total, 256)), dim3(256), 0, st, partial,
+                       dbias ? bias_partial : nullptr, nsplit, KK, Cin, Cout, CinP, CoutP, dw, dbias);
+    DIP_CHECK_LAUNCH();
+    return 0;
+}

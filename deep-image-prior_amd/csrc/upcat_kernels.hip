@@ -1,0 +1,251 @@
+// 2x upsample (bilinear align_corners=False / nearest) + channel concat + BatchNorm partial
+// statistics (forward), and the adjoint gather fused with LeakyReLU backward + BatchNorm backward
+// phase 1 (backward).  HBM-bound, float4 per lane, NHWC.
+#include "dip_common.h"
+
+namespace {
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+__device__ __forceinline__ f32x4 tr4(f32x4 x, const DipTransform& t, int ch) {
+    if (t.a == nullptr) return x;
+    const f32x4 a = ld4(t.a + ch), b = ld4(t.b + ch);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = dip_act(fmaf(a[e], x[e], b[e]), t.slope);
+    return o;
+}
+
+// PyTorch upsample_bilinear2d source index, align_corners=False, scale 0.5 (src per dst)
+__device__ __forceinline__ void bil_src(int dst, int n_in, int& i0, int& i1, float& l0, float& l1) {
+    float real = 0.5f * ((float)dst + 0.5f) - 0.5f;
+    if (real < 0.f) real = 0.f;
+    i0 = (int)real;
+    i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+    l1 = real - (float)i0;
+    l0 = 1.f - l1;
+}
+
+struct RowLayout {
+    int nc4, rpi, prow, cg;
+    bool active;
+};
+__device__ __forceinline__ RowLayout row_layout(int C) {
+    RowLayout L;
+    L.nc4 = (C + 3) >> 2;
+    L.rpi = 256 / L.nc4;
+    if (L.rpi < 1) L.rpi = 1;
+    L.prow = threadIdx.x / L.nc4;
+    L.cg = threadIdx.x - L.prow * L.nc4;
+    L.active = (int)threadIdx.x < L.rpi * L.nc4;
+    return L;
+}
+
+__global__ __launch_bounds__(256) void upcat_fwd_kernel(const DipUpcatDesc d, int ppb) {
+    __shared__ __attribute__((aligned(16))) float sh[256 * 12];
+    const int C = d.ns + d.nd;
+    const RowLayout L = row_layout(C);
+    // shifted sums per thread, 4 channels
+    f32x4 cnt = f32x4{0.f, 0.f, 0.f, 0.f}, K = cnt, s1 = cnt, s2 = cnt;
+    float n = 0.f;
+    if (L.active) {
+        const int ch = L.cg * 4;
+        const int npix = d.H * d.W;
+        const int p0 = blockIdx.x * ppb, p1 = min(p0 + ppb, npix);
+        const int Hl = d.H >> 1, Wl = d.W >> 1;
+        for (int p = p0 + L.prow; p < p1; p += L.rpi) {
+            f32x4 v;
+            if (ch < d.ns) {
+                v = tr4(ld4(d.s + (size_t)p * d.Cs_s + ch), d.ts, ch);
+            } else {
+                const int cd = ch - d.ns;
+                const int r = p / d.W, c = p - r * d.W;
+                if (d.mode == DIP_UP_NEAREST) {
+                    v = tr4(ld4(d.d + ((size_t)(r >> 1) * Wl + (c >> 1)) * d.Cs_d + cd), d.td, cd);
+                } else {
+                    int r0, r1, c0, c1;
+                    float lr0, lr1, lc0, lc1;
+                    bil_src(r, Hl, r0, r1, lr0, lr1);
+                    bil_src(c, Wl, c0, c1, lc0, lc1);
+                    const f32x4 v00 = tr4(ld4(d.d + ((size_t)r0 * Wl + c0) * d.Cs_d + cd), d.td, cd);
+                    const f32x4 v01 = tr4(ld4(d.d + ((size_t)r0 * Wl + c1) * d.Cs_d + cd), d.td, cd);
+                    const f32x4 v10 = tr4(ld4(d.d + ((size_t)r1 * Wl + c0) * d.Cs_d + cd), d.td, cd);
+                    const f32x4 v11 = tr4(ld4(d.d + ((size_t)r1 * Wl + c1) * d.Cs_d + cd), d.td, cd);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        v[e] = lr0 * (lc0 * v00[e] + lc1 * v01[e]) + lr1 * (lc0 * v10[e] + lc1 * v11[e]);
+                }
+            }
+            st4(d.cat + (size_t)p * d.Cs_cat + ch, v);
+            if (n == 0.f) K = v;
+            n += 1.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float dv = v[e] - K[e];
+                s1[e] += dv;
+                s2[e] += dv * dv;
+            }
+        }
+    }
+    // per-thread (n, mean, M2) -> LDS -> Chan-combine over prow
+    f32x4 mean = f32x4{0.f, 0.f, 0.f, 0.f}, M2 = mean;
+    if (n > 0.f) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            mean[e] = K[e] + s1[e] / n;
+            M2[e] = s2[e] - s1[e] * s1[e] / n;
+        }
+    }
+    sh[threadIdx.x * 12] = n;
+    st4(sh + threadIdx.x * 12 + 4, mean);
+    st4(sh + threadIdx.x * 12 + 8, M2);
+    __syncthreads();
+    if (L.active && L.prow == 0) {
+        float na[4] = {n, n, n, n};
+        for (int r = 1; r < L.rpi; ++r) {
+            const float* q = sh + (r * L.nc4 + L.cg) * 12;
+            const float nb = q[0];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float me = mean[e], Me = M2[e];
+                dip_chan(na[e], me, Me, nb, q[4 + e], q[8 + e]);
+                mean[e] = me; M2[e] = Me;
+            }
+        }
+        float* o = d.stats + (size_t)blockIdx.x * 3 * d.Cs_cat + L.cg * 4;
+        st4(o, f32x4{na[0], na[1], na[2], na[3]});
+        st4(o + d.Cs_cat, mean);
+        st4(o + 2 * d.Cs_cat, M2);
+    }
+}
+
+// low-res pixel (i,j): du = sum over the <=4x4 high-res pixels whose interpolation touches it
+__global__ __launch_bounds__(256) void upsample_bwd_stats_kernel(const float* __restrict__ dcat, int Cs_cat, int choff,
+                                                                 int H, int W, int mode, const float* __restrict__ y,
+                                                                 int Cy, int C, const float* __restrict__ state, int Cs,
+                                                                 float slope, float* dz, int Cdz, float* partials,
+                                                                 int ppb) {
+    __shared__ __attribute__((aligned(16))) float sh[256 * 8];
+    const RowLayout L = row_layout(C);
+    f32x4 s1 = f32x4{0.f, 0.f, 0.f, 0.f}, s2 = s1;
+    const int Hl = H >> 1, Wl = W >> 1;
+    if (L.active) {
+        const int ch = L.cg * 4;
+        const f32x4 mean = ld4(state + ch), rstd = ld4(state + Cs + ch), a = ld4(state + 2 * Cs + ch),
+                    b = ld4(state + 3 * Cs + ch);
+        const int npix = Hl * Wl;
+        const int p0 = blockIdx.x * ppb, p1 = min(p0 + ppb, npix);
+        for (int p = p0 + L.prow; p < p1; p += L.rpi) {
+            const int i = p / Wl, j = p - i * Wl;
+            f32x4 du = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (mode == DIP_UP_NEAREST) {
+#pragma unroll
+                for (int dr = 0; dr < 2; ++dr)
+#pragma unroll
+                    for (int dc = 0; dc < 2; ++dc)
+                        du += ld4(dcat + ((size_t)(2 * i + dr) * W + (2 * j + dc)) * Cs_cat + choff + ch);
+            } else {
+                float wr[4], wc[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    int i0, i1;
+                    float l0, l1;
+                    const int hr = 2 * i - 1 + t;
+                    wr[t] = 0.f;
+                    if (hr >= 0 && hr < H) {
+                        bil_src(hr, Hl, i0, i1, l0, l1);
+                        wr[t] = (i0 == i ? l0 : 0.f) + (i1 == i ? l1 : 0.f);
+                    }
+                    const int hc = 2 * j - 1 + t;
+                    wc[t] = 0.f;
+                    if (hc >= 0 && hc < W) {
+                        bil_src(hc, Wl, i0, i1, l0, l1);
+                        wc[t] = (i0 == j ? l0 : 0.f) + (i1 == j ? l1 : 0.f);
+                    }
+                }
+#pragma unroll
+                for (int tr = 0; tr < 4; ++tr) {
+                    if (wr[tr] == 0.f) continue;
+                    const int hr = 2 * i - 1 + tr;
+#pragma unroll
+                    for (int tc = 0; tc < 4; ++tc) {
+                        if (wc[tc] == 0.f) continue;
+                        const int hc = 2 * j - 1 + tc;
+                        const f32x4 g = ld4(dcat + ((size_t)hr * W + hc) * Cs_cat + choff + ch);
+                        const float w = wr[tr] * wc[tc];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) du[e] = fmaf(w, g[e], du[e]);
+                    }
+                }
+            }
+            const f32x4 yv = ld4(y + (size_t)p * Cy + ch);
+            f32x4 g;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float z = fmaf(a[e], yv[e], b[e]);
+                g[e] = z > 0.f ? du[e] : du[e] * slope;
+                const float xh = (yv[e] - mean[e]) * rstd[e];
+                s1[e] += g[e];
+                s2[e] += g[e] * xh;
+            }
+            st4(dz + (size_t)p * Cdz + ch, g);
+        }
+    }
+    st4(sh + threadIdx.x * 8, s1);
+    st4(sh + threadIdx.x * 8 + 4, s2);
+    __syncthreads();
+    if (L.active && L.prow == 0) {
+        for (int r = 1; r < L.rpi; ++r) {
+            s1 += ld4(sh + (r * L.nc4 + L.cg) * 8);
+            s2 += ld4(sh + (r * L.nc4 + L.cg) * 8 + 4);
+        }
+        float* o = partials + (size_t)blockIdx.x * 2 * Cs + L.cg * 4;
+        st4(o, s1);
+        st4(o + Cs, s2);
+    }
+}
+
+int pixels_per_block(int npix, int C, int* nblk) {
+    const int nc4 = (C + 3) / 4;
+    int rpi = 256 / nc4;
+    if (rpi < 1) rpi = 1;
+    int ppb = dip_cdiv(npix, 1024);
+    if (ppb < rpi * 8) ppb = rpi * 8;
+    *nblk = dip_cdiv(npix, ppb);
+    return ppb;
+}
+
+}  // namespace
+
+extern "C" int dip_upcat_nblk(int H, int W, int C) {
+    int nblk;
+    pixels_per_block(H * W, C, &nblk);
+    return nblk;
+}
+
+extern "C" int dip_upcat_fwd(const DipUpcatDesc* d, void* stream) {
+    const int C = d->ns + d->nd;
+    if ((d->ns & 3) || (d->nd & 3)) DIP_FAIL("upcat_fwd: channel counts must be multiples of 4");
+    if ((d->H & 1) || (d->W & 1)) DIP_FAIL("upcat_fwd: output size must be even");
+    if (C > 1024) DIP_FAIL("upcat_fwd: C > 1024 unsupported");
+    int nb;
+    const int ppb = pixels_per_block(d->H * d->W, C, &nb);
+    if (nb != d->nblk) DIP_FAIL("upcat_fwd: nblk mismatch (use dip_upcat_nblk)");
+    hipLaunchKernelGGL(upcat_fwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *d, ppb);
+    DIP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dip_upsample_bwd_stats(const float* dcat, int Cs_cat, int choff, int H, int W, int mode,
+                                      const float* y, int Cy, int C, const float* state, int Cs, float slope,
+                                      float* dz, int Cdz, float* partials, int nblk, void* stream) {
+    if (C > 1024) DIP_FAIL("upsample_bwd_stats: C > 1024 unsupported");
+    int nb;
+    const int ppb = pixels_per_block((H / 2) * (W / 2), C, &nb);
+    if (nb != nblk) DIP_FAIL("upsample_bwd_stats: nblk mismatch (use dip_bn_bwd_nblk(H/2, W/2, C))");
+    hipLaunchKernelGGL(upsample_bwd_stats_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dcat, Cs_cat, choff, H,
+                       W, mode, y, Cy, C, state, Cs, slope, dz, Cdz, partials, ppb);
+    DIP_CHECK_LAUNCH();
+    return 0;
+}

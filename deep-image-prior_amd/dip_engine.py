@@ -1,0 +1,599 @@
+"""Execution engine: compiles a `skip()` module tree (models/skip.py) into a static list of
+libdip_hip.so kernel launches for forward and backward, and exposes it to autograd as ONE
+`torch.autograd.Function`, so the reference's closure-style loop (`out = net(z); loss(...)
+.backward(); optimizer.step()`, utils/common_utils.py:223-230 of the reference) runs unchanged.
+
+MI355X-first design:
+  * activations live in HBM as NHWC fp32, channel stride padded to 4; every conv is an
+    implicit-GEMM on the fp32 MFMA with the PRODUCER's BatchNorm-apply + LeakyReLU and the
+    padding fused into its loader and the CONSUMER BatchNorm's statistics fused into its epilogue;
+  * parameters, gradients, Adam moments and BatchNorm running stats are flat arenas; the
+    nn.Parameters the user sees are views into them (state_dict()/load_state_dict()/.data.copy_()
+    keep working), and one fused launch steps Adam over the whole arena;
+  * all buffers are allocated once per input size; the launch list is static (hipGraph-capturable).
+
+PyTorch is used for device memory, streams and the autograd boundary only.  There is no eager
+fallback: a missing libdip_hip.so or an unsupported option raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import torch
+
+import dip_native as N
+from dip_native import round_up
+
+
+def _ptr(t: Optional[torch.Tensor], off_floats: int = 0) -> Optional[int]:
+    if t is None:
+        return None
+    return t.data_ptr() + 4 * off_floats
+
+
+class BNRec:
+    """One BatchNorm2d (train mode): parameters in the arena + a device state block
+    [mean, rstd, a, b] x Cs and backward coefficients [k1, k2] x Cs."""
+
+    def __init__(self, module: torch.nn.BatchNorm2d, name: str):
+        self.module = module
+        self.name = name
+        self.C = module.num_features
+        self.Cs = round_up(self.C, 4)
+        self.gamma_off = self.beta_off = -1
+        self.rm_off = self.rv_off = -1
+        self.state = None
+        self.coef = None
+
+
+class ConvRec:
+    def __init__(self, module: torch.nn.Conv2d, pad_mode: int, name: str):
+        self.module = module
+        self.name = name
+        self.Cin, self.Cout = module.in_channels, module.out_channels
+        self.ks = module.kernel_size[0]
+        self.stride = module.stride[0]
+        self.P = (self.ks - 1) // 2
+        self.pad_mode = pad_mode if self.P > 0 else N.PAD_ZERO
+        self.w_off = self.b_off = -1
+        self.fwd_off = self.dgrad_off = -1
+        self.need_dgrad = True
+
+    @property
+    def fwd_elems(self):
+        return self.ks * self.ks * round_up(self.Cin, 4) * round_up(self.Cout, 32)
+
+    @property
+    def dgrad_elems(self):
+        return self.ks * self.ks * round_up(self.Cout, 4) * round_up(self.Cin, 32)
+
+
+class Act:
+    """An activation as a consumer sees it: raw NHWC buffer + the (BatchNorm, LeakyReLU slope)
+    that the consumer's loader applies on the fly."""
+
+    def __init__(self, buf, H, W, Cch, bn: Optional[BNRec] = None, slope: float = 1.0):
+        self.buf, self.H, self.W, self.C = buf, H, W, Cch
+        self.Cs = round_up(Cch, 4)
+        self.bn, self.slope = bn, slope
+
+    def transform(self) -> N.DipTransform:
+        if self.bn is None:
+            return N.DipTransform(None, None, 1.0)
+        assert self.bn.Cs == self.Cs
+        return N.DipTransform(_ptr(self.bn.state, 2 * self.Cs), _ptr(self.bn.state, 3 * self.Cs), self.slope)
+
+
+class ScalePlan:
+    """Module handles of one scale of the hour-glass (filled by models.skip.skip())."""
+
+    def __init__(self):
+        self.skip_conv = self.skip_bn = None
+        self.down_a = self.down_a_bn = self.down_b = self.down_b_bn = None
+        self.cat_bn = self.up = self.up_bn = self.up1 = self.up1_bn = None
+        self.ns = 0
+        self.upsample_mode = "nearest"
+
+
+class SkipEngine:
+    def __init__(self, net, scales: List[ScalePlan], out_conv: torch.nn.Conv2d, need_sigmoid: bool, pad: str,
+                 act_slope: float = 0.2):
+        self.net = net
+        self.need_sigmoid = need_sigmoid
+        self.pad_mode = N.PAD_REFLECT if pad == "reflection" else N.PAD_ZERO
+        self.slope = act_slope
+        self.nscales = len(scales)
+        self.fwd_id = 0
+        self.device = None
+        self.shape_key = None
+        self.lib = None
+
+        # records in a fixed traversal order
+        self.convs: List[ConvRec] = []
+        self.bns: List[BNRec] = []
+        self.sc = []
+        for i, s in enumerate(scales):
+            rec = ScalePlan()
+            rec.ns, rec.upsample_mode = s.ns, s.upsample_mode
+            for attr in ("skip_conv", "down_a", "down_b", "up", "up1"):
+                m = getattr(s, attr)
+                if m is not None:
+                    r = ConvRec(m, self.pad_mode, f"s{i}.{attr}")
+                    self.convs.append(r)
+                    setattr(rec, attr, r)
+            for attr in ("skip_bn", "down_a_bn", "down_b_bn", "cat_bn", "up_bn", "up1_bn"):
+                m = getattr(s, attr)
+                if m is not None:
+                    r = BNRec(m, f"s{i}.{attr}")
+                    self.bns.append(r)
+                    setattr(rec, attr, r)
+            self.sc.append(rec)
+        self.out_conv = ConvRec(out_conv, self.pad_mode, "out")
+        self.convs.append(self.out_conv)
+        # the two convs reading net_input need no data gradient unless the input is optimised
+        self.param_list = list(net.parameters())
+        self._check_supported()
+
+    # ------------------------------------------------------------------ support matrix
+    def _check_supported(self):
+        for r in self.convs:
+            if r.ks not in (1, 3, 5) or r.stride not in (1, 2) or (r.ks == 1 and r.stride != 1):
+                raise NotImplementedError(f"dip-amd: conv {r.name} k={r.ks} s={r.stride} has no gfx950 kernel")
+            m = r.module
+            if m.dilation != (1, 1) or m.groups != 1 or m.kernel_size[0] != m.kernel_size[1]:
+                raise NotImplementedError(f"dip-amd: conv {r.name}: dilation/groups/non-square unsupported")
+        for i, s in enumerate(self.sc):
+            if s.ns % 4 or s.down_b.Cout % 4 or s.up.Cout % 4 or (s.up.Cin % 4):
+                raise NotImplementedError("dip-amd: internal channel counts must be multiples of 4")
+            if s.skip_conv is not None and s.skip_conv.ks != 1:
+                raise NotImplementedError("dip-amd: filter_skip_size != 1 unsupported")
+
+    # ------------------------------------------------------------------ arenas
+    def _build_arenas(self, device):
+        self.lib = N.lib()
+        self.device = device
+        params = self.param_list
+        off = 0
+        slots = []
+        for p in params:
+            slots.append(off)
+            off += round_up(p.numel(), 4)
+        self.n_arena = off
+        self.params = torch.zeros(off, dtype=torch.float32, device=device)
+        self.grads = torch.zeros(off, dtype=torch.float32, device=device)
+        self.slots = slots
+        with torch.no_grad():
+            for p, o in zip(params, slots):
+                n = p.numel()
+                self.params[o:o + n].copy_(p.detach().reshape(-1).to(device=device, dtype=torch.float32))
+                p.data = self.params[o:o + n].view(p.shape)
+        pid = {id(p): o for p, o in zip(params, slots)}
+        for r in self.convs:
+            r.w_off = pid[id(r.module.weight)]
+            r.b_off = pid[id(r.module.bias)] if r.module.bias is not None else -1
+        # BatchNorm buffers arena
+        nb = sum(2 * b.Cs for b in self.bns)
+        self.bnbuf = torch.zeros(max(nb, 4), dtype=torch.float32, device=device)
+        self.nbt = torch.zeros(max(len(self.bns), 1), dtype=torch.int64, device=device)
+        o = 0
+        with torch.no_grad():
+            for k, b in enumerate(self.bns):
+                m = b.module
+                b.gamma_off, b.beta_off = pid[id(m.weight)], pid[id(m.bias)]
+                if m.track_running_stats and m.running_mean is not None:
+                    b.rm_off, b.rv_off = o, o + b.Cs
+                    self.bnbuf[o:o + b.C].copy_(m.running_mean.to(device))
+                    self.bnbuf[o + b.Cs:o + b.Cs + b.C].copy_(m.running_var.to(device))
+                    m._buffers["running_mean"] = self.bnbuf[o:o + b.C]
+                    m._buffers["running_var"] = self.bnbuf[o + b.Cs:o + b.Cs + b.C]
+                    self.nbt[k] = m.num_batches_tracked.to(device)
+                    m._buffers["num_batches_tracked"] = self.nbt[k]
+                o += 2 * b.Cs
+                b.state = torch.zeros(4 * b.Cs, dtype=torch.float32, device=device)
+                b.coef = torch.zeros(2 * b.Cs, dtype=torch.float32, device=device)
+        # packed weights
+        off = 0
+        recs = (N.DipPackRec * len(self.convs))()
+        max_elems = 0
+        for k, r in enumerate(self.convs):
+            r.fwd_off = off
+            off += r.fwd_elems
+            r.dgrad_off = off
+            off += r.dgrad_elems
+            recs[k] = N.DipPackRec(r.w_off, r.fwd_off, r.dgrad_off, r.Cout, r.Cin, r.ks, round_up(r.Cin, 4),
+                                   round_up(r.Cout, 32), round_up(r.Cout, 4), round_up(r.Cin, 32))
+            max_elems = max(max_elems, r.fwd_elems + r.dgrad_elems)
+        self.packed = torch.zeros(off, dtype=torch.float32, device=device)
+        raw = bytes(recs)
+        self.pack_recs = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+        self.pack_max = max_elems
+        self.shape_key = None
+
+    def _arena_ok(self) -> bool:
+        if self.device is None:
+            return False
+        base = self.params.data_ptr()
+        for p, o in zip(self.param_list, self.slots):
+            if p.data_ptr() != base + 4 * o:
+                return False
+        return True
+
+    # ------------------------------------------------------------------ per-shape plan
+    def _new(self, *shape):
+        return torch.empty(shape, dtype=torch.float32, device=self.device)
+
+    def _build_plan(self, H, W, Cin_img):
+        div = 2 ** self.nscales
+        if H % div or W % div:
+            raise NotImplementedError(
+                f"dip-amd: input {H}x{W} must be divisible by 2^{self.nscales} (ragged Concat crop, "
+                "models/common.py:29-37 of the reference, is not implemented)")
+        self.H, self.W, self.Cimg = H, W, Cin_img
+        self.stat_need = self.wg_need = self.wgb_need = self.bwdp_need = 4
+        oc = self.out_conv
+        self.n_out = oc.Cout
+        # The plan is generated twice: a sizing pass (no allocations, no descriptors) that only
+        # measures the shared scratch buffers, then the emitting pass.
+        for sizing in (True, False):
+            self._sizing = sizing
+            self.fwd_ops, self.bwd_ops, self.bwd_input_ops, self.keep = [], [], [], []
+            if not sizing:
+                self.stats_scratch = self._new(self.stat_need)
+                self.bwd_scratch = self._new(self.bwdp_need)
+                self.wg_scratch = self._new(self.wg_need)
+                self.wgb_scratch = self._new(self.wgb_need)
+            self.x_nhwc = self._buf(H * W * round_up(Cin_img, 4))
+            xin = Act(self.x_nhwc, H, W, Cin_img)
+            last = self._plan_scale(0, xin, H, W)
+            # output conv (no BatchNorm) + sigmoid head
+            self.y_out = self._buf(H * W * round_up(oc.Cout, 4))
+            self._emit_conv_fwd(oc, last, self.y_out, None)
+            # backward: head, out conv, then the scales from the top
+            self.dy_out = self._buf(H * W * round_up(oc.Cout, 4))
+            pre = []
+            self._emit_wgrad(oc, last, self.dy_out, pre)
+            du_last = self._emit_dgrad(oc, last, self.dy_out, pre)
+            dy_last = self._emit_bn_act_bwd(last, du_last, pre)
+            self.bwd_ops = pre + self._bwd_scale_ops(0, dy_last)
+        self.shape_key = (H, W, Cin_img)
+
+    def _plan_scale(self, i, xin: Act, H, W):
+        s = self.sc[i]
+        st = {}
+        Hl, Wl = H // 2, W // 2
+        if s.ns:
+            st["s_y"] = self._buf(H * W * round_up(s.ns, 4))
+            self._emit_conv_fwd(s.skip_conv, xin, st["s_y"], s.skip_bn)
+            st["s_act"] = Act(st["s_y"], H, W, s.ns, s.skip_bn, self.slope)
+        st["d1_y"] = self._buf(Hl * Wl * round_up(s.down_a.Cout, 4))
+        self._emit_conv_fwd(s.down_a, xin, st["d1_y"], s.down_a_bn)
+        d1 = Act(st["d1_y"], Hl, Wl, s.down_a.Cout, s.down_a_bn, self.slope)
+        st["d2_y"] = self._buf(Hl * Wl * round_up(s.down_b.Cout, 4))
+        self._emit_conv_fwd(s.down_b, d1, st["d2_y"], s.down_b_bn)
+        d2 = Act(st["d2_y"], Hl, Wl, s.down_b.Cout, s.down_b_bn, self.slope)
+        st["d1"], st["d2"] = d1, d2
+        deep = d2
+        if i < self.nscales - 1:
+            deep = self._plan_scale(i + 1, d2, Hl, Wl)
+        st["deep"] = deep
+        ccat = s.ns + deep.C
+        assert ccat == s.cat_bn.C == s.up.Cin, (ccat, s.cat_bn.C, s.up.Cin)
+        st["cat"] = self._buf(H * W * round_up(ccat, 4))
+        self._emit_upcat(s, st.get("s_act"), deep, st["cat"], H, W)
+        cat = Act(st["cat"], H, W, ccat, s.cat_bn, 1.0)
+        st["cat_act"] = cat
+        st["u_y"] = self._buf(H * W * round_up(s.up.Cout, 4))
+        self._emit_conv_fwd(s.up, cat, st["u_y"], s.up_bn)
+        u = Act(st["u_y"], H, W, s.up.Cout, s.up_bn, self.slope)
+        st["u"] = u
+        res = u
+        if s.up1 is not None:
+            st["u1_y"] = self._buf(H * W * round_up(s.up1.Cout, 4))
+            self._emit_conv_fwd(s.up1, u, st["u1_y"], s.up1_bn)
+            res = Act(st["u1_y"], H, W, s.up1.Cout, s.up1_bn, self.slope)
+        st["xin"], st["H"], st["W"] = xin, H, W
+        s.st = st
+        return res
+
+    def _buf(self, n):
+        return None if self._sizing else self._new(n)
+
+    # ------------------------------------------------------------------ op emitters
+    def _emit_conv_fwd(self, r: ConvRec, x: Act, y, bn: Optional[BNRec]):
+        assert x.C == r.Cin, (r.name, x.C, r.Cin)
+        Ho = (x.H + 2 * r.P - r.ks) // r.stride + 1
+        Wo = (x.W + 2 * r.P - r.ks) // r.stride + 1
+        ntiles = self.lib.dip_conv_ntiles(Ho, Wo)
+        if bn is not None:
+            need = ntiles * 3 * round_up(r.Cout, 32)
+            if self._sizing:
+                self.stat_need = max(self.stat_need, need)
+        if self._sizing:
+            return
+        Cy = round_up(r.Cout, 4)
+        d = N.DipConvDesc(_ptr(x.buf), x.H, x.W, x.Cs, round_up(x.C, 4), x.transform(),
+                          _ptr(self.packed, r.fwd_off), _ptr(self.params, r.b_off) if r.b_off >= 0 else None,
+                          _ptr(y), Ho, Wo, Cy, r.Cout, 0, r.ks, r.stride, r.pad_mode, r.P, 1, 0,
+                          _ptr(self.stats_scratch) if bn is not None else None)
+        self.keep.append(d)
+        lib = self.lib
+        self.fwd_ops.append((lib.dip_conv_igemm, (C.byref(d),), "conv_fwd:" + r.name))
+        if bn is not None:
+            m = bn.module
+            args = (_ptr(self.stats_scratch), ntiles, round_up(r.Cout, 32), bn.C, _ptr(self.params, bn.gamma_off),
+                    _ptr(self.params, bn.beta_off), float(m.eps), float(m.momentum if m.momentum is not None else 0.1),
+                    _ptr(bn.state), bn.Cs,
+                    _ptr(self.bnbuf, bn.rm_off) if bn.rm_off >= 0 else None,
+                    _ptr(self.bnbuf, bn.rv_off) if bn.rv_off >= 0 else None)
+            self.fwd_ops.append((lib.dip_bn_finalize, args, "bn_fin:" + bn.name))
+
+    def _emit_upcat(self, s, s_act: Optional[Act], deep: Act, cat, H, W):
+        Ccat = s.ns + deep.C
+        Cs_cat = round_up(Ccat, 4)
+        nblk = self.lib.dip_upcat_nblk(H, W, Ccat)
+        if self._sizing:
+            self.stat_need = max(self.stat_need, nblk * 3 * Cs_cat)
+            return
+        mode = N.UP_BILINEAR if s.upsample_mode == "bilinear" else N.UP_NEAREST
+        d = N.DipUpcatDesc(_ptr(s_act.buf) if s_act else None, s_act.Cs if s_act else 4, s.ns,
+                           s_act.transform() if s_act else N.DipTransform(None, None, 1.0),
+                           _ptr(deep.buf), deep.Cs, deep.C, deep.transform(), H, W, mode, _ptr(cat), Cs_cat,
+                           _ptr(self.stats_scratch), nblk)
+        self.keep.append(d)
+        bn = s.cat_bn
+        m = bn.module
+        self.fwd_ops.append((self.lib.dip_upcat_fwd, (C.byref(d),), "upcat:" + bn.name))
+        args = (_ptr(self.stats_scratch), nblk, Cs_cat, bn.C, _ptr(self.params, bn.gamma_off),
+                _ptr(self.params, bn.beta_off), float(m.eps), float(m.momentum if m.momentum is not None else 0.1),
+                _ptr(bn.state), bn.Cs,
+                _ptr(self.bnbuf, bn.rm_off) if bn.rm_off >= 0 else None,
+                _ptr(self.bnbuf, bn.rv_off) if bn.rv_off >= 0 else None)
+        self.fwd_ops.append((self.lib.dip_bn_finalize, args, "bn_fin:" + bn.name))
+
+    def _emit_wgrad(self, r: ConvRec, x: Act, dy, ops):
+        Ho = (x.H + 2 * r.P - r.ks) // r.stride + 1
+        Wo = (x.W + 2 * r.P - r.ks) // r.stride + 1
+        CinP, CoutP = round_up(r.Cin, 32), round_up(r.Cout, 32)
+        nt = self.lib.dip_conv_wgrad_ntiles(Ho, Wo)
+        groups = {1: 1, 3: 1, 5: 5}[r.ks]
+        wgs_per_split = (CinP // 32) * groups * ((CoutP + 127) // 128)
+        nsplit = max(1, min(nt, 512 // max(1, wgs_per_split)))
+        slab = r.ks * r.ks * CinP * CoutP
+        while nsplit > 1 and nsplit * slab > (64 << 20):       # <= 256 MB of partials
+            nsplit //= 2
+        if self._sizing:
+            self.wg_need = max(self.wg_need, nsplit * slab)
+            self.wgb_need = max(self.wgb_need, nsplit * CoutP)
+            return
+        has_b = r.b_off >= 0
+        d = N.DipWgradDesc(_ptr(x.buf), x.H, x.W, x.Cs, x.C, x.transform(), _ptr(dy), Ho, Wo,
+                           round_up(r.Cout, 4), r.Cout, r.ks, r.stride, r.pad_mode, r.P,
+                           _ptr(self.wg_scratch), _ptr(self.wgb_scratch) if has_b else None, nsplit)
+        self.keep.append(d)
+        ops.append((self.lib.dip_conv_wgrad, (C.byref(d),), "wgrad:" + r.name))
+        ops.append((self.lib.dip_wgrad_reduce,
+                    (_ptr(self.wg_scratch), _ptr(self.wgb_scratch) if has_b else None, nsplit, r.ks, r.Cin, r.Cout,
+                     _ptr(self.grads, r.w_off), _ptr(self.grads, r.b_off) if has_b else None), "wgred:" + r.name))
+
+    def _emit_dgrad(self, r: ConvRec, x: Act, dy, ops, accumulate_into=None):
+        """Data gradient of conv r wrt its input x.  Returns a DipGradSrc-describing tuple
+        (buf, pad, fold).  accumulate_into = (buf, pad): add a 1x1 conv's gradient into the
+        interior of an existing (padded) gradient buffer."""
+        Ho = (x.H + 2 * r.P - r.ks) // r.stride + 1
+        Wo = (x.W + 2 * r.P - r.ks) // r.stride + 1
+        reflect = r.pad_mode == N.PAD_REFLECT and r.P > 0
+        pad = r.P if reflect else 0
+        Hg, Wg = x.H + 2 * pad, x.W + 2 * pad
+        off = (r.ks - 1) if reflect else (r.ks - 1 - r.P)
+        Cg = x.Cs
+        if accumulate_into is not None:
+            assert r.ks == 1
+            if self._sizing:
+                return accumulate_into
+            gbuf, gpad = accumulate_into
+            Wg2 = x.W + 2 * gpad
+            ybase = _ptr(gbuf, (gpad * Wg2 + gpad) * Cg)
+            d = N.DipConvDesc(_ptr(dy), Ho, Wo, round_up(r.Cout, 4), round_up(r.Cout, 4),
+                              N.DipTransform(None, None, 1.0), _ptr(self.packed, r.dgrad_off), None,
+                              ybase, x.H, x.W, Cg, r.Cin, Wg2, 1, 1, N.PAD_ZERO, 0, 1, 1, None)
+            self.keep.append(d)
+            ops.append((self.lib.dip_conv_igemm, (C.byref(d),), "dgrad+:" + r.name))
+            return accumulate_into
+        gbuf = self._buf(Hg * Wg * Cg)
+        if self._sizing:
+            return (gbuf, pad)
+        d = N.DipConvDesc(_ptr(dy), Ho, Wo, round_up(r.Cout, 4), round_up(r.Cout, 4),
+                          N.DipTransform(None, None, 1.0), _ptr(self.packed, r.dgrad_off), None,
+                          _ptr(gbuf), Hg, Wg, Cg, r.Cin, 0, r.ks, 1, N.PAD_ZERO, off, r.stride, 0, None)
+        self.keep.append(d)
+        ops.append((self.lib.dip_conv_igemm, (C.byref(d),), "dgrad:" + r.name))
+        return (gbuf, pad)
+
+    def _gradsrc(self, g, Cg, choff=0):
+        buf, pad = g
+        d = N.DipGradSrc(_ptr(buf), pad, 1 if pad > 0 else 0, Cg, choff)
+        self.keep.append(d)
+        return d
+
+    def _emit_bn_act_bwd(self, a: Act, g, ops, choff=0, Cg=None):
+        """BatchNorm(+LeakyReLU) backward of activation `a` given the gradient source g=(buf,pad)
+        wrt the activated value.  Returns the dy buffer (grad wrt a.buf, the conv's raw output)."""
+        bn = a.bn
+        nblk = self.lib.dip_bn_bwd_nblk(a.H, a.W, a.C)
+        if self._sizing:
+            self.bwdp_need = max(self.bwdp_need, nblk * 2 * a.Cs)
+            return None
+        dz = self._new(a.H * a.W * a.Cs)
+        src = self._gradsrc(g, Cg if Cg is not None else a.Cs, choff)
+        lib = self.lib
+        ops.append((lib.dip_bn_bwd_stats, (C.byref(src), _ptr(a.buf), a.H, a.W, a.Cs, a.C, _ptr(bn.state), bn.Cs,
+                                           float(a.slope), _ptr(dz), a.Cs, _ptr(self.bwd_scratch), nblk),
+                    "bnb_stats:" + bn.name))
+        ops.append((lib.dip_bn_bwd_finalize, (_ptr(self.bwd_scratch), nblk, bn.Cs, bn.C, a.H * a.W,
+                                              _ptr(self.grads, bn.gamma_off), _ptr(self.grads, bn.beta_off),
+                                              _ptr(bn.coef)), "bnb_fin:" + bn.name))
+        ops.append((lib.dip_bn_bwd_apply, (_ptr(dz), a.Cs, _ptr(a.buf), a.Cs, a.H * a.W, a.C, _ptr(bn.state), bn.Cs,
+                                           _ptr(bn.coef)), "bnb_apply:" + bn.name))
+        return dz
+
+    def _emit_up_bwd(self, deep: Act, dcat, Cs_cat, choff, H, W, mode, ops):
+        bn = deep.bn
+        nblk = self.lib.dip_bn_bwd_nblk(H // 2, W // 2, deep.C)
+        if self._sizing:
+            self.bwdp_need = max(self.bwdp_need, nblk * 2 * deep.Cs)
+            return None
+        dz = self._new(deep.H * deep.W * deep.Cs)
+        lib = self.lib
+        m = N.UP_BILINEAR if mode == "bilinear" else N.UP_NEAREST
+        ops.append((lib.dip_upsample_bwd_stats, (_ptr(dcat), Cs_cat, choff, H, W, m, _ptr(deep.buf), deep.Cs, deep.C,
+                                                 _ptr(bn.state), bn.Cs, float(deep.slope), _ptr(dz), deep.Cs,
+                                                 _ptr(self.bwd_scratch), nblk), "upb_stats:" + bn.name))
+        ops.append((lib.dip_bn_bwd_finalize, (_ptr(self.bwd_scratch), nblk, bn.Cs, bn.C, deep.H * deep.W,
+                                              _ptr(self.grads, bn.gamma_off), _ptr(self.grads, bn.beta_off),
+                                              _ptr(bn.coef)), "bnb_fin:" + bn.name))
+        ops.append((lib.dip_bn_bwd_apply, (_ptr(dz), deep.Cs, _ptr(deep.buf), deep.Cs, deep.H * deep.W, deep.C,
+                                           _ptr(bn.state), bn.Cs, _ptr(bn.coef)), "bnb_apply:" + bn.name))
+        return dz
+
+    def _bwd_scale_ops(self, i, dy_last):
+        """Backward of scale i given dy wrt the raw output of its last conv.  For i > 0 returns ops
+        that end with the gradient source of the scale's input stored in self.sc[i].gin; for
+        i == 0 the input-gradient ops go to self.bwd_input_ops (only run when net_input is optimised)."""
+        s = self.sc[i]
+        st = s.st
+        ops = []
+        H, W, xin = st["H"], st["W"], st["xin"]
+        if s.up1 is not None:
+            self._emit_wgrad(s.up1, st["u"], dy_last, ops)
+            g = self._emit_dgrad(s.up1, st["u"], dy_last, ops)
+            dy_u = self._emit_bn_act_bwd(st["u"], g, ops)
+        else:
+            dy_u = dy_last
+        cat = st["cat_act"]
+        self._emit_wgrad(s.up, cat, dy_u, ops)
+        g = self._emit_dgrad(s.up, cat, dy_u, ops)
+        dcat = self._emit_bn_act_bwd(cat, g, ops)            # grad wrt the concat tensor [H,W,Cs_cat]
+        dy_s = None
+        if s.ns:
+            dy_s = self._emit_bn_act_bwd(st["s_act"], (dcat, 0), ops, choff=0, Cg=cat.Cs)
+            self._emit_wgrad(s.skip_conv, xin, dy_s, ops)
+        deep = st["deep"]
+        dy_deep = self._emit_up_bwd(deep, dcat, cat.Cs, s.ns, H, W, s.upsample_mode, ops)
+        if i < self.nscales - 1:
+            ops += self._bwd_scale_ops(i + 1, dy_deep)
+            gin = self.sc[i + 1].gin                         # gradient source wrt act d2
+            dy_d2 = self._emit_bn_act_bwd(st["d2"], gin, ops)
+        else:
+            dy_d2 = dy_deep
+        self._emit_wgrad(s.down_b, st["d1"], dy_d2, ops)
+        g = self._emit_dgrad(s.down_b, st["d1"], dy_d2, ops)
+        dy_d1 = self._emit_bn_act_bwd(st["d1"], g, ops)
+        self._emit_wgrad(s.down_a, xin, dy_d1, ops)
+        tgt = ops if i > 0 else self.bwd_input_ops
+        g = self._emit_dgrad(s.down_a, xin, dy_d1, tgt)
+        if s.ns:
+            g = self._emit_dgrad(s.skip_conv, xin, dy_s, tgt, accumulate_into=g)
+        s.gin = g
+        return ops
+
+    # ------------------------------------------------------------------ run
+    def _run(self, ops, stream):
+        check = N.check
+        for fn, args, name in ops:
+            rc = fn(*args, stream)
+            if rc:
+                check(rc, name)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.dim() != 4 or x.shape[0] != 1:
+            raise NotImplementedError("dip-amd: input must be [1,C,H,W] (train-mode BatchNorm couples a batch; "
+                                      "independent images run as independent nets)")
+        if not self.net.training:
+            raise NotImplementedError("dip-amd: eval-mode BatchNorm is not implemented (the reference never "
+                                      "calls .eval() on the skip path)")
+        dev = x.device
+        if self.device != dev or not self._arena_ok():
+            self._build_arenas(dev)
+        _, Cimg, H, W = x.shape
+        if self.shape_key != (H, W, Cimg):
+            if Cimg != self.sc[0].down_a.Cin:
+                raise RuntimeError(f"dip-amd: input has {Cimg} channels, net expects {self.sc[0].down_a.Cin}")
+            self._build_plan(H, W, Cimg)
+        lib = self.lib
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        xs = x.detach()
+        if xs.dtype != torch.float32:
+            xs = xs.float()
+        xs = xs.contiguous()
+        self.fwd_id += 1
+        N.check(lib.dip_pack_weights(_ptr(self.params), _ptr(self.packed), self.pack_recs.data_ptr(), len(self.convs),
+                                     self.pack_max, stream), "pack_weights")
+        N.check(lib.dip_nchw_to_nhwc(xs.data_ptr(), _ptr(self.x_nhwc), Cimg, H * W, round_up(Cimg, 4), stream),
+                "nchw_to_nhwc")
+        self._run(self.fwd_ops, stream)
+        out = torch.empty((1, self.n_out, H, W), dtype=torch.float32, device=dev)
+        N.check(lib.dip_head_fwd(_ptr(self.y_out), out.data_ptr(), self.n_out, H * W, round_up(self.n_out, 4),
+                                 1 if self.need_sigmoid else 0, stream), "head_fwd")
+        if len(self.bns):
+            self.nbt.add_(1)
+        self.last_out = out
+        return out
+
+    def backward(self, gout: torch.Tensor, fwd_id: int, need_input_grad: bool):
+        if fwd_id != self.fwd_id:
+            raise RuntimeError("dip-amd: backward() of a stale forward: the engine keeps the activations of the "
+                               "most recent net(x) only (one forward, one backward per closure call)")
+        dev = self.device
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        lib = self.lib
+        g = gout.detach()
+        if g.dtype != torch.float32:
+            g = g.float()
+        g = g.contiguous()
+        H, W = self.H, self.W
+        # if the previous backward's gradient views are still installed as .grad (accumulation
+        # across two backward() calls), write this backward into a fresh arena
+        grads = self.grads
+        p0 = self.param_list[0]
+        if p0.grad is not None and p0.grad.data_ptr() == grads.data_ptr() + 4 * self.slots[0]:
+            raise RuntimeError("dip-amd: a second backward() while the previous gradients are still installed "
+                               "(.grad not cleared) is not supported; call optimizer.zero_grad() between "
+                               "closure evaluations as utils/common_utils.optimize does")
+        N.check(lib.dip_head_bwd(g.data_ptr(), self.last_out.data_ptr(), _ptr(self.dy_out), self.n_out, H * W,
+                                 round_up(self.n_out, 4), 1 if self.need_sigmoid else 0, stream), "head_bwd")
+        self._run(self.bwd_ops, stream)
+        gx = None
+        if need_input_grad:
+            self._run(self.bwd_input_ops, stream)
+            gbuf, pad = self.sc[0].gin
+            src = N.DipGradSrc(_ptr(gbuf), pad, 1 if pad > 0 else 0, round_up(self.Cimg, 4), 0)
+            gx = torch.empty((1, self.Cimg, H, W), dtype=torch.float32, device=dev)
+            N.check(lib.dip_fold_to_nchw(C.byref(src), H, W, self.Cimg, gx.data_ptr(), stream), "fold_to_nchw")
+        views = [grads[o:o + p.numel()].view(p.shape) for p, o in zip(self.param_list, self.slots)]
+        return gx, views
+
+
+class _SkipFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, engine: SkipEngine, x, *params):
+        out = engine.forward(x)
+        ctx.engine = engine
+        ctx.fwd_id = engine.fwd_id
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        need_x = ctx.needs_input_grad[1]
+        gx, views = ctx.engine.backward(gout, ctx.fwd_id, need_x)
+        return (None, gx, *views)
+
+
+def run_net(engine: SkipEngine, x: torch.Tensor) -> torch.Tensor:
+    if not x.is_cuda:
+        raise RuntimeError("dip-amd: the skip-net runs on an MI355X only (input tensor is on the CPU); there is "
+                           "no CPU fallback in this backend")
+    # make sure the parameter arena exists before autograd records the parameter tensors
+    if engine.device != x.device or not engine._arena_ok():
+        engine._build_arenas(x.device)
+    return _SkipFn.apply(engine, x, *engine.param_list)

@@ -1,0 +1,129 @@
+"""ctypes binding of libdip_hip.so (C ABI: include/dip_hip.h).
+
+The product path has NO fallback: if the shared library is missing, `lib()` raises.  Build it
+with `python __graft_entry__.py build` (hipcc --offload-arch=gfx950) or `make -C csrc`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdip_hip.so")
+ABI_VERSION = 1
+
+PAD_ZERO, PAD_REFLECT = 0, 1
+UP_NEAREST, UP_BILINEAR = 0, 1
+
+c_float_p = C.c_void_p  # device pointers travel as raw addresses
+
+
+class DipTransform(C.Structure):
+    _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("slope", C.c_float)]
+
+
+class DipPackRec(C.Structure):
+    _fields_ = [("w_off", C.c_int64), ("fwd_off", C.c_int64), ("dgrad_off", C.c_int64),
+                ("Cout", C.c_int32), ("Cin", C.c_int32), ("KS", C.c_int32),
+                ("CinP4", C.c_int32), ("CoutP32", C.c_int32), ("CoutP4", C.c_int32), ("CinP32", C.c_int32)]
+
+
+class DipConvDesc(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("Hin", C.c_int32), ("Win", C.c_int32), ("Cx", C.c_int32), ("Cin", C.c_int32),
+                ("tr", DipTransform), ("wp", C.c_void_p), ("bias", C.c_void_p), ("y", C.c_void_p),
+                ("Hout", C.c_int32), ("Wout", C.c_int32), ("Cy", C.c_int32), ("Cout", C.c_int32),
+                ("y_pitch", C.c_int32),
+                ("ks", C.c_int32), ("stride", C.c_int32), ("pad_mode", C.c_int32), ("off", C.c_int32),
+                ("dil", C.c_int32), ("accumulate", C.c_int32), ("stats", C.c_void_p)]
+
+
+class DipWgradDesc(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("Hin", C.c_int32), ("Win", C.c_int32), ("Cx", C.c_int32), ("Cin", C.c_int32),
+                ("tr", DipTransform), ("dy", C.c_void_p),
+                ("Hout", C.c_int32), ("Wout", C.c_int32), ("Cdy", C.c_int32), ("Cout", C.c_int32),
+                ("ks", C.c_int32), ("stride", C.c_int32), ("pad_mode", C.c_int32), ("off", C.c_int32),
+                ("partial", C.c_void_p), ("bias_partial", C.c_void_p), ("nsplit", C.c_int32)]
+
+
+class DipGradSrc(C.Structure):
+    _fields_ = [("g", C.c_void_p), ("pad", C.c_int32), ("fold", C.c_int32), ("Cg", C.c_int32), ("choff", C.c_int32)]
+
+
+class DipUpcatDesc(C.Structure):
+    _fields_ = [("s", C.c_void_p), ("Cs_s", C.c_int32), ("ns", C.c_int32), ("ts", DipTransform),
+                ("d", C.c_void_p), ("Cs_d", C.c_int32), ("nd", C.c_int32), ("td", DipTransform),
+                ("H", C.c_int32), ("W", C.c_int32), ("mode", C.c_int32),
+                ("cat", C.c_void_p), ("Cs_cat", C.c_int32),
+                ("stats", C.c_void_p), ("nblk", C.c_int32)]
+
+
+_SIGS = {
+    "dip_abi_version": (C.c_int, []),
+    "dip_last_error": (C.c_char_p, []),
+    "dip_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "dip_nhwc_to_nchw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "dip_head_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "dip_head_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "dip_pack_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "dip_conv_igemm": (C.c_int, [C.POINTER(DipConvDesc), C.c_void_p]),
+    "dip_conv_ntiles": (C.c_int, [C.c_int, C.c_int]),
+    "dip_conv_wgrad": (C.c_int, [C.POINTER(DipWgradDesc), C.c_void_p]),
+    "dip_conv_wgrad_ntiles": (C.c_int, [C.c_int, C.c_int]),
+    "dip_wgrad_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                   C.c_void_p, C.c_void_p]),
+    "dip_bn_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
+                                  C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dip_bn_bwd_stats": (C.c_int, [C.POINTER(DipGradSrc), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                   C.c_void_p]),
+    "dip_bn_bwd_nblk": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "dip_bn_bwd_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p]),
+    "dip_bn_bwd_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                   C.c_void_p, C.c_void_p]),
+    "dip_fold_to_nchw": (C.c_int, [C.POINTER(DipGradSrc), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "dip_upcat_fwd": (C.c_int, [C.POINTER(DipUpcatDesc), C.c_void_p]),
+    "dip_upcat_nblk": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "dip_upsample_bwd_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                         C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int,
+                                         C.c_void_p, C.c_int, C.c_void_p]),
+    "dip_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double,
+                                C.c_double, C.c_double, C.c_int, C.c_void_p]),
+    "dip_noise_axpy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "dip_lanczos_down_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, C.c_int, C.c_void_p]),
+    "dip_lanczos_down_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, C.c_int, C.c_void_p]),
+}
+
+EXPORTS = tuple(_SIGS.keys())
+_lib = None
+
+
+def lib():
+    """Load libdip_hip.so once; fail loudly if it is not built (no CPU / eager fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the deep-image-prior MI355X backend has no fallback path. "
+                "Build it with `python __graft_entry__.py build` (needs hipcc, targets gfx950).")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)          # AttributeError -> missing symbol: loud
+            fn.restype = res
+            fn.argtypes = args
+        if L.dip_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"libdip_hip.so ABI {L.dip_abi_version()} != binding ABI {ABI_VERSION}")
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().dip_last_error()
+        raise RuntimeError(f"libdip_hip {what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m

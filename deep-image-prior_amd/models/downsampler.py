@@ -1,0 +1,127 @@
+"""Fixed-kernel down-sampler (Lanczos / Gauss / box), API-compatible with the reference's
+models/downsampler.py:9-135, executed by a depth-wise gfx950 kernel.
+
+The reference realises it as ReplicationPad2d + a dense Conv2d(n, n, k, stride=factor) whose
+weight is the 2-D tap table on the channel diagonal (2/3 of the MACs multiply zeros for n=3) and
+registers the fixed taps as trainable parameters.  Here the same taps (float64 numpy, then fp32)
+drive `dip_lanczos_down_fwd/bwd`: one depth-wise stencil with clamped (replicated) borders.
+`downsampler_.weight/bias` are kept as parameters so `get_params('down', ...)` and
+`.type(dtype)` behave as in the reference; the native path reads the taps, not the dense weight.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+
+def get_kernel(factor, kernel_type, phase, kernel_width, support=None, sigma=None):
+    """2-D resampling taps, normalised to sum 1 (float64).  Half-phase kernels have an even
+    size (kernel_width - 1)."""
+    assert kernel_type in ('lanczos', 'gauss', 'box')
+    n = kernel_width - 1 if (phase == 0.5 and kernel_type != 'box') else kernel_width
+    taps = np.zeros([n, n])
+    if kernel_type == 'box':
+        assert phase == 0.5, 'Box filter is always half-phased'
+        taps[:] = 1. / (kernel_width * kernel_width)
+    elif kernel_type == 'gauss':
+        assert sigma, 'sigma is not specified'
+        assert phase != 0.5, 'phase 1/2 for gauss not implemented'
+        center = (kernel_width + 1.) / 2.
+        s2 = sigma * sigma
+        for i in range(1, n + 1):
+            for j in range(1, n + 1):
+                di, dj = (i - center) / 2., (j - center) / 2.
+                taps[i - 1][j - 1] = np.exp(-(di * di + dj * dj) / (2 * s2)) / (2. * np.pi * s2)
+    else:
+        assert support, 'support is not specified'
+        center = (kernel_width + 1) / 2.
+        shift = 0.5 if phase == 0.5 else 0.0
+
+        for i in range(1, n + 1):
+            for j in range(1, n + 1):
+                di = abs(i + shift - center) / factor
+                dj = abs(j + shift - center) / factor
+                val = 1
+                if di != 0:
+                    val = val * support * np.sin(np.pi * di) * np.sin(np.pi * di / support)
+                    val = val / (np.pi * np.pi * di * di)
+                if dj != 0:
+                    val = val * support * np.sin(np.pi * dj) * np.sin(np.pi * dj / support)
+                    val = val / (np.pi * np.pi * dj * dj)
+                taps[i - 1][j - 1] = val
+    taps /= taps.sum()
+    return taps
+
+
+_PRESETS = {
+    'lanczos2': dict(support=2, width=lambda f: 4 * f + 1, base='lanczos'),
+    'lanczos3': dict(support=3, width=lambda f: 6 * f + 1, base='lanczos'),
+    'gauss12': dict(sigma=1 / 2, width=lambda f: 7, base='gauss'),
+    'gauss1sq2': dict(sigma=1. / np.sqrt(2), width=lambda f: 9, base='gauss'),
+}
+
+
+class _LanczosFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, taps, k, factor, pad):
+        import dip_native as N
+        lib = N.lib()
+        _, C, H, W = x.shape
+        Ho, Wo = (H + 2 * pad - k) // factor + 1, (W + 2 * pad - k) // factor + 1
+        xs = x.detach().contiguous().float()
+        y = torch.empty((1, C, Ho, Wo), dtype=torch.float32, device=x.device)
+        st = torch.cuda.current_stream(x.device).cuda_stream
+        N.check(lib.dip_lanczos_down_fwd(xs.data_ptr(), taps.data_ptr(), y.data_ptr(), C, H, W, k, factor, pad, st),
+                "lanczos_down_fwd")
+        ctx.meta = (taps, k, factor, pad, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        import dip_native as N
+        lib = N.lib()
+        taps, k, factor, pad, C, H, W = ctx.meta
+        g = gy.detach().contiguous().float()
+        gx = torch.empty((1, C, H, W), dtype=torch.float32, device=gy.device)
+        st = torch.cuda.current_stream(gy.device).cuda_stream
+        N.check(lib.dip_lanczos_down_bwd(g.data_ptr(), taps.data_ptr(), gx.data_ptr(), C, H, W, k, factor, pad, st),
+                "lanczos_down_bwd")
+        return gx, None, None, None, None
+
+
+class Downsampler(nn.Module):
+    def __init__(self, n_planes, factor, kernel_type, phase=0, kernel_width=None, support=None, sigma=None,
+                 preserve_size=False):
+        super().__init__()
+        assert phase in [0, 0.5], 'phase should be 0 or 0.5'
+        if kernel_type in _PRESETS:
+            p = _PRESETS[kernel_type]
+            support, sigma = p.get('support', support), p.get('sigma', sigma)
+            kernel_width, base = p['width'](factor), p['base']
+        elif kernel_type in ('lanczos', 'gauss', 'box'):
+            base = kernel_type
+        else:
+            assert False, 'wrong name kernel'
+        self.kernel = get_kernel(factor, base, phase, kernel_width, support=support, sigma=sigma)
+        self.factor = factor
+        k = self.kernel.shape[0]
+        # parameter holder with the reference's shapes/names (downsampler_.weight / .bias)
+        holder = nn.Conv2d(n_planes, n_planes, kernel_size=self.kernel.shape, stride=factor, padding=0)
+        holder.weight.data[:] = 0
+        holder.bias.data[:] = 0
+        kt = torch.from_numpy(self.kernel)
+        for c in range(n_planes):
+            holder.weight.data[c, c] = kt
+        self.downsampler_ = holder
+        self.register_buffer('_taps', kt.to(torch.float32).contiguous(), persistent=False)
+        self.preserve_size = preserve_size
+        self._pad = 0
+        if preserve_size:
+            self._pad = int((k - 1) / 2.) if k % 2 == 1 else int((k - factor) / 2.)
+            self.padding = nn.ReplicationPad2d(self._pad)
+
+    def forward(self, input):
+        if not input.is_cuda:
+            raise RuntimeError("dip-amd: Downsampler runs on an MI355X only (no CPU fallback in this backend)")
+        if input.dim() != 4 or input.shape[0] != 1:
+            raise NotImplementedError("dip-amd: Downsampler expects a [1,C,H,W] tensor")
+        return _LanczosFn.apply(input, self._taps.to(input.device), self.kernel.shape[0], self.factor, self._pad)

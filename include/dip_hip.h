@@ -1,0 +1,207 @@
+/*
+ * dip_hip.h -- C ABI of libdip_hip.so: the MI355X (gfx950) kernels behind the
+ * deep-image-prior optimisation loop (skip-net forward + backward + Adam).
+ *
+ * The reference (DmitryUlyanov/deep-image-prior) has NO native code and no FFI: its arithmetic
+ * is PyTorch `nn` modules.  Each entry point below therefore cites the reference *call site* of
+ * the PyTorch op(s) it replaces.  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *   - every tensor is fp32, device memory, NHWC ("pixel-major": [H][W][Cs]) unless stated;
+ *     Cs (channel stride) is a multiple of 4, channels [C, Cs) are zero;
+ *   - the library allocates nothing and never synchronises: all buffers are caller-owned
+ *     (PyTorch caching allocator), every launch goes to the `stream` argument (a hipStream_t),
+ *     so the launch sequence is hipGraph-capturable;
+ *   - return value: 0 on success, otherwise a hipError_t (or -1 for an unsupported
+ *     configuration); dip_last_error() returns a static description of the last failure.
+ *   - one process per GPU, calls come from the thread that owns the stream.
+ */
+#ifndef DIP_HIP_H
+#define DIP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DIP_ABI_VERSION 1
+
+#define DIP_PAD_ZERO 0
+#define DIP_PAD_REFLECT 1
+
+#define DIP_UP_NEAREST 0
+#define DIP_UP_BILINEAR 1
+
+int dip_abi_version(void);
+const char* dip_last_error(void);
+
+/* Per-channel input transform fused into a consumer's loader:
+ *   u = max(t, slope*t),  t = a[c]*x + b[c]        (slope = 1 -> affine only)
+ * This is BatchNorm2d(train)-apply (models/common.py:95-96) + LeakyReLU(0.2)
+ * (models/common.py:82) with a = gamma*rstd, b = beta - mean*a.  a == NULL -> identity. */
+typedef struct DipTransform {
+    const float* a;
+    const float* b;
+    float slope;
+} DipTransform;
+
+/* ---------------------------------------------------------------- layout / head ------------ */
+/* NCHW [C][H*W] -> NHWC [H*W][Cs] (pad channels zeroed).  Boundary of `net(net_input)`:
+ * get_noise() makes [1,C,H,W] NCHW (utils/common_utils.py:140). */
+int dip_nchw_to_nhwc(const float* src, float* dst, int C, int HW, int Cs, void* stream);
+/* NHWC [H*W][Cs] -> NCHW [C][H*W], optionally adding into dst (grad wrt net_input). */
+int dip_nhwc_to_nchw(const float* src, float* dst, int C, int HW, int Cs, int accumulate, void* stream);
+/* out[c][p] = sigmoid(y[p][c]) (or copy): nn.Sigmoid, models/skip.py:97-98; NHWC -> NCHW. */
+int dip_head_fwd(const float* y, float* out, int C, int HW, int Cs, int sigmoid, void* stream);
+/* dy[p][c] = gout[c][p] * out[c][p]*(1-out[c][p]) (sigmoid backward); NCHW -> NHWC. */
+int dip_head_bwd(const float* gout, const float* out, float* dy, int C, int HW, int Cs, int sigmoid,
+                 void* stream);
+
+/* ---------------------------------------------------------------- weights ----------------- */
+/* One record per Conv2d: repacks OIHW weights (nn.Conv2d, models/common.py:120) from the flat
+ * parameter arena into the MFMA B-operand layouts used by dip_conv_igemm:
+ *   forward : Wf[tap][c/4][o (CoutP32)][c%4]          = W[o][c][tap]
+ *   dgrad   : Wd[tap][o/4][c (CinP32)][o%4]           = W[o][c][KS*KS-1-tap]
+ * offsets are in floats; dgrad_off < 0 skips the dgrad pack. */
+typedef struct DipPackRec {
+    int64_t w_off;      /* into `params` */
+    int64_t fwd_off;    /* into `packed` */
+    int64_t dgrad_off;  /* into `packed`, or -1 */
+    int32_t Cout, Cin, KS;
+    int32_t CinP4, CoutP32, CoutP4, CinP32;
+} DipPackRec;
+int dip_pack_weights(const float* params, float* packed, const DipPackRec* recs_dev, int nrec,
+                     int max_elems, void* stream);
+
+/* ---------------------------------------------------------------- convolution ------------- */
+/* Implicit-GEMM convolution on the fp32 MFMA (v_mfma_f32_32x32x2_f32):
+ *   y[q][o] (+)= bias[o] + sum_{tap,c} u[src(q,tap)][c] * Wp[tap][c][o],  u = transform(x)
+ * per spatial dim  v = q*stride + k - off ; pad_mode reflect mirrors v into [0,Hv), zero drops
+ * it;  Hv = (Hin-1)*dil + 1 ; dil == 2 reads x[v/2] for even v and 0 for odd v.
+ * Replaces ReflectionPad2d + Conv2d (models/common.py:114-124) for the forward
+ * (off = pad, dil = 1) and autograd's ConvolutionBackward data-gradient (transposed conv for
+ * the stride-2 layers, models/skip.py:64) with flipped weights (off = KS-1-zero_pad, stride 1,
+ * dil = forward stride; with reflection padding the result is the gradient on the PADDED
+ * domain, folded back by dip_bn_bwd_stats / dip_fold_add).
+ * stats != NULL: per-workgroup BatchNorm partials {count, mean, M2}[CoutP32] per tile
+ * (Chan/Welford form) for the BatchNorm2d that follows the conv (models/common.py:95-96). */
+typedef struct DipConvDesc {
+    const float* x;
+    int32_t Hin, Win, Cx, Cin;   /* Cx = channel stride of x, Cin = channels convolved (mult of 4) */
+    DipTransform tr;
+    const float* wp;             /* packed weights (see DipPackRec) */
+    const float* bias;           /* [Cout] or NULL */
+    float* y;
+    int32_t Hout, Wout, Cy, Cout; /* Cy = channel stride of y */
+    int32_t y_pitch;             /* pixels per output row in memory (0 -> Wout); lets a 1x1 dgrad
+                                    accumulate into the interior of a padded gradient buffer */
+    int32_t ks, stride, pad_mode, off, dil, accumulate;
+    float* stats;                /* [ntiles][3][CoutP32] or NULL */
+} DipConvDesc;
+int dip_conv_igemm(const DipConvDesc* d, void* stream);
+/* number of 8x16 output tiles = rows of the stats partial buffer */
+int dip_conv_ntiles(int Hout, int Wout);
+
+/* Weight gradient (autograd ConvolutionBackward, weight + bias part):
+ *   dW[o][c][tap] = sum_q dy[q][o] * u[src(q,tap)][c],  db[o] = sum_q dy[q][o]
+ * Two stages, deterministic: dip_conv_wgrad writes `nsplit` partial slabs
+ * [nsplit][tap][CinP32][CoutP32] (+ [nsplit][CoutP32] bias partials), dip_wgrad_reduce sums the
+ * slabs in a fixed order and writes OIHW gradients into the grad arena. */
+typedef struct DipWgradDesc {
+    const float* x;
+    int32_t Hin, Win, Cx, Cin;
+    DipTransform tr;
+    const float* dy;
+    int32_t Hout, Wout, Cdy, Cout;
+    int32_t ks, stride, pad_mode, off;
+    float* partial;
+    float* bias_partial;          /* or NULL */
+    int32_t nsplit;
+} DipWgradDesc;
+int dip_conv_wgrad(const DipWgradDesc* d, void* stream);
+/* number of 4x16 output tiles walked by the wgrad workgroups (upper bound for nsplit) */
+int dip_conv_wgrad_ntiles(int Hout, int Wout);
+int dip_wgrad_reduce(const float* partial, const float* bias_partial, int nsplit, int ks, int Cin,
+                     int Cout, float* dw /*OIHW*/, float* dbias /*or NULL*/, void* stream);
+
+/* ---------------------------------------------------------------- BatchNorm (train mode) -- */
+/* state block per BatchNorm: 4 rows of Cs floats: mean, rstd, a, b  (a = gamma*rstd, b = beta - mean*a) */
+/* Combine per-tile partials -> batch statistics, update running stats (momentum 0.1, unbiased
+ * var), nn.BatchNorm2d training forward (models/common.py:95-96). */
+int dip_bn_finalize(const float* partials, int ntiles, int Cstride, int C, const float* gamma,
+                    const float* beta, float eps, float momentum, float* state, int Cs,
+                    float* running_mean, float* running_var, void* stream);
+
+/* Source of an incoming activation gradient `du` for pixel (r,c), channel ch:
+ *   du = sum over folded positions of  g[((r+pad)*Wg + (c+pad)) * Cg + choff + ch]
+ * fold == 1 adds the mirror images of the reflection-padded border (adjoint of
+ * nn.ReflectionPad2d, models/common.py:116-118); Hg = H + 2*pad, Wg = W + 2*pad. */
+typedef struct DipGradSrc {
+    const float* g;
+    int32_t pad, fold, Cg, choff;
+} DipGradSrc;
+
+/* BatchNorm+LeakyReLU backward, phase 1:  dz = du * (a*y+b > 0 ? 1 : slope); writes dz and the
+ * per-block partial sums {sum dz, sum dz*xhat}.  (autograd NativeBatchNormBackward +
+ * LeakyReluBackward of models/common.py:82,96.) */
+int dip_bn_bwd_stats(const DipGradSrc* src, const float* y, int H, int W, int Cy, int C,
+                     const float* state, int Cs, float slope, float* dz, int Cdz,
+                     float* partials /*[nblk][2][Cs]*/, int nblk, void* stream);
+int dip_bn_bwd_nblk(int H, int W, int C);
+/* phase 2: reduce partials -> dgamma, dbeta (grad arena) and k1 = S1/N, k2 = S2/N in `coef` [2][Cs] */
+int dip_bn_bwd_finalize(const float* partials, int nblk, int Cs, int C, int npix, float* dgamma,
+                        float* dbeta, float* coef, void* stream);
+/* phase 3 (in place): dy = a * (dz - k1 - xhat*k2) */
+int dip_bn_bwd_apply(float* dz, int Cdz, const float* y, int Cy, int npix, int C, const float* state,
+                     int Cs, const float* coef, void* stream);
+/* Fold a (reflection-)padded gradient back onto the image and emit it NCHW: gradient wrt
+ * `net_input` for get_params('net,input') (utils/common_utils.py:47-49). */
+int dip_fold_to_nchw(const DipGradSrc* src, int H, int W, int C, float* dst, void* stream);
+
+/* ---------------------------------------------------------------- upsample + concat ------- */
+/* cat[p][0:ns]      = T_s(s[p])                      (skip branch, Concat child "0")
+ * cat[p][ns:ns+nd]  = upsample2x(T_d(d))[p]          (deeper branch, nn.Upsample models/skip.py:81)
+ * and the {count, mean, M2} partials of the BatchNorm2d(ns+nd) that follows (models/skip.py:55).
+ * Concat: models/common.py:11-42 (no crop: H, W divisible by 2^scales). */
+typedef struct DipUpcatDesc {
+    const float* s; int32_t Cs_s, ns; DipTransform ts;      /* ns may be 0 (s == NULL) */
+    const float* d; int32_t Cs_d, nd; DipTransform td;      /* low-res [H/2][W/2][Cs_d] */
+    int32_t H, W, mode;                                      /* output (high-res) size */
+    float* cat; int32_t Cs_cat;
+    float* stats; int32_t nblk;                              /* [nblk][3][Cs_cat] */
+} DipUpcatDesc;
+int dip_upcat_fwd(const DipUpcatDesc* d, void* stream);
+int dip_upcat_nblk(int H, int W, int C);
+
+/* Adjoint of the 2x upsample fused with the LeakyReLU/BatchNorm backward phase 1 of the
+ * deeper branch: du_d = upsample2x^T(dcat[:, choff:choff+nd]); dz = du_d * lrelu'(a*y+b);
+ * partial sums as in dip_bn_bwd_stats.  (autograd UpsampleBilinear2DBackward / Nearest.) */
+int dip_upsample_bwd_stats(const float* dcat, int Cs_cat, int choff, int H, int W, int mode,
+                           const float* y, int Cy, int C, const float* state, int Cs, float slope,
+                           float* dz, int Cdz, float* partials, int nblk, void* stream);
+
+/* ---------------------------------------------------------------- optimiser --------------- */
+/* torch.optim.Adam(lr) defaults, one fused launch over a flat arena
+ * (utils/common_utils.py:225-230):  m += (1-b1)(g-m); v = b2 v + (1-b2) g^2;
+ * p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps),  bc = 1 - beta^step. */
+int dip_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
+                  double beta2, double eps, int step, void* stream);
+
+/* net_input = z + sigma * N(0,1): the closure's reg-noise line (denoising.ipynb:208-209),
+ * counter-based Philox4x32-10 + Box-Muller, NCHW in / NCHW out (elementwise). */
+int dip_noise_axpy(const float* z, float* out, int64_t n, float sigma, uint64_t seed, uint64_t offset,
+                   void* stream);
+
+/* ---------------------------------------------------------------- Lanczos down-sampler ---- */
+/* Downsampler.forward (models/downsampler.py:65-71): ReplicationPad2d(pad) + depth-wise
+ * k x k stride-`factor` correlation with the fixed taps; NCHW [C][H][W] -> [C][H/f][W/f]. */
+int dip_lanczos_down_fwd(const float* x, const float* taps, float* y, int C, int H, int W, int k,
+                         int factor, int pad, void* stream);
+int dip_lanczos_down_bwd(const float* gy, const float* taps, float* gx, int C, int H, int W, int k,
+                         int factor, int pad, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIP_HIP_H */

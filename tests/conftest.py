@@ -1,0 +1,33 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import __graft_entry__ as ge  # noqa: E402
+
+ge.add_to_path()
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu through gpurun)")
+
+
+@pytest.fixture(scope="session")
+def built():
+    """libdip_hip.so built (hipcc cross-compiles without a GPU) and loadable."""
+    ge.build()
+    import dip_native
+    return dip_native.lib()
+
+
+@pytest.fixture(scope="session")
+def dev(built):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")

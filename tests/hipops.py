@@ -1,0 +1,134 @@
+"""Thin test-side wrappers that drive single libdip_hip.so entry points with NCHW torch tensors
+(the layout conversions here are plain torch permutes: test plumbing, not product code)."""
+import ctypes as C
+
+import torch
+
+import dip_native as N
+from dip_native import round_up
+
+
+def stream(dev):
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def to_nhwc(x, Cs=None):
+    """[1,C,H,W] -> flat NHWC with channel stride Cs (zero padded)."""
+    _, Cc, H, W = x.shape
+    Cs = Cs or round_up(Cc, 4)
+    out = torch.zeros(H, W, Cs, dtype=torch.float32, device=x.device)
+    out[:, :, :Cc] = x[0].permute(1, 2, 0)
+    return out.contiguous()
+
+
+def from_nhwc(buf, Cc, H, W, Cs=None):
+    Cs = Cs or round_up(Cc, 4)
+    return buf.view(H, W, Cs)[:, :, :Cc].permute(2, 0, 1)[None].contiguous()
+
+
+def pack(w, need_dgrad=True):
+    """OIHW weight -> (packed buffer, fwd_off, dgrad_off) through dip_pack_weights."""
+    lib = N.lib()
+    Cout, Cin, ks, _ = w.shape
+    fwd = ks * ks * round_up(Cin, 4) * round_up(Cout, 32)
+    dg = ks * ks * round_up(Cout, 4) * round_up(Cin, 32)
+    packed = torch.full((fwd + dg,), float("nan"), dtype=torch.float32, device=w.device)
+    rec = (N.DipPackRec * 1)()
+    rec[0] = N.DipPackRec(0, 0, fwd if need_dgrad else -1, Cout, Cin, ks, round_up(Cin, 4), round_up(Cout, 32),
+                          round_up(Cout, 4), round_up(Cin, 32))
+    recs = torch.frombuffer(bytearray(bytes(rec)), dtype=torch.uint8).to(w.device)
+    wc = w.contiguous().float()
+    N.check(lib.dip_pack_weights(wc.data_ptr(), packed.data_ptr(), recs.data_ptr(), 1, fwd + dg, stream(w.device)))
+    torch.cuda.synchronize()
+    return packed, 0, fwd
+
+
+def transform(a, b, slope):
+    if a is None:
+        return N.DipTransform(None, None, 1.0), None
+    Cs = round_up(a.numel(), 4)
+    t = torch.zeros(2, Cs, dtype=torch.float32, device=a.device)
+    t[0, :a.numel()] = a
+    t[1, :b.numel()] = b
+    return N.DipTransform(t.data_ptr(), t.data_ptr() + 4 * Cs, float(slope)), t
+
+
+def conv_fwd(x, w, bias, stride, pad_mode, tr=(None, None, 1.0), want_stats=False):
+    """x [1,Cin,H,W], w OIHW -> y [1,Cout,Ho,Wo] (+ stats partial tensor)."""
+    lib = N.lib()
+    dev = x.device
+    _, Cin, H, W = x.shape
+    Cout, _, ks, _ = w.shape
+    P = (ks - 1) // 2
+    Ho, Wo = (H + 2 * P - ks) // stride + 1, (W + 2 * P - ks) // stride + 1
+    xb = to_nhwc(x)
+    packed, fo, _ = pack(w)
+    Cy = round_up(Cout, 4)
+    y = torch.full((Ho * Wo * Cy,), float("nan"), dtype=torch.float32, device=dev)
+    trd, keep = transform(*tr)
+    ntiles = lib.dip_conv_ntiles(Ho, Wo)
+    CoutP = round_up(Cout, 32)
+    stats = torch.full((ntiles * 3 * CoutP,), float("nan"), dtype=torch.float32, device=dev) if want_stats else None
+    bb = bias.contiguous().float() if bias is not None else None
+    d = N.DipConvDesc(xb.data_ptr(), H, W, round_up(Cin, 4), round_up(Cin, 4), trd, packed.data_ptr() + 4 * fo,
+                      bb.data_ptr() if bb is not None else None, y.data_ptr(), Ho, Wo, Cy, Cout, 0, ks, stride,
+                      pad_mode if P > 0 else N.PAD_ZERO, P, 1, 0, stats.data_ptr() if want_stats else None)
+    N.check(lib.dip_conv_igemm(C.byref(d), stream(dev)), "conv_igemm")
+    torch.cuda.synchronize()
+    out = from_nhwc(y, Cout, Ho, Wo)
+    padvals = y.view(Ho, Wo, Cy)[:, :, Cout:]
+    assert torch.all(padvals == 0), "pad channels must be written as zeros"
+    if want_stats:
+        return out, stats.view(ntiles, 3, CoutP)
+    return out
+
+
+def conv_dgrad(dy, w, stride, pad_mode, Hin, Win):
+    """dy [1,Cout,Ho,Wo] -> gradient wrt the conv input [1,Cin,Hin,Win] (fold included)."""
+    lib = N.lib()
+    dev = dy.device
+    Cout, Cin, ks, _ = w.shape
+    P = (ks - 1) // 2
+    _, _, Ho, Wo = dy.shape
+    reflect = pad_mode == N.PAD_REFLECT and P > 0
+    pad = P if reflect else 0
+    Hg, Wg = Hin + 2 * pad, Win + 2 * pad
+    off = (ks - 1) if reflect else (ks - 1 - P)
+    packed, _, do = pack(w)
+    dyb = to_nhwc(dy)
+    Cg = round_up(Cin, 4)
+    g = torch.full((Hg * Wg * Cg,), float("nan"), dtype=torch.float32, device=dev)
+    d = N.DipConvDesc(dyb.data_ptr(), Ho, Wo, round_up(Cout, 4), round_up(Cout, 4), N.DipTransform(None, None, 1.0),
+                      packed.data_ptr() + 4 * do, None, g.data_ptr(), Hg, Wg, Cg, Cin, 0, ks, 1, N.PAD_ZERO, off,
+                      stride, 0, None)
+    N.check(lib.dip_conv_igemm(C.byref(d), stream(dev)), "conv_igemm(dgrad)")
+    src = N.DipGradSrc(g.data_ptr(), pad, 1 if pad else 0, Cg, 0)
+    gx = torch.empty(1, Cin, Hin, Win, dtype=torch.float32, device=dev)
+    N.check(lib.dip_fold_to_nchw(C.byref(src), Hin, Win, Cin, gx.data_ptr(), stream(dev)), "fold")
+    torch.cuda.synchronize()
+    return gx
+
+
+def conv_wgrad(x, dy, ks, stride, pad_mode, tr=(None, None, 1.0), nsplit=None, bias=True):
+    lib = N.lib()
+    dev = x.device
+    _, Cin, H, W = x.shape
+    _, Cout, Ho, Wo = dy.shape
+    P = (ks - 1) // 2
+    xb, dyb = to_nhwc(x), to_nhwc(dy)
+    CinP, CoutP = round_up(Cin, 32), round_up(Cout, 32)
+    nt = lib.dip_conv_wgrad_ntiles(Ho, Wo)
+    nsplit = nsplit or max(1, min(nt, 7))
+    partial = torch.full((nsplit * ks * ks * CinP * CoutP,), float("nan"), dtype=torch.float32, device=dev)
+    bpart = torch.full((nsplit * CoutP,), float("nan"), dtype=torch.float32, device=dev)
+    trd, keep = transform(*tr)
+    d = N.DipWgradDesc(xb.data_ptr(), H, W, round_up(Cin, 4), Cin, trd, dyb.data_ptr(), Ho, Wo, round_up(Cout, 4),
+                       Cout, ks, stride, pad_mode if P > 0 else N.PAD_ZERO, P, partial.data_ptr(),
+                       bpart.data_ptr() if bias else None, nsplit)
+    N.check(lib.dip_conv_wgrad(C.byref(d), stream(dev)), "conv_wgrad")
+    dw = torch.full((Cout, Cin, ks, ks), float("nan"), dtype=torch.float32, device=dev)
+    db = torch.full((Cout,), float("nan"), dtype=torch.float32, device=dev)
+    N.check(lib.dip_wgrad_reduce(partial.data_ptr(), bpart.data_ptr() if bias else None, nsplit, ks, Cin, Cout,
+                                 dw.data_ptr(), db.data_ptr() if bias else None, stream(dev)), "wgrad_reduce")
+    torch.cuda.synchronize()
+    return dw, (db if bias else None)

@@ -1,0 +1,158 @@
+"""CPU suite: host-side logic of the MI355X backend -- C-ABI surface, module tree / state_dict
+naming, planner, reference-compatible helper semantics, loud failure without the HIP path, and
+the multi-process sharding used by `bench.py --gpus N` (world_size-2 gloo)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT
+
+
+def test_cabi_exports_every_declared_symbol(built):
+    hdr = open(os.path.join(ROOT, "include", "dip_hip.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(dip_[a-z0-9_]+)\s*\(", hdr, flags=re.M))
+    import dip_native
+    assert declared == set(dip_native.EXPORTS), declared ^ set(dip_native.EXPORTS)
+    L = ctypes.CDLL(dip_native.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert built.dip_abi_version() == 1
+    # struct layouts agree with the header's field order (sizes on LP64)
+    assert ctypes.sizeof(dip_native.DipTransform) == 24
+    assert ctypes.sizeof(dip_native.DipGradSrc) == 24
+    assert ctypes.sizeof(dip_native.DipPackRec) == 56
+
+
+def test_state_dict_names_and_shapes_match_oracle_spec():
+    import dip_oracle as O
+    from models.skip import skip
+    from test_net_gpu import NETS
+    from test_oracle import _spec
+    for name, cfg in NETS.items():
+        net = skip(*cfg["args"], **cfg["kw"])
+        shapes = O.param_shapes(_spec(cfg))
+        got = {k: tuple(p.shape) for k, p in net.named_parameters()}
+        assert got == shapes, name
+        gold = np.load(os.path.join(GOLDEN, f"net_{name}.npz"))
+        assert list(net.state_dict().keys()) == [k[3:] for k in gold.files if k.startswith("sd/")]
+
+
+def test_planner_launch_lists(built):
+    """Sizing pass of the engine runs without a GPU: one launch list per direction."""
+    from models import get_net
+    torch.manual_seed(0)
+    net = get_net(32, "skip", "reflection", skip_n33d=128, skip_n33u=128, skip_n11=4, num_scales=5,
+                  upsample_mode="bilinear")
+    eng = net.__dict__["_dip_engine"]
+    assert len(eng.convs) == 26 and len(eng.bns) == 30
+    eng.lib = built
+    eng._new = lambda *s: None
+    eng._sizing = True
+    for only_sizing in (True,):
+        eng.H = eng.W = 512
+        eng.stat_need = eng.wg_need = eng.wgb_need = eng.bwdp_need = 4
+        eng.fwd_ops, eng.bwd_ops, eng.bwd_input_ops, eng.keep = [], [], [], []
+        from dip_engine import Act
+        last = eng._plan_scale(0, Act(None, 512, 512, 32), 512, 512)
+        assert (last.H, last.W, last.C) == (512, 512, 128)
+    assert eng.stat_need >= 2048 * 3 * 128
+    with pytest.raises(NotImplementedError):
+        eng._build_plan(500, 512, 32)          # ragged Concat crop is not implemented
+
+
+def test_get_noise_get_params_semantics():
+    from utils.common_utils import get_noise, get_params, np_to_torch, torch_to_np
+    gn = np.load(os.path.join(GOLDEN, "get_noise.npz"))
+    torch.manual_seed(0)
+    assert np.array_equal(get_noise(32, "noise", (16, 24)).numpy(), gn["u_s0_32x16x24"])
+    torch.manual_seed(7)
+    assert np.array_equal(get_noise(3, "noise", 8, noise_type="n", var=0.5).numpy(), gn["n_s7_3x8x8"])
+    m = get_noise(2, "meshgrid", (8, 12))
+    assert m.dtype == torch.float64 and np.array_equal(m.numpy(), gn["mesh_8x12"])
+    net = torch.nn.Conv2d(3, 3, 1)
+    z = torch.zeros(1, 3, 4, 4)
+    p = get_params("net,input", net, z)
+    assert len(p) == 3 and p[-1] is z and z.requires_grad
+    down = torch.nn.Conv2d(1, 1, 1)
+    assert get_params("net,down", net, z, down) == list(down.parameters())      # 'down' REPLACES
+    a = np.random.rand(3, 5, 7).astype(np.float32)
+    assert np_to_torch(a).shape == (1, 3, 5, 7) and np.array_equal(torch_to_np(np_to_torch(a)), a)
+
+
+def test_downsampler_taps_match_reference_vectors():
+    from models.downsampler import Downsampler, get_kernel
+    gold = np.load(os.path.join(GOLDEN, "downsampler.npz"))
+    for factor in (4, 2, 8):
+        d = Downsampler(n_planes=3, factor=factor, kernel_type="lanczos2", phase=0.5, preserve_size=True)
+        assert np.array_equal(d.kernel, gold[f"lanczos2_f{factor}/kernel"])
+        assert list(d.state_dict().keys()) == ["downsampler_.weight", "downsampler_.bias"]
+        assert d.downsampler_.weight.shape == (3, 3, 4 * factor, 4 * factor)
+    assert get_kernel(2, "box", 0.5, 4).shape == (4, 4)
+
+
+def test_no_silent_fallback():
+    """CPU tensors and unsupported options raise instead of running an eager path."""
+    from models.skip import skip
+    from models import get_net
+    net = skip(4, 3, [8, 8], [8, 8], [4, 4], pad="reflection", upsample_mode="bilinear")
+    with pytest.raises(RuntimeError, match="MI355X"):
+        net(torch.zeros(1, 4, 16, 16))
+    bad = skip(4, 3, [8, 8], [8, 8], [4, 4], act_fun="Swish")
+    with pytest.raises(NotImplementedError):
+        bad(torch.zeros(1, 4, 16, 16))
+    avg = skip(4, 3, [8, 8], [8, 8], [4, 4], downsample_mode="avg")
+    with pytest.raises(NotImplementedError):
+        avg(torch.zeros(1, 4, 16, 16))
+    with pytest.raises(NotImplementedError):
+        get_net(3, "UNet", "zero", "nearest")
+    # missing shared library -> loud error
+    code = ("import sys; sys.path.insert(0, %r); import dip_native as N; N.LIB_PATH = '/nonexistent/libdip_hip.so';"
+            "N._lib = None\ntry:\n    N.lib()\nexcept RuntimeError as e:\n    print('LOUD', e)\n"
+            % os.path.join(ROOT, "deep-image-prior_amd"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert "LOUD" in r.stdout and "no fallback" in r.stdout
+
+
+def test_fused_adam_grouping_cpu_logic():
+    from dip_optim import _split_contiguous
+    arena = torch.zeros(64)
+    a, b, c = arena[0:10], arena[12:20], arena[20:40]
+    other = torch.zeros(5)
+    groups = _split_contiguous([a, b, c, other])
+    assert [len(g) for g in groups] == [3, 1]
+
+
+def test_shard_assignment_world_size_2_gloo():
+    """bench.py's image->rank partition under torch.distributed (gloo, 2 processes, CPU)."""
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from bench import shard_images, reduce_max_time
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%%s" %% os.environ["PORT"],
+                        rank=int(os.environ["RANK"]), world_size=2)
+mine = shard_images(8, dist.get_rank(), 2)
+t = reduce_max_time(1.0 + dist.get_rank(), "cpu")
+allm = [None, None]
+dist.all_gather_object(allm, mine)
+if dist.get_rank() == 0:
+    assert sorted(allm[0] + allm[1]) == list(range(8)) and not set(allm[0]) & set(allm[1]), allm
+    assert abs(t - 2.0) < 1e-6, t
+    print("OK")
+dist.destroy_process_group()
+''' % ROOT
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "OK" in outs[0][0]

@@ -1,0 +1,375 @@
+"""Per-kernel parity on a real MI355X: every libdip_hip.so kernel against a torch-CPU fp64
+reference of the same op, at the layer shapes of the reference nets plus ragged / odd cases.
+Tolerance: error vs fp64 no worse than 3x the error of torch's own fp32 CPU kernel (plus an
+fp32-roundoff floor) -- i.e. fp32-class numerics, no reduced precision anywhere."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import dip_native as N  # noqa: E402
+from dip_native import round_up  # noqa: E402
+import hipops as H  # noqa: E402
+
+REFLECT, ZERO = N.PAD_REFLECT, N.PAD_ZERO
+
+
+def _ref_conv(x, w, b, stride, pad_mode, dtype):
+    x, w = x.to(dtype), w.to(dtype)
+    b = b.to(dtype) if b is not None else None
+    P = (w.shape[-1] - 1) // 2
+    if pad_mode == REFLECT and P:
+        return F.conv2d(F.pad(x, (P,) * 4, mode="reflect"), w, b, stride=stride)
+    return F.conv2d(x, w, b, stride=stride, padding=P)
+
+
+def _check(name, got, ref64, ref32, floor=2e-6):
+    got = got.detach().cpu().double()
+    e = (got - ref64).abs().max().item()
+    e32 = (ref32.double() - ref64).abs().max().item()
+    scale = ref64.abs().max().item() + 1e-30
+    tol = max(3 * e32, floor * scale)
+    assert np.isfinite(e), f"{name}: non-finite output"
+    assert e <= tol, f"{name}: max|err| {e:.3e} > tol {tol:.3e} (torch-fp32 err {e32:.3e}, scale {scale:.3e})"
+
+
+CONV_CASES = [
+    # Cin, Cout, ks, stride, pad, H, W, transform
+    (32, 128, 3, 1, REFLECT, 16, 32, False),
+    (132, 128, 3, 1, REFLECT, 24, 40, True),     # decoder conv: 4x32 + merged 4-channel tail
+    (128, 128, 3, 2, REFLECT, 32, 32, True),     # encoder stride-2
+    (128, 128, 3, 1, REFLECT, 16, 16, True),
+    (128, 128, 1, 1, REFLECT, 24, 24, True),     # 1x1 decoder conv
+    (32, 4, 1, 1, REFLECT, 19, 37, False),       # skip conv, ragged size
+    (128, 3, 1, 1, REFLECT, 16, 48, True),       # output conv
+    (3, 8, 3, 2, REFLECT, 32, 48, False),        # snail net first conv (Cin 3 -> stride 4)
+    (16, 32, 5, 2, REFLECT, 32, 32, True),       # library net 5x5 stride 2
+    (32, 64, 5, 1, REFLECT, 16, 24, True),
+    (1, 16, 5, 2, REFLECT, 32, 32, False),
+    (8, 16, 3, 1, ZERO, 16, 16, True),
+    (8, 16, 3, 2, ZERO, 16, 32, False),
+    (256, 128, 3, 1, REFLECT, 16, 16, True),     # kate net decoder conv
+    (48, 128, 3, 1, REFLECT, 8, 16, True),       # 32 + 16 chunks
+    (72, 64, 3, 1, REFLECT, 8, 16, True),        # 32 + merged 40
+    (64, 160, 3, 1, REFLECT, 8, 16, False),      # N = 128 + 32 split launch
+]
+
+
+def _mk(case, seed=0):
+    Cin, Cout, ks, stride, pad, Hh, Ww, use_tr = case
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(1, Cin, Hh, Ww, generator=g)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) / (Cin * ks * ks) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    a = bb = None
+    if use_tr:
+        a = torch.rand(Cin, generator=g) + 0.5
+        bb = torch.randn(Cin, generator=g) * 0.3
+    return x, w, b, a, bb
+
+
+def _apply_tr(x, a, b, slope, dtype):
+    if a is None:
+        return x.to(dtype)
+    t = x.to(dtype) * a.to(dtype).view(1, -1, 1, 1) + b.to(dtype).view(1, -1, 1, 1)
+    return torch.maximum(t, slope * t)
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_forward_and_stats(dev, case):
+    Cin, Cout, ks, stride, pad, Hh, Ww, use_tr = case
+    x, w, b, a, bb = _mk(case)
+    slope = 0.2
+    ref64 = _ref_conv(_apply_tr(x, a, bb, slope, torch.float64), w, b, stride, pad, torch.float64)
+    ref32 = _ref_conv(_apply_tr(x, a, bb, slope, torch.float32), w, b, stride, pad, torch.float32)
+    tr = (a.to(dev), bb.to(dev), slope) if use_tr else (None, None, 1.0)
+    y, stats = H.conv_fwd(x.to(dev), w.to(dev), b.to(dev), stride, pad, tr, want_stats=True)
+    _check("conv_fwd", y, ref64, ref32)
+    # BatchNorm partials -> mean / biased variance per channel
+    st = stats.cpu().double().numpy()
+    n = st[:, 0, :Cout]; m = st[:, 1, :Cout]; M2 = st[:, 2, :Cout]
+    N_ = n.sum(0)
+    mean = (n * m).sum(0) / N_
+    var = (M2.sum(0) + (n * (m - mean) ** 2).sum(0)) / N_
+    r = ref64[0].reshape(Cout, -1)
+    assert np.allclose(N_, r.shape[1])
+    assert np.allclose(mean, r.mean(1).numpy(), rtol=1e-5, atol=1e-5 * float(r.std()))
+    assert np.allclose(var, r.var(1, unbiased=False).numpy(), rtol=2e-5)
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_dgrad(dev, case):
+    Cin, Cout, ks, stride, pad, Hh, Ww, _ = case
+    x, w, b, _, _ = _mk(case, 1)
+    res = {}
+    for dt in (torch.float64, torch.float32):
+        xx = x.to(dt).requires_grad_(True)
+        y = _ref_conv(xx, w, None, stride, pad, dt)
+        g = torch.Generator().manual_seed(7)
+        dy = torch.randn(y.shape, generator=g)
+        (y * dy.to(dt)).sum().backward()
+        res[dt] = xx.grad
+    gx = H.conv_dgrad(dy.to(dev), w.to(dev), stride, pad, Hh, Ww)
+    _check("conv_dgrad", gx, res[torch.float64], res[torch.float32])
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_wgrad(dev, case):
+    Cin, Cout, ks, stride, pad, Hh, Ww, use_tr = case
+    x, w, b, a, bb = _mk(case, 2)
+    slope = 0.2
+    res = {}
+    for dt in (torch.float64, torch.float32):
+        ww = w.to(dt).requires_grad_(True)
+        bias = b.to(dt).requires_grad_(True)
+        y = _ref_conv(_apply_tr(x, a, bb, slope, dt), ww, bias, stride, pad, dt)
+        g = torch.Generator().manual_seed(9)
+        dy = torch.randn(y.shape, generator=g)
+        (y * dy.to(dt)).sum().backward()
+        res[dt] = (ww.grad, bias.grad)
+    tr = (a.to(dev), bb.to(dev), slope) if use_tr else (None, None, 1.0)
+    dw, db = H.conv_wgrad(x.to(dev), dy.to(dev), ks, stride, pad, tr)
+    _check("conv_wgrad.dw", dw, res[torch.float64][0], res[torch.float32][0], floor=4e-6)
+    _check("conv_wgrad.db", db, res[torch.float64][1], res[torch.float32][1], floor=4e-6)
+
+
+def test_mfma_layout_asymmetric(dev):
+    """A = one-hot pixel/channel probes with an asymmetric weight: catches a transposed or
+    permuted MFMA fragment mapping that symmetric data would hide (1x1 conv == plain GEMM)."""
+    Cin, Cout, Hh, Ww = 32, 128, 8, 16
+    x = torch.zeros(1, Cin, Hh, Ww)
+    for p in range(Hh * Ww):
+        x[0, p % Cin, p // Ww, p % Ww] = 1.0 + p
+    w = (torch.arange(Cout * Cin, dtype=torch.float32).view(Cout, Cin, 1, 1) % 97) / 97.0
+    y = H.conv_fwd(x.to(dev), w.to(dev), None, 1, REFLECT)
+    ref = F.conv2d(x.double(), w.double())
+    assert torch.allclose(y.cpu().double(), ref, rtol=1e-6, atol=1e-6)
+
+
+# ----------------------------------------------------------------------------- BatchNorm
+@pytest.mark.parametrize("Cc,Hh,Ww,P,slope", [(128, 16, 32, 1, 0.2), (4, 19, 23, 0, 0.2), (132, 12, 20, 1, 1.0),
+                                               (16, 8, 8, 2, 0.2)])
+def test_bn_forward_backward_chain(dev, Cc, Hh, Ww, P, slope):
+    """conv-output y -> BN(train)+LeakyReLU -> reflection pad -> random linear functional.
+    Checks dip_bn_finalize (via conv-style partials built by a 1x1 identity conv), and the three
+    backward phases incl. the reflection fold, against autograd in fp64."""
+    lib = N.lib()
+    g = torch.Generator().manual_seed(3)
+    y = torch.randn(1, Cc, Hh, Ww, generator=g) * 2.0 + torch.randn(1, Cc, 1, 1, generator=g) * 5.0
+    gamma = torch.rand(Cc, generator=g) + 0.5
+    beta = torch.randn(Cc, generator=g)
+    G = torch.randn(1, Cc, Hh + 2 * P, Ww + 2 * P, generator=g)
+
+    def ref(dt):
+        yy = y.to(dt).requires_grad_(True)
+        ga, be = gamma.to(dt).requires_grad_(True), beta.to(dt).requires_grad_(True)
+        u = F.batch_norm(yy, None, None, ga, be, True, 0.1, 1e-5)
+        u = torch.maximum(u, slope * u)
+        if P:
+            u = F.pad(u, (P,) * 4, mode="reflect")
+        (u * G.to(dt)).sum().backward()
+        return yy.grad, ga.grad, be.grad
+
+    r64, r32 = ref(torch.float64), ref(torch.float32)
+    # forward statistics through an identity 1x1 conv (exercises the conv epilogue partials)
+    eye = torch.eye(Cc).view(Cc, Cc, 1, 1)
+    yv, stats = H.conv_fwd(y.to(dev), eye.to(dev), None, 1, REFLECT, want_stats=True)
+    assert torch.equal(yv.cpu(), y)
+    Cs = round_up(Cc, 4)
+    state = torch.zeros(4 * Cs, device=dev)
+    rm, rv = torch.zeros(Cc, device=dev), torch.ones(Cc, device=dev)
+    gam, bet = gamma.to(dev), beta.to(dev)
+    st = H.stream(dev)
+    N.check(lib.dip_bn_finalize(stats.data_ptr(), stats.shape[0], stats.shape[2], Cc, gam.data_ptr(), bet.data_ptr(),
+                                1e-5, 0.1, state.data_ptr(), Cs, rm.data_ptr(), rv.data_ptr(), st))
+    torch.cuda.synchronize()
+    s = state.view(4, Cs).cpu().double()
+    y64 = y.double()[0].reshape(Cc, -1)
+    mean, var = y64.mean(1), y64.var(1, unbiased=False)
+    assert torch.allclose(s[0, :Cc], mean, rtol=1e-6, atol=1e-6)
+    assert torch.allclose(s[1, :Cc], 1 / torch.sqrt(var + 1e-5), rtol=2e-6)
+    assert torch.allclose(rm.cpu().double(), 0.1 * mean, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(rv.cpu().double(), 0.9 + 0.1 * y64.var(1, unbiased=True), rtol=1e-5)
+    # backward
+    yb = H.to_nhwc(y.to(dev))
+    Gb = H.to_nhwc(G.to(dev))
+    src = N.DipGradSrc(Gb.data_ptr(), P, 1 if P else 0, Cs, 0)
+    nblk = lib.dip_bn_bwd_nblk(Hh, Ww, Cc)
+    dz = torch.full((Hh * Ww * Cs,), float("nan"), device=dev)
+    part = torch.full((nblk * 2 * Cs,), float("nan"), device=dev)
+    N.check(lib.dip_bn_bwd_stats(C.byref(src), yb.data_ptr(), Hh, Ww, Cs, Cc, state.data_ptr(), Cs, slope,
+                                 dz.data_ptr(), Cs, part.data_ptr(), nblk, st))
+    dgam, dbet = torch.zeros(Cc, device=dev), torch.zeros(Cc, device=dev)
+    coef = torch.zeros(2 * Cs, device=dev)
+    N.check(lib.dip_bn_bwd_finalize(part.data_ptr(), nblk, Cs, Cc, Hh * Ww, dgam.data_ptr(), dbet.data_ptr(),
+                                    coef.data_ptr(), st))
+    N.check(lib.dip_bn_bwd_apply(dz.data_ptr(), Cs, yb.data_ptr(), Cs, Hh * Ww, Cc, state.data_ptr(), Cs,
+                                 coef.data_ptr(), st))
+    torch.cuda.synchronize()
+    dy = H.from_nhwc(dz, Cc, Hh, Ww)
+    _check("bn_bwd.dy", dy, r64[0], r32[0], floor=5e-6)
+    _check("bn_bwd.dgamma", dgam, r64[1], r32[1], floor=5e-6)
+    _check("bn_bwd.dbeta", dbet, r64[2], r32[2], floor=5e-6)
+
+
+# ----------------------------------------------------------------------------- upsample + concat
+@pytest.mark.parametrize("ns,nd,Hh,Ww,mode", [(4, 128, 16, 32, "bilinear"), (0, 32, 8, 8, "nearest"),
+                                               (128, 128, 8, 16, "nearest"), (4, 16, 12, 20, "bilinear"),
+                                               (0, 8, 4, 6, "bilinear")])
+def test_upcat_forward_backward(dev, ns, nd, Hh, Ww, mode):
+    lib = N.lib()
+    g = torch.Generator().manual_seed(5)
+    Hl, Wl = Hh // 2, Ww // 2
+    s = torch.randn(1, max(ns, 1), Hh, Ww, generator=g)
+    d = torch.randn(1, nd, Hl, Wl, generator=g)
+    a_s, b_s = torch.rand(max(ns, 1), generator=g) + 0.5, torch.randn(max(ns, 1), generator=g) * 0.3
+    a_d, b_d = torch.rand(nd, generator=g) + 0.5, torch.randn(nd, generator=g) * 0.3
+    Gc = torch.randn(1, ns + nd, Hh, Ww, generator=g)
+    slope = 0.2
+
+    def ref(dt):
+        dd = d.to(dt).requires_grad_(True)
+        ud = _apply_tr(dd, a_d, b_d, slope, dt)
+        up = F.interpolate(ud, scale_factor=2, mode=mode)
+        parts = [up]
+        if ns:
+            parts = [_apply_tr(s, a_s, b_s, slope, dt), up]
+        cat = torch.cat(parts, 1)
+        (cat * Gc.to(dt)).sum().backward()
+        return cat.detach(), dd.grad
+
+    (c64, g64), (c32, g32) = ref(torch.float64), ref(torch.float32)
+    st = H.stream(dev)
+    sb = H.to_nhwc(s.to(dev)) if ns else None
+    db = H.to_nhwc(d.to(dev))
+    ts, k1 = H.transform(a_s.to(dev), b_s.to(dev), slope) if ns else (N.DipTransform(None, None, 1.0), None)
+    td, k2 = H.transform(a_d.to(dev), b_d.to(dev), slope)
+    Ccat = ns + nd
+    Cs_cat = round_up(Ccat, 4)
+    cat = torch.full((Hh * Ww * Cs_cat,), float("nan"), device=dev)
+    nblk = lib.dip_upcat_nblk(Hh, Ww, Ccat)
+    stats = torch.full((nblk * 3 * Cs_cat,), float("nan"), device=dev)
+    desc = N.DipUpcatDesc(sb.data_ptr() if ns else None, round_up(max(ns, 1), 4), ns, ts, db.data_ptr(),
+                          round_up(nd, 4), nd, td, Hh, Ww, N.UP_BILINEAR if mode == "bilinear" else N.UP_NEAREST,
+                          cat.data_ptr(), Cs_cat, stats.data_ptr(), nblk)
+    N.check(lib.dip_upcat_fwd(C.byref(desc), st))
+    torch.cuda.synchronize()
+    got = H.from_nhwc(cat, Ccat, Hh, Ww)
+    _check("upcat_fwd", got, c64, c32)
+    stn = stats.view(nblk, 3, Cs_cat).cpu().double().numpy()
+    n, m, M2 = stn[:, 0, :Ccat], stn[:, 1, :Ccat], stn[:, 2, :Ccat]
+    Nt = n.sum(0)
+    mean = (n * m).sum(0) / Nt
+    var = (M2.sum(0) + (n * (m - mean) ** 2).sum(0)) / Nt
+    r = c64[0].reshape(Ccat, -1)
+    assert np.allclose(mean, r.mean(1).numpy(), rtol=1e-5, atol=1e-6)
+    assert np.allclose(var, r.var(1, unbiased=False).numpy(), rtol=2e-5)
+    # backward of the deeper branch: dz = up^T(dcat) * lrelu'(a*y+b); (mean, rstd) arbitrary here
+    Cs = round_up(nd, 4)
+    state = torch.zeros(4, Cs)
+    state[0, :nd] = 0.1
+    state[1, :nd] = 1.3
+    state[2, :nd] = a_d
+    state[3, :nd] = b_d
+    state = state.to(dev).contiguous()
+    Gb = H.to_nhwc(Gc.to(dev), Cs_cat)
+    nb2 = lib.dip_bn_bwd_nblk(Hl, Wl, nd)
+    dz = torch.full((Hl * Wl * Cs,), float("nan"), device=dev)
+    part = torch.full((nb2 * 2 * Cs,), float("nan"), device=dev)
+    N.check(lib.dip_upsample_bwd_stats(Gb.data_ptr(), Cs_cat, ns, Hh, Ww,
+                                       N.UP_BILINEAR if mode == "bilinear" else N.UP_NEAREST, db.data_ptr(), Cs, nd,
+                                       state.data_ptr(), Cs, slope, dz.data_ptr(), Cs, part.data_ptr(), nb2, st))
+    torch.cuda.synchronize()
+    # reference dz = d(loss)/d(z) where z = a*y+b  ->  grad wrt d divided by a
+    _check("upsample_bwd.dz", H.from_nhwc(dz, nd, Hl, Wl) * a_d.view(1, -1, 1, 1).to(dev), g64, g32, floor=5e-6)
+    p = part.view(nb2, 2, Cs).cpu().double().sum(0)
+    dz64 = (g64 / a_d.double().view(1, -1, 1, 1))[0].reshape(nd, -1)
+    xh = ((d.double()[0].reshape(nd, -1)) - 0.1) * 1.3
+    assert torch.allclose(p[0, :nd], dz64.sum(1), rtol=1e-4, atol=1e-4)
+    assert torch.allclose(p[1, :nd], (dz64 * xh).sum(1), rtol=1e-4, atol=1e-4)
+
+
+# ----------------------------------------------------------------------------- small kernels
+def test_layout_head_roundtrip(dev):
+    lib = N.lib()
+    st = H.stream(dev)
+    for Cc, HW in ((32, 64 * 48), (3, 1000), (1, 77)):
+        x = torch.randn(Cc, HW, device=dev)
+        Cs = round_up(Cc, 4)
+        nh = torch.full((HW * Cs,), float("nan"), device=dev)
+        N.check(lib.dip_nchw_to_nhwc(x.data_ptr(), nh.data_ptr(), Cc, HW, Cs, st))
+        back = torch.empty_like(x)
+        N.check(lib.dip_nhwc_to_nchw(nh.data_ptr(), back.data_ptr(), Cc, HW, Cs, 0, st))
+        out = torch.empty_like(x)
+        N.check(lib.dip_head_fwd(nh.data_ptr(), out.data_ptr(), Cc, HW, Cs, 1, st))
+        gout = torch.randn_like(x)
+        dy = torch.full((HW * Cs,), float("nan"), device=dev)
+        N.check(lib.dip_head_bwd(gout.data_ptr(), out.data_ptr(), dy.data_ptr(), Cc, HW, Cs, 1, st))
+        torch.cuda.synchronize()
+        assert torch.equal(back, x)
+        assert torch.all(nh.view(HW, Cs)[:, Cc:] == 0)
+        ref = torch.sigmoid(x.cpu().double())
+        assert torch.allclose(out.cpu().double(), ref, rtol=2e-6, atol=1e-7)
+        refg = gout.cpu().double() * ref * (1 - ref)
+        assert torch.allclose(dy.view(HW, Cs)[:, :Cc].t().cpu().double(), refg, rtol=1e-5, atol=1e-7)
+
+
+def test_adam_matches_torch(dev):
+    """dip_adam_step vs torch.optim.Adam on identical gradients: <= 2 ulp-class agreement."""
+    lib = N.lib()
+    g = torch.Generator().manual_seed(11)
+    n = 100003
+    p0 = torch.randn(n, generator=g)
+    pt = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([pt], lr=0.01)
+    p = p0.to(dev)
+    m, v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    for step in range(1, 6):
+        gr = torch.randn(n, generator=g) * (10.0 ** torch.randint(-6, 1, (n,), generator=g).float())
+        pt.grad = gr.clone()
+        opt.step()
+        gd = gr.to(dev)
+        N.check(lib.dip_adam_step(p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, 0.01, 0.9, 0.999, 1e-8,
+                                  step, H.stream(dev)))
+        torch.cuda.synchronize()
+        d = (p.cpu() - pt.detach()).abs()
+        ulp = torch.finfo(torch.float32).eps * pt.detach().abs().clamp_min(1e-3)
+        assert (d <= 4 * ulp + 1e-8).all(), (step, (d / ulp).max().item())
+
+
+def test_noise_axpy_statistics(dev):
+    lib = N.lib()
+    n = 1 << 22
+    z = torch.rand(n, device=dev)
+    out = torch.empty_like(z)
+    N.check(lib.dip_noise_axpy(z.data_ptr(), out.data_ptr(), n, 0.5, 1234, 0, H.stream(dev)))
+    out2 = torch.empty_like(z)
+    N.check(lib.dip_noise_axpy(z.data_ptr(), out2.data_ptr(), n, 0.5, 1234, n // 4, H.stream(dev)))
+    torch.cuda.synchronize()
+    e = ((out - z) / 0.5).cpu().double()
+    assert abs(e.mean().item()) < 3e-3 and abs(e.std().item() - 1) < 3e-3
+    assert abs((e ** 4).mean().item() - 3) < 0.05                      # kurtosis of a normal
+    assert not torch.equal(out, out2)                                    # offset advances the stream
+    c = np.corrcoef(e[:-1].numpy(), e[1:].numpy())[0, 1]
+    assert abs(c) < 3e-3
+
+
+def test_lanczos_downsampler_golden(dev):
+    """Downsampler forward/backward against vectors produced by the real reference."""
+    import os
+    from conftest import GOLDEN
+    from models.downsampler import Downsampler
+    gold = np.load(os.path.join(GOLDEN, "downsampler.npz"))
+    for factor in (4, 2, 8):
+        tag = f"lanczos2_f{factor}"
+        dmod = Downsampler(n_planes=3, factor=factor, kernel_type="lanczos2", phase=0.5, preserve_size=True).to(dev)
+        assert np.array_equal(dmod.kernel, gold[tag + "/kernel"])
+        x = torch.from_numpy(gold[tag + "/x"]).to(dev).requires_grad_(True)
+        y = dmod(x)
+        (y * torch.from_numpy(gold[tag + "/gy"]).to(dev)).sum().backward()
+        assert torch.allclose(y.detach().cpu(), torch.from_numpy(gold[tag + "/y"]), rtol=1e-5, atol=2e-6)
+        assert torch.allclose(x.grad.cpu(), torch.from_numpy(gold[tag + "/gx"]), rtol=1e-5, atol=2e-6)

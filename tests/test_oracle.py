@@ -1,0 +1,106 @@
+"""CPU suite: the oracle (oracle/dip_oracle.py) against the committed golden vectors that the REAL
+reference produced (oracle/make_golden.py), plus -- when the reference checkout is present (build
+container only) -- the bitwise check against the reference itself."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT
+import dip_oracle as O
+from test_net_gpu import NETS
+
+
+def _spec(cfg):
+    kw = cfg["kw"]
+    return O.SkipSpec(cfg["args"][0], cfg["args"][1], kw["num_channels_down"], kw["num_channels_up"],
+                      kw["num_channels_skip"], kw.get("filter_size_down", 3), kw.get("filter_size_up", 3),
+                      kw.get("filter_skip_size", 1), True, True, kw.get("pad", "zero"),
+                      kw.get("upsample_mode", "nearest"), kw.get("need1x1_up", True))
+
+
+@pytest.mark.parametrize("name", list(NETS))
+def test_oracle_reproduces_reference_vectors(name):
+    torch.set_num_threads(1)
+    gold = np.load(os.path.join(GOLDEN, f"net_{name}.npz"))
+    spec = _spec(NETS[name])
+    sd = {k[3:]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith("sd/")}
+    learn = {k: v for k, v in sd.items() if k in O.param_shapes(spec)}
+    assert set(learn) == set(O.param_shapes(spec))
+    onet = O.OracleNet(spec, learn)
+    z, target, mask = (torch.from_numpy(gold[k]) for k in ("z", "target", "mask"))
+    out = onet(z)
+    loss = torch.nn.functional.mse_loss(out * mask, target * mask)
+    loss.backward()
+    assert torch.equal(out.detach(), torch.from_numpy(gold["out"]))
+    assert loss.item() == float(gold["loss"])
+    for k, p in zip(onet.names, onet.params):
+        assert torch.equal(p.grad, torch.from_numpy(gold["grad/" + k])), k
+    # optimize('adam') trajectories: 1 and 3 iterations
+    mse = torch.nn.MSELoss()
+    for nsteps in (1, 3):
+        o2 = O.OracleNet(spec, learn)
+
+        def closure():
+            l = mse(o2(z) * mask, target * mask)
+            l.backward()
+            return l
+
+        O.optimize_adam(o2.params, closure, 0.01, nsteps)
+        for k, p in zip(o2.names, o2.params):
+            assert torch.equal(p.detach(), torch.from_numpy(gold[f"adam{nsteps}/" + k])), (nsteps, k)
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+
+
+def test_oracle_downsampler_and_noise_vectors():
+    gold = np.load(os.path.join(GOLDEN, "downsampler.npz"))
+    for factor in (4, 2, 8):
+        tag = f"lanczos2_f{factor}"
+        assert np.array_equal(O.lanczos_kernel(factor, 0.5, 4 * factor + 1, 2), gold[tag + "/kernel"])
+        x = torch.from_numpy(gold[tag + "/x"]).requires_grad_(True)
+        y = O.downsampler_forward(x, factor, "lanczos2", 0.5, True)
+        (y * torch.from_numpy(gold[tag + "/gy"])).sum().backward()
+        assert torch.equal(y.detach(), torch.from_numpy(gold[tag + "/y"]))
+        assert torch.allclose(x.grad, torch.from_numpy(gold[tag + "/gx"]), rtol=0, atol=1e-6)
+    gn = np.load(os.path.join(GOLDEN, "get_noise.npz"))
+    torch.manual_seed(0)
+    assert np.array_equal(O.get_noise(32, "noise", (16, 24)).numpy(), gn["u_s0_32x16x24"])
+    torch.manual_seed(7)
+    assert np.array_equal(O.get_noise(3, "noise", 8, noise_type="n", var=0.5).numpy(), gn["n_s7_3x8x8"])
+    assert np.array_equal(O.get_noise(2, "meshgrid", (8, 12)).numpy(), gn["mesh_8x12"])
+
+
+def test_oracle_default_net_digest():
+    """Full default net built by the PRODUCT's skip() under manual_seed(0) + oracle numerics ==
+    digest recorded from the real reference (parameter RNG order, key names, fwd/bwd)."""
+    from models import get_net
+    from utils.common_utils import get_noise
+    dg = json.load(open(os.path.join(GOLDEN, "default64_digest.json")))
+    torch.manual_seed(0)
+    net = get_net(32, "skip", "reflection", skip_n33d=128, skip_n33u=128, skip_n11=4, num_scales=5,
+                  upsample_mode="bilinear")
+    z = get_noise(32, "noise", (64, 64))
+    assert list(net.state_dict().keys()) == dg["keys"]
+    assert sum(p.numel() for p in net.parameters()) == dg["n_params"] == 2217831
+    for k, p in net.named_parameters():
+        assert abs(p.detach().double().sum().item() - dg["params"][k]["sum"]) <= 1e-9 * (1 + dg["params"][k]["abssum"])
+    sd = {k: v.detach() for k, v in net.state_dict().items() if k in O.param_shapes(O.default_spec())}
+    onet = O.OracleNet(O.default_spec(), sd)
+    np.random.seed(0)
+    target = torch.from_numpy(np.random.rand(1, 3, 64, 64).astype(np.float32))
+    out = onet(z)
+    loss = torch.nn.functional.mse_loss(out, target)
+    assert abs(out.detach().double().sum().item() - dg["out"]["sum"]) <= 1e-6 * dg["out"]["abssum"]
+    assert abs(loss.item() - dg["loss"]) <= 1e-6 * dg["loss"]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/models"), reason="reference checkout not mounted")
+def test_oracle_bitwise_equal_to_reference():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "verify_against_reference.py")],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "oracle pinned against the reference" in r.stdout
