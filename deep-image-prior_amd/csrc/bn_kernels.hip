@@ -6,28 +6,52 @@ namespace {
 
 // ------------------------------------------------------------------------------------------
 // forward finalise: Chan-combine per-tile {count, mean, M2} partials (fp64) -> state + running
-// grid.x = ceil(C/16); block = 256 = 16 tile-rows x 16 channels
+// grid.x = ceil(C/8); block = 256 = 32 tile-rows x 8 channels
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partials, int ntiles,
                                                           int Cstride, int C, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float eps, float momentum,
                                                           float* state, int Cs, float* running_mean,
                                                           float* running_var) {
-    __shared__ double sh[16][16][3];
-    const int cl = threadIdx.x & 15, row = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
-    double n = 0.0, mean = 0.0, M2 = 0.0;
+    // block = 32 tile-rows x 8 channels.  Two passes of plain fp64 FMAs (no division in the loops):
+    //   N = sum n_i, mean = sum n_i m_i / N ;  M2 = sum (M2_i + n_i (m_i - mean)^2)
+    __shared__ double sh[32][8][2];
+    __shared__ double shmean[8];
+    const int cl = threadIdx.x & 7, row = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cl;
+    double n = 0.0, nm = 0.0;
     if (c < C) {
-        for (int t = row; t < ntiles; t += 16) {
+        for (int t = row; t < ntiles; t += 32) {
             const float* p = partials + (size_t)t * 3 * Cstride + c;
-            dip_chan_d(n, mean, M2, (double)p[0], (double)p[Cstride], (double)p[2 * Cstride]);
+            const double ni = (double)p[0];
+            n += ni;
+            nm += ni * (double)p[Cstride];
         }
     }
-    sh[row][cl][0] = n; sh[row][cl][1] = mean; sh[row][cl][2] = M2;
+    sh[row][cl][0] = n; sh[row][cl][1] = nm;
+    __syncthreads();
+    if (row == 0) {
+        for (int r = 1; r < 32; ++r) { n += sh[r][cl][0]; nm += sh[r][cl][1]; }
+        sh[0][cl][0] = n;
+        shmean[cl] = n > 0.0 ? nm / n : 0.0;
+    }
+    __syncthreads();
+    const double mean = shmean[cl];
+    const double N = sh[0][cl][0];
+    __syncthreads();
+    double M2 = 0.0;
+    if (c < C) {
+        for (int t = row; t < ntiles; t += 32) {
+            const float* p = partials + (size_t)t * 3 * Cstride + c;
+            const double dm = (double)p[Cstride] - mean;
+            M2 += (double)p[2 * Cstride] + (double)p[0] * dm * dm;
+        }
+    }
+    sh[row][cl][1] = M2;
     __syncthreads();
     if (row == 0 && c < C) {
-        for (int r = 1; r < 16; ++r) dip_chan_d(n, mean, M2, sh[r][cl][0], sh[r][cl][1], sh[r][cl][2]);
-        const double var = M2 / n;                       // biased (normalisation)
+        for (int r = 1; r < 32; ++r) M2 += sh[r][cl][1];
+        const double var = M2 / N;                       // biased (normalisation)
         const float rstd = (float)(1.0 / sqrt(var + (double)eps));
         const float a = gamma[c] * rstd;
         const float fm = (float)mean;
@@ -36,7 +60,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
         state[2 * Cs + c] = a;
         state[3 * Cs + c] = beta[c] - fm * a;
         if (running_mean != nullptr) {
-            const double unb = n > 1.0 ? M2 / (n - 1.0) : var;
+            const double unb = N > 1.0 ? M2 / (N - 1.0) : var;
             running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * fm;
             running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
         }
@@ -144,12 +168,12 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const DipGradSrc src,
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nblk, int Cs,
                                                               int C, int npix, float* dgamma, float* dbeta,
                                                               float* coef) {
-    __shared__ double sh[16][16][2];
-    const int cl = threadIdx.x & 15, row = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
+    __shared__ double sh[32][8][2];
+    const int cl = threadIdx.x & 7, row = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cl;
     double s1 = 0.0, s2 = 0.0;
     if (c < C) {
-        for (int t = row; t < nblk; t += 16) {
+        for (int t = row; t < nblk; t += 32) {
             const float* p = partials + (size_t)t * 2 * Cs + c;
             s1 += (double)p[0];
             s2 += (double)p[Cs];
@@ -158,7 +182,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     sh[row][cl][0] = s1; sh[row][cl][1] = s2;
     __syncthreads();
     if (row == 0 && c < C) {
-        for (int r = 1; r < 16; ++r) { s1 += sh[r][cl][0]; s2 += sh[r][cl][1]; }
+        for (int r = 1; r < 32; ++r) { s1 += sh[r][cl][0]; s2 += sh[r][cl][1]; }
         if (dbeta != nullptr) dbeta[c] = (float)s1;
         if (dgamma != nullptr) dgamma[c] = (float)s2;
         coef[c] = (float)(s1 / npix);
@@ -220,7 +244,7 @@ __host__ int pixels_per_block(int npix, int C, int* nblk) {
 extern "C" int dip_bn_finalize(const float* partials, int ntiles, int Cstride, int C, const float* gamma,
                                const float* beta, float eps, float momentum, float* state, int Cs,
                                float* running_mean, float* running_var, void* stream) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(dip_cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, partials,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(dip_cdiv(C, 8)), dim3(256), 0, (hipStream_t)stream, partials,
                        ntiles, Cstride, C, gamma, beta, eps, momentum, state, Cs, running_mean, running_var);
     DIP_CHECK_LAUNCH();
     return 0;
@@ -247,7 +271,7 @@ extern "C" int dip_bn_bwd_stats(const DipGradSrc* src, const float* y, int H, in
 
 extern "C" int dip_bn_bwd_finalize(const float* partials, int nblk, int Cs, int C, int npix, float* dgamma,
                                    float* dbeta, float* coef, void* stream) {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(dip_cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, partials,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(dip_cdiv(C, 8)), dim3(256), 0, (hipStream_t)stream, partials,
                        nblk, Cs, C, npix, dgamma, dbeta, coef);
     DIP_CHECK_LAUNCH();
     return 0;

@@ -2,10 +2,13 @@
 //
 // One workgroup (4 waves) computes an 8x16-pixel x BN-channel output tile:
 //   M = 128 output pixels, N = BN output channels, K = taps x input channels.
-// K is walked in channel chunks; for each chunk the (transformed) input halo tile is staged ONCE
-// in LDS ([pixel][channel], pixel pitch == 4 mod 8 dwords -> conflict-free ds_read_b128) and all
-// KS*KS taps read shifted windows of it, so HBM/L2 sees each input pixel ~1.4x instead of 9x.
-// The packed weights of one (chunk, tap) are a [cc/4][BN][4] slab, double-buffered in LDS.
+// K is walked in "units" = (channel chunk, tap).  For each chunk the (transformed) input halo
+// tile is staged ONCE in LDS ([pixel][channel], pixel pitch == 4 mod 8 dwords -> conflict-free
+// ds_read_b128) and all KS*KS taps read shifted windows of it, so HBM/L2 sees each input pixel
+// ~1.4x instead of 9x.  The packed weights of one unit are a [cc/4][BN][4] slab that is copied
+// global->LDS by the LDS-DMA path (global_load_lds_dwordx4, no VGPR round trip), double-buffered:
+// the DMA for unit u+1 is in flight while the MFMAs of unit u run.  The next chunk's halo is
+// prefetched into registers during the last tap of the current chunk.
 // BatchNorm-apply + LeakyReLU of the PRODUCER layer, reflection/zero padding, the transposed
 // (dilated) gather of the stride-2 data gradient, bias, and the BatchNorm partial statistics of
 // the CONSUMER layer are all fused here, so activations cross HBM once per conv.
@@ -14,9 +17,15 @@
 // consecutive channels with one ds_read_b128 (lanes 0-31: channels 8kk..8kk+3, lanes 32-63:
 // 8kk+4..8kk+7) and feeds them to four MFMAs; B uses the same permutation ([c/4][n][c%4] slab),
 // so the k-sum is merely re-ordered.
+//
+// Small images: a grid of <= 256 tiles cannot fill 256 CUs and each workgroup would walk all of K
+// serially; blockIdx.z then splits the unit range (split-K) into a workspace and
+// splitk_finish_kernel sums the slices in a fixed order, adds the bias and emits the statistics.
 #include "dip_common.h"
 
 namespace {
+
+constexpr int TR_MAX = 512;   // max input channels whose BN coefficients are cached in LDS
 
 template <int KS, int S, int CCH, int BN>
 struct Cfg {
@@ -24,6 +33,7 @@ struct Cfg {
     static constexpr int HTH = (TH - 1) * S + KS, HTW = (TW - 1) * S + KS;
     static constexpr int NPIX = HTH * HTW;
     static constexpr int CMAX = CCH + 8;
+    static constexpr int C4MAX = CMAX / 4;
     static constexpr int LDP = CMAX + 4;  // == 4 (mod 8): 16 distinct 16-B slots per 16 pixels
     static constexpr int A_FLOATS = NPIX * LDP;
     static constexpr int B_FLOATS = CMAX * BN;
@@ -31,9 +41,10 @@ struct Cfg {
     static constexpr int WM = 4 / WN;
     static constexpr int MS = 4 / WM;
     static constexpr int NS = BN / 32 / WN;
-    static constexpr int A_SLOTS = (NPIX * (CMAX / 4) + 255) / 256;
-    static constexpr int B_SLOTS = ((CMAX / 4) * BN + 255) / 256;
-    static constexpr int LDS_BYTES = (A_FLOATS + 2 * B_FLOATS + NPIX) * 4;
+    static constexpr int A_SLOTS = (NPIX * C4MAX + 255) / 256;
+    static constexpr int B_SLOTS = (C4MAX * BN + 255) / 256;
+    static constexpr int LDS_BYTES = (A_FLOATS + 2 * B_FLOATS + NPIX + 2 * TR_MAX) * 4;
+    static constexpr bool PREFETCH_A = false;   // holding the next halo in VGPRs across the MFMAs spills at BN=128 (scratch reloads drain vmcnt)
 };
 
 __device__ __forceinline__ int map_src(int v, int n_in, int dil, int reflect) {
@@ -47,18 +58,40 @@ __device__ __forceinline__ int map_src(int v, int n_in, int dil, int reflect) {
     return v;
 }
 
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// One LDS-DMA piece: every active lane copies 16 B from its own global address to
+// LDS[m0_base + lane*16].  Issued through inline asm so that hipcc neither counts it nor fences
+// the following ds_reads of the OTHER weight buffer behind it (it cannot prove the two LDS
+// buffers disjoint and would drain vmcnt(0) before every MFMA block); the kernel drains the DMA
+// itself with dma_wait() in front of the barrier that publishes the buffer.  m0 is saved/restored
+// inside the statement (cdna_hip_programming.md section 5.7).
+__device__ __forceinline__ void lds_dma16(const float* gsrc, float* lds_dst_wave_uniform) {
+    const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t)lds_dst_wave_uniform);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(base)
+                 : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 template <int KS, int S, int CCH, int BN>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const DipConvDesc d, const int ntx, const int ntiles,
-                                                            const int CoutP, const int n_base) {
+                                                            const int CoutP, const int n_base, const int ksplit,
+                                                            float* __restrict__ ws) {
     using C = Cfg<KS, S, CCH, BN>;
+    constexpr int KK = KS * KS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
     float* Bs = smem + C::A_FLOATS;
     int* srcoff = reinterpret_cast<int*>(smem + C::A_FLOATS + 2 * C::B_FLOATS);
+    float* tra = smem + C::A_FLOATS + 2 * C::B_FLOATS + C::NPIX;
+    float* trb = tra + TR_MAX;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31;
     const int half = lane >> 5;
     const int wn = wave % C::WN;
@@ -75,14 +108,26 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const DipConvDesc d,
         const int sc = map_src(tx * C::TW * S + hc - d.off, d.Win, d.dil, d.pad_mode);
         srcoff[hp] = (sr < 0 || sc < 0) ? -1 : (sr * d.Win + sc);
     }
+    const bool has_tr = d.tr.a != nullptr;
+    const float slope = d.tr.slope;
+    if (has_tr) {
+        for (int c = tid; c < d.Cin; c += 256) {
+            tra[c] = d.tr.a[c];
+            trb[c] = d.tr.b[c];
+        }
+    }
 
-    // ---- chunking of the input channels ----
+    // ---- chunking of the input channels; K "units" = (chunk, tap) ----
     const int nfull = d.Cin / CCH, rem = d.Cin - nfull * CCH;
     int nchunks, last_cc;
     if (rem == 0) { nchunks = nfull; last_cc = CCH; }
     else if (rem <= 8 && nfull >= 1) { nchunks = nfull; last_cc = CCH + rem; }
     else { nchunks = nfull + 1; last_cc = rem; }
     const int cin4 = d.Cin >> 2;
+    const int nunits = nchunks * KK;
+    const int z = blockIdx.z;
+    const int u0 = (int)(((long long)z * nunits) / ksplit);
+    const int u1 = (int)(((long long)(z + 1) * nunits) / ksplit);
 
     f32x16 acc[C::MS][C::NS];
 #pragma unroll
@@ -104,137 +149,143 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const DipConvDesc d,
 #pragma unroll
     for (int ns = 0; ns < C::NS; ++ns) bcol[ns] = ((wn * C::NS + ns) * 32 + l31) * 4;
 
-    const bool has_tr = d.tr.a != nullptr;
-    const float slope = d.tr.slope;
-
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const int cb = ch * CCH;
-        const int cc = (ch == nchunks - 1) ? last_cc : CCH;
-        const int c4n = cc >> 2;
-        __syncthreads();  // previous chunk fully consumed (also orders srcoff writes on ch == 0)
-
-        // ---- stage A: halo tile of this channel chunk, producer BN+LeakyReLU applied ----
-        {
-            const int nslots = C::NPIX * c4n;
-            f32x4 v[C::A_SLOTS];
-            int dst[C::A_SLOTS];
-            int c4s[C::A_SLOTS];
+    // ---- staging helpers -------------------------------------------------------------------
+    f32x4 av[C::A_SLOTS];
+    auto chunk_cc = [&](int ch) { return (ch == nchunks - 1) ? last_cc : CCH; };
+    auto loadA = [&](int ch) {       // issue the global loads of chunk ch's halo tile into registers
+        const int cb = ch * CCH, c4n = chunk_cc(ch) >> 2;
 #pragma unroll
-            for (int i = 0; i < C::A_SLOTS; ++i) {
-                const int f = tid + i * 256;
-                dst[i] = -1;
-                v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                c4s[i] = 0;
-                if (f < nslots) {
-                    const int hp = f / c4n, c4 = f - hp * c4n;
-                    const int so = srcoff[hp];
-                    dst[i] = hp * C::LDP + c4 * 4;
-                    c4s[i] = so < 0 ? -1 : c4;
-                    if (so >= 0)
-                        v[i] = *reinterpret_cast<const f32x4*>(d.x + (size_t)so * d.Cx + cb + c4 * 4);
+        for (int i = 0; i < C::A_SLOTS; ++i) {
+            const int f = tid + i * 256;
+            const int hp = f / C::C4MAX, c4 = f - hp * C::C4MAX;
+            const int so = ((hp < C::NPIX) && (c4 < c4n)) ? srcoff[hp] : -1;
+            av[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (so >= 0) av[i] = *reinterpret_cast<const f32x4*>(d.x + (size_t)so * d.Cx + cb + c4 * 4);
+        }
+    };
+    auto storeA = [&](int ch) {      // producer BN + LeakyReLU, then LDS (slot geometry recomputed, not kept live)
+        const int cb = ch * CCH, c4n = chunk_cc(ch) >> 2;
+#pragma unroll
+        for (int i = 0; i < C::A_SLOTS; ++i) {
+            const int f = tid + i * 256;
+            const int hp = f / C::C4MAX, c4 = f - hp * C::C4MAX;
+            if ((hp < C::NPIX) && (c4 < c4n)) {
+                f32x4 o = av[i];
+                if (has_tr && srcoff[hp] >= 0) {
+                    const f32x4 a4 = *reinterpret_cast<const f32x4*>(tra + cb + c4 * 4);
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(trb + cb + c4 * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = dip_act(fmaf(a4[e], o[e], b4[e]), slope);
                 }
-            }
-#pragma unroll
-            for (int i = 0; i < C::A_SLOTS; ++i) {
-                if (dst[i] >= 0) {
-                    f32x4 o = v[i];
-                    if (has_tr && c4s[i] >= 0) {
-                        const f32x4 a4 = *reinterpret_cast<const f32x4*>(d.tr.a + cb + c4s[i] * 4);
-                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(d.tr.b + cb + c4s[i] * 4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = dip_act(fmaf(a4[e], o[e], b4[e]), slope);
-                    }
-                    *reinterpret_cast<f32x4*>(As + dst[i]) = o;
-                }
+                *reinterpret_cast<f32x4*>(As + hp * C::LDP + c4 * 4) = o;
             }
         }
-        // ---- stage B for tap 0 straight into buffer 0 ----
-        {
-            const int nb4 = c4n * BN;
+    };
+    auto dmaB = [&](int u, float* Bdst) {   // LDS-DMA of unit u's weight slab (linear image)
+        const int ch = u / KK, tap = u - ch * KK;
+        const int cb = ch * CCH, nb4 = (chunk_cc(ch) >> 2) * BN;
 #pragma unroll
-            for (int i = 0; i < C::B_SLOTS; ++i) {
-                const int f = tid + i * 256;
-                if (f < nb4) {
-                    const int c4 = f / BN, n = f - c4 * BN;
-                    f32x4 w = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (n0 + n < CoutP)
-                        w = *reinterpret_cast<const f32x4*>(
-                            d.wp + ((size_t)(0 * cin4 + (cb >> 2) + c4) * CoutP + n0 + n) * 4);
-                    *reinterpret_cast<f32x4*>(Bs + f * 4) = w;
-                }
+        for (int i = 0; i < C::B_SLOTS; ++i) {
+            const int f = tid + i * 256;
+            if (f < nb4) {
+                const int c4 = f / BN, n = f - c4 * BN;
+                const int nn = min(n0 + n, CoutP - 1);   // columns past CoutP are never stored
+                const float* src = d.wp + ((size_t)(tap * cin4 + (cb >> 2) + c4) * CoutP + nn) * 4;
+                float* dst = Bdst + (i * 256 + wave * 64) * 4;   // wave-uniform base, lane*16 B added by HW
+                lds_dma16(src, dst);
             }
         }
-        __syncthreads();
+    };
+    auto mma8 = [&](const float* Ab, const float* Bb) {   // 8 channels: 2x b128 A, 2x b128 B, 16 MFMA
+        f32x4 a[C::MS], b[C::NS];
+#pragma unroll
+        for (int ms = 0; ms < C::MS; ++ms) a[ms] = *reinterpret_cast<const f32x4*>(Ab + apix[ms]);
+#pragma unroll
+        for (int ns = 0; ns < C::NS; ++ns) b[ns] = *reinterpret_cast<const f32x4*>(Bb + half * (BN * 4) + bcol[ns]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int ms = 0; ms < C::MS; ++ms)
+#pragma unroll
+                for (int ns = 0; ns < C::NS; ++ns)
+                    acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ms][j], b[ns][j], acc[ms][ns], 0, 0, 0);
+    };
+    auto mma4 = [&](const float* Ab, const float* Bb) {   // 4-channel tail: lanes 0-31 ch 0,1; 32-63 ch 2,3
+        f32x2 a[C::MS], b[C::NS];
+#pragma unroll
+        for (int ms = 0; ms < C::MS; ++ms) a[ms] = *reinterpret_cast<const f32x2*>(Ab + apix[ms] - 2 * half);
+#pragma unroll
+        for (int ns = 0; ns < C::NS; ++ns) b[ns] = *reinterpret_cast<const f32x2*>(Bb + bcol[ns] + 2 * half);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ms = 0; ms < C::MS; ++ms)
+#pragma unroll
+                for (int ns = 0; ns < C::NS; ++ns)
+                    acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ms][j], b[ns][j], acc[ms][ns], 0, 0, 0);
+    };
 
+    // ---- prologue: first chunk's halo + first unit's weights ----
+    __syncthreads();                       // srcoff / tr tables visible
+    loadA(u0 / KK);
+    dmaB(u0, Bs);
+    storeA(u0 / KK);
+    dma_wait();
+    __syncthreads();
+
+    for (int u = u0; u < u1; ++u) {
+        const int ch = u / KK, tap = u - ch * KK;
+        const int ky = tap / KS, kx = tap - ky * KS;
+        const int cc = chunk_cc(ch);
+        const float* Bcur = Bs + ((u - u0) & 1) * C::B_FLOATS;
+        float* Bnxt = Bs + ((u - u0 + 1) & 1) * C::B_FLOATS;
+        const bool more = (u + 1) < u1;
+        const bool newchunk = more && (tap == KK - 1);
+        if (more) dmaB(u + 1, Bnxt);
+        if constexpr (C::PREFETCH_A) {
+            if (newchunk) loadA(ch + 1);   // global loads fly under this unit's MFMAs
+        }
+        const float* Ab = As + (ky * C::HTW + kx) * C::LDP;
+        if (cc == CCH) {
 #pragma unroll
-        for (int tap = 0; tap < KS * KS; ++tap) {
-            const int ky = tap / KS, kx = tap - ky * KS;
-            const float* Bcur = Bs + (tap & 1) * C::B_FLOATS;
-            float* Bnxt = Bs + ((tap + 1) & 1) * C::B_FLOATS;
-            const bool more = tap + 1 < KS * KS;
-            // prefetch next tap's weights into registers
-            f32x4 pre[C::B_SLOTS];
-            const int nb4 = c4n * BN;
-            if (more) {
-#pragma unroll
-                for (int i = 0; i < C::B_SLOTS; ++i) {
-                    const int f = tid + i * 256;
-                    if (f < nb4) {
-                        const int c4 = f / BN, n = f - c4 * BN;
-                        pre[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        if (n0 + n < CoutP)
-                            pre[i] = *reinterpret_cast<const f32x4*>(
-                                d.wp + ((size_t)((tap + 1) * cin4 + (cb >> 2) + c4) * CoutP + n0 + n) * 4);
-                    }
-                }
-            }
-            // ---- MFMA over this tap's cc channels ----
-            const int tapoff = (ky * C::HTW + kx) * C::LDP;
+            for (int kk = 0; kk < CCH / 8; ++kk) mma8(Ab + kk * 8, Bcur + kk * 2 * (BN * 4));
+        } else {
             const int kk8 = cc >> 3;
-            for (int kk = 0; kk < kk8; ++kk) {
-                f32x4 a[C::MS], b[C::NS];
-#pragma unroll
-                for (int ms = 0; ms < C::MS; ++ms)
-                    a[ms] = *reinterpret_cast<const f32x4*>(As + apix[ms] + tapoff + kk * 8);
-#pragma unroll
-                for (int ns = 0; ns < C::NS; ++ns)
-                    b[ns] = *reinterpret_cast<const f32x4*>(Bcur + (kk * 2 + half) * (BN * 4) + bcol[ns]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int ms = 0; ms < C::MS; ++ms)
-#pragma unroll
-                        for (int ns = 0; ns < C::NS; ++ns)
-                            acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ms][j], b[ns][j], acc[ms][ns], 0, 0, 0);
-            }
-            if (cc & 4) {  // 4-channel tail: lanes 0-31 take channels cc-4, cc-3; lanes 32-63 cc-2, cc-1
-                f32x2 a[C::MS], b[C::NS];
-#pragma unroll
-                for (int ms = 0; ms < C::MS; ++ms)
-                    a[ms] = *reinterpret_cast<const f32x2*>(As + apix[ms] - 4 * half + tapoff + (cc - 4) + 2 * half);
-#pragma unroll
-                for (int ns = 0; ns < C::NS; ++ns)
-                    b[ns] = *reinterpret_cast<const f32x2*>(Bcur + ((cc - 4) >> 2) * (BN * 4) + bcol[ns] + 2 * half);
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int ms = 0; ms < C::MS; ++ms)
-#pragma unroll
-                        for (int ns = 0; ns < C::NS; ++ns)
-                            acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ms][j], b[ns][j], acc[ms][ns], 0, 0, 0);
-            }
-            if (more) {
-#pragma unroll
-                for (int i = 0; i < C::B_SLOTS; ++i) {
-                    const int f = tid + i * 256;
-                    if (f < nb4) *reinterpret_cast<f32x4*>(Bnxt + f * 4) = pre[i];
-                }
-                __syncthreads();
-            }
+            for (int kk = 0; kk < kk8; ++kk) mma8(Ab + kk * 8, Bcur + kk * 2 * (BN * 4));
+            if (cc & 4) mma4(Ab + (cc - 4), Bcur + ((cc - 4) >> 2) * (BN * 4));
+        }
+        if (newchunk) {
+            __syncthreads();               // every wave is done reading the old halo
+            if constexpr (!C::PREFETCH_A) loadA(ch + 1);
+            storeA(ch + 1);
+        }
+        if (more) {
+            dma_wait();                    // this wave's DMA pieces have landed ...
+            __syncthreads();               // ... and so have everyone else's; halo stores visible
         }
     }
 
-    // ---- epilogue: bias, store, BatchNorm partial statistics ----
+    // ---- epilogue ----
+    if (ksplit > 1) {                      // split-K slice: raw partial sums to the workspace
+        float* wz = ws + (size_t)z * d.Hout * d.Wout * d.Cy;
+#pragma unroll
+        for (int ns = 0; ns < C::NS; ++ns) {
+            const int n = n0 + (wn * C::NS + ns) * 32 + l31;
+#pragma unroll
+            for (int ms = 0; ms < C::MS; ++ms) {
+                const int sub = wm * C::MS + ms;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int oy = ty * C::TH + 2 * sub + (m >> 4);
+                    const int ox = tx * C::TW + (m & 15);
+                    if (oy < d.Hout && ox < d.Wout && n < d.Cy)
+                        wz[((size_t)oy * d.Wout + ox) * d.Cy + n] = acc[ms][ns][r];
+                }
+            }
+        }
+        return;
+    }
     const int pitch = d.y_pitch > 0 ? d.y_pitch : d.Wout;
     float st_n[C::NS], st_k[C::NS], st_s1[C::NS], st_s2[C::NS];
 #pragma unroll
@@ -299,8 +350,93 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const DipConvDesc d,
     }
 }
 
+// Sum the split-K slices (fixed order), add bias, store (honouring y_pitch / accumulate) and emit
+// {count, mean, M2} partials per block: thread (prow, cg) owns 4 channels of pixels prow, prow+rpi...
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ ws, int ksplit, DipConvDesc d,
+                                                            int CoutP, int ppb) {
+    __shared__ __attribute__((aligned(16))) float sh[256 * 12];
+    const int nc4 = d.Cy >> 2;
+    int rpi = 256 / nc4;
+    if (rpi < 1) rpi = 1;
+    const int prow = threadIdx.x / nc4, cg = threadIdx.x - prow * nc4;
+    const bool active = (int)threadIdx.x < rpi * nc4;
+    const int npix = d.Hout * d.Wout;
+    const size_t zs = (size_t)npix * d.Cy;
+    const int pitch = d.y_pitch > 0 ? d.y_pitch : d.Wout;
+    f32x4 K = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = K, s2 = K;
+    float n = 0.f;
+    if (active) {
+        const int ch = cg * 4;
+        f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (d.bias != nullptr) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (ch + e < d.Cout) bias[e] = d.bias[ch + e];
+        }
+        const int p0 = blockIdx.x * ppb, p1 = min(p0 + ppb, npix);
+        for (int p = p0 + prow; p < p1; p += rpi) {
+            f32x4 v = bias;
+            for (int k = 0; k < ksplit; ++k) v += *reinterpret_cast<const f32x4*>(ws + k * zs + (size_t)p * d.Cy + ch);
+            const int oy = p / d.Wout, ox = p - oy * d.Wout;
+            float* o = d.y + ((size_t)oy * pitch + ox) * d.Cy + ch;
+            if (d.accumulate) v += *reinterpret_cast<const f32x4*>(o);
+            *reinterpret_cast<f32x4*>(o) = v;
+            if (n == 0.f) K = v;
+            n += 1.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float dv = v[e] - K[e];
+                s1[e] += dv;
+                s2[e] += dv * dv;
+            }
+        }
+    }
+    if (d.stats == nullptr) return;
+    f32x4 mean = f32x4{0.f, 0.f, 0.f, 0.f}, M2 = mean;
+    if (n > 0.f) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            mean[e] = K[e] + s1[e] / n;
+            M2[e] = s2[e] - s1[e] * s1[e] / n;
+        }
+    }
+    sh[threadIdx.x * 12] = n;
+    *reinterpret_cast<f32x4*>(sh + threadIdx.x * 12 + 4) = mean;
+    *reinterpret_cast<f32x4*>(sh + threadIdx.x * 12 + 8) = M2;
+    __syncthreads();
+    if (active && prow == 0) {
+        float na[4] = {n, n, n, n};
+        for (int r = 1; r < rpi; ++r) {
+            const float* q = sh + (r * nc4 + cg) * 12;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float me = mean[e], Me = M2[e];
+                dip_chan(na[e], me, Me, q[0], q[4 + e], q[8 + e]);
+                mean[e] = me; M2[e] = Me;
+            }
+        }
+        float* o = d.stats + (size_t)blockIdx.x * 3 * CoutP + cg * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (cg * 4 + e < CoutP) {
+                o[e] = na[e]; o[CoutP + e] = mean[e]; o[2 * CoutP + e] = M2[e];
+            }
+        }
+    }
+}
+
+int finish_ppb(int npix, int Cy, int* nblk) {
+    const int nc4 = Cy / 4;
+    int rpi = 256 / nc4;
+    if (rpi < 1) rpi = 1;
+    int ppb = dip_cdiv(npix, 512);
+    if (ppb < rpi * 4) ppb = rpi * 4;
+    *nblk = dip_cdiv(npix, ppb);
+    return ppb;
+}
+
 template <int KS, int S, int CCH, int BN>
-int launch(const DipConvDesc& d, hipStream_t st, int n_base, int grid_y) {
+int launch(const DipConvDesc& d, hipStream_t st, int n_base, int grid_y, int ksplit, float* ws) {
     using C = Cfg<KS, S, CCH, BN>;
     static bool attr_set = false;
     auto kern = conv_igemm_kernel<KS, S, CCH, BN>;
@@ -313,8 +449,8 @@ int launch(const DipConvDesc& d, hipStream_t st, int n_base, int grid_y) {
     const int ntx = dip_cdiv(d.Wout, C::TW), nty = dip_cdiv(d.Hout, C::TH);
     const int ntiles = ntx * nty;
     const int CoutP = dip_round_up(d.Cout, 32);
-    dim3 grid(ntiles, grid_y);
-    hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, st, d, ntx, ntiles, CoutP, n_base);
+    dim3 grid(ntiles, grid_y, ksplit);
+    hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, st, d, ntx, ntiles, CoutP, n_base, ksplit, ws);
     DIP_CHECK_LAUNCH();
     return 0;
 }
@@ -322,30 +458,91 @@ int launch(const DipConvDesc& d, hipStream_t st, int n_base, int grid_y) {
 // N is covered by full 128-wide blocks plus one narrower remainder launch (e.g. the 132-channel
 // data gradient of the decoder convs = 128 + a 32-wide block instead of two 128-wide ones).
 template <int KS, int S, int CCH>
-int launch_bn(const DipConvDesc& d, hipStream_t st) {
+int launch_bn(const DipConvDesc& d, hipStream_t st, int ksplit, float* ws) {
     const int CoutP = dip_round_up(d.Cout, 32);
     const int nfull = CoutP / 128, rem = CoutP - nfull * 128;
     int rc = 0;
-    if (nfull) rc = launch<KS, S, CCH, 128>(d, st, 0, nfull);
+    if (nfull) rc = launch<KS, S, CCH, 128>(d, st, 0, nfull, ksplit, ws);
     if (rc || !rem) return rc;
-    if (rem <= 32) return launch<KS, S, CCH, 32>(d, st, nfull * 128, 1);
-    if (rem <= 64) return launch<KS, S, CCH, 64>(d, st, nfull * 128, 1);
-    return launch<KS, S, CCH, 128>(d, st, nfull * 128, 1);
+    if (rem <= 32) return launch<KS, S, CCH, 32>(d, st, nfull * 128, 1, ksplit, ws);
+    if (rem <= 64) return launch<KS, S, CCH, 64>(d, st, nfull * 128, 1, ksplit, ws);
+    return launch<KS, S, CCH, 128>(d, st, nfull * 128, 1, ksplit, ws);
+}
+
+int cch_of(int ks, int stride) {
+    if (ks == 1 && stride == 1) return 32;
+    if (ks == 3 && stride == 1) return 32;
+    if (ks == 3 && stride == 2) return 16;
+    if (ks == 5 && stride == 1) return 16;
+    if (ks == 5 && stride == 2) return 8;
+    return 0;
+}
+
+int units_of(int Cin, int ks, int stride) {
+    const int cch = cch_of(ks, stride);
+    if (!cch) return 0;
+    const int nfull = Cin / cch, rem = Cin - nfull * cch;
+    const int nchunks = (rem == 0) ? nfull : ((rem <= 8 && nfull >= 1) ? nfull : nfull + 1);
+    return nchunks * ks * ks;
 }
 
 }  // namespace
 
 extern "C" int dip_conv_ntiles(int Hout, int Wout) { return dip_cdiv(Wout, 16) * dip_cdiv(Hout, 8); }
 
+// Launch plan of one convolution: split-K factor, rows of the BatchNorm partial buffer, and the
+// split-K workspace size in floats (0 when ksplit == 1).
+extern "C" int dip_conv_plan(int Hout, int Wout, int Cin, int Cout, int ks, int stride, int* ksplit,
+                             int* stats_rows, int64_t* ws_floats) {
+    const int ntiles = dip_conv_ntiles(Hout, Wout);
+    const int gy = dip_cdiv(dip_round_up(Cout, 32), 128);
+    const int units = units_of(dip_round_up(Cin, 4), ks, stride);
+    if (!units) DIP_FAIL("conv_plan: unsupported kernel size / stride");
+    int k = 1;
+    const int wgs = ntiles * gy;
+    if (wgs <= 256) {
+        k = 768 / wgs;
+        if (k > units) k = units;
+        if (k < 1) k = 1;
+    }
+    const int Cy = dip_round_up(Cout, 4);
+    *ksplit = k;
+    if (k > 1) {
+        int nblk;
+        finish_ppb(Hout * Wout, Cy, &nblk);
+        *stats_rows = nblk;
+        *ws_floats = (int64_t)k * Hout * Wout * Cy;
+    } else {
+        *stats_rows = ntiles;
+        *ws_floats = 0;
+    }
+    return 0;
+}
+
 extern "C" int dip_conv_igemm(const DipConvDesc* dp, void* stream) {
     const DipConvDesc& d = *dp;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if ((d.Cin & 3) || (d.Cx & 3) || (d.Cy & 3) || d.Cin <= 0 || d.Cin > d.Cx) DIP_FAIL("conv_igemm: channel strides must be multiples of 4");
     if (d.dil != 1 && d.dil != 2) DIP_FAIL("conv_igemm: dil must be 1 or 2");
-    if (d.ks == 1 && d.stride == 1) return launch_bn<1, 1, 32>(d, st);
-    if (d.ks == 3 && d.stride == 1) return launch_bn<3, 1, 32>(d, st);
-    if (d.ks == 3 && d.stride == 2) return launch_bn<3, 2, 16>(d, st);
-    if (d.ks == 5 && d.stride == 1) return launch_bn<5, 1, 16>(d, st);
-    if (d.ks == 5 && d.stride == 2) return launch_bn<5, 2, 8>(d, st);
-    DIP_FAIL("conv_igemm: unsupported kernel size / stride");
+    if (d.tr.a != nullptr && d.Cin > TR_MAX) DIP_FAIL("conv_igemm: more than 512 input channels with a fused transform");
+    int ksplit = d.ksplit > 1 ? d.ksplit : 1;
+    if (ksplit > 1) {
+        if (d.ws == nullptr) DIP_FAIL("conv_igemm: ksplit > 1 needs a workspace");
+        const int units = units_of(d.Cin, d.ks, d.stride);
+        if (ksplit > units) DIP_FAIL("conv_igemm: ksplit exceeds the number of K units");
+    }
+    int rc;
+    if (d.ks == 1 && d.stride == 1) rc = launch_bn<1, 1, 32>(d, st, ksplit, d.ws);
+    else if (d.ks == 3 && d.stride == 1) rc = launch_bn<3, 1, 32>(d, st, ksplit, d.ws);
+    else if (d.ks == 3 && d.stride == 2) rc = launch_bn<3, 2, 16>(d, st, ksplit, d.ws);
+    else if (d.ks == 5 && d.stride == 1) rc = launch_bn<5, 1, 16>(d, st, ksplit, d.ws);
+    else if (d.ks == 5 && d.stride == 2) rc = launch_bn<5, 2, 8>(d, st, ksplit, d.ws);
+    else DIP_FAIL("conv_igemm: unsupported kernel size / stride");
+    if (rc || ksplit == 1) return rc;
+    int nblk;
+    const int ppb = finish_ppb(d.Hout * d.Wout, d.Cy, &nblk);
+    hipLaunchKernelGGL(splitk_finish_kernel, dim3(nblk), dim3(256), 0, st, d.ws, ksplit, d,
+                       dip_round_up(d.Cout, 32), ppb);
+    DIP_CHECK_LAUNCH();
+    return 0;
 }

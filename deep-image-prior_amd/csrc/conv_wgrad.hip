@@ -172,25 +172,36 @@ int launch(const DipWgradDesc& d, hipStream_t st) {
     return 0;
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bias_partial,
-                                    int nsplit, int KK, int Cin, int Cout, int CinP, int CoutP, float* dw,
-                                    float* dbias) {
-    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+// block = 8 split-lanes x 32 consecutive outputs (o fastest -> 128-B coalesced slab reads); each
+// split-lane sums slabs sl, sl+8, ... then the 8 partials are added in a fixed order.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial,
+                                                           const float* __restrict__ bias_partial, int nsplit, int KK,
+                                                           int Cin, int Cout, int CinP, int CoutP, float* dw,
+                                                           float* dbias) {
+    __shared__ float sh[8][32];
+    const int oi = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int id = blockIdx.x * 32 + oi;
     const int total = KK * Cin * Cout;
+    float s = 0.f;
+    int o = 0, c = 0, tap = 0;
     if (id < total) {
-        const int o = id % Cout;
-        const int c = (id / Cout) % Cin;
-        const int tap = id / (Cout * Cin);
+        o = id % Cout;
+        c = (id / Cout) % Cin;
+        tap = id / (Cout * Cin);
         const size_t slab = (size_t)KK * CinP * CoutP;
         const float* p = partial + ((size_t)tap * CinP + c) * CoutP + o;
-        float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += p[k * slab];
-        dw[((size_t)o * Cin + c) * KK + tap] = s;
+        for (int k = sl; k < nsplit; k += 8) s += p[k * slab];
     } else if (dbias != nullptr && id < total + Cout) {
-        const int o = id - total;
-        float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += bias_partial[(size_t)k * CoutP + o];
-        dbias[o] = s;
+        o = id - total;
+        for (int k = sl; k < nsplit; k += 8) s += bias_partial[(size_t)k * CoutP + o];
+    }
+    sh[sl][oi] = s;
+    __syncthreads();
+    if (sl == 0) {
+#pragma unroll
+        for (int r = 1; r < 8; ++r) s += sh[r][oi];
+        if (id < total) dw[((size_t)o * Cin + c) * KK + tap] = s;
+        else if (dbias != nullptr && id < total + Cout) dbias[o] = s;
     }
 }
 
@@ -216,7 +227,7 @@ extern "C" int dip_wgrad_reduce(const float* partial, const float* bias_partial,
     const int KK = ks * ks;
     const int CinP = dip_round_up(Cin, 32), CoutP = dip_round_up(Cout, 32);
     const int total = KK * Cin * Cout + (dbias ? Cout : 0);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dip_cdiv(total, 256)), dim3(256), 0, st, partial,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dip_cdiv(total, 32)), dim3(256), 0, st, partial,
                        dbias ? bias_partial : nullptr, nsplit, KK, Cin, Cout, CinP, CoutP, dw, dbias);
     DIP_CHECK_LAUNCH();
     return 0;

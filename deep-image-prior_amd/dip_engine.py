@@ -221,7 +221,9 @@ class SkipEngine:
 
     # ------------------------------------------------------------------ per-shape plan
     def _new(self, *shape):
-        return torch.empty(shape, dtype=torch.float32, device=self.device)
+        t = torch.empty(shape, dtype=torch.float32, device=self.device)
+        self._alloc.append(t)          # the launch descriptors hold raw pointers: keep every buffer alive
+        return t
 
     def _build_plan(self, H, W, Cin_img):
         div = 2 ** self.nscales
@@ -230,7 +232,8 @@ class SkipEngine:
                 f"dip-amd: input {H}x{W} must be divisible by 2^{self.nscales} (ragged Concat crop, "
                 "models/common.py:29-37 of the reference, is not implemented)")
         self.H, self.W, self.Cimg = H, W, Cin_img
-        self.stat_need = self.wg_need = self.wgb_need = self.bwdp_need = 4
+        self.stat_need = self.wg_need = self.wgb_need = self.bwdp_need = self.ws_need = 4
+        self._alloc = []
         oc = self.out_conv
         self.n_out = oc.Cout
         # The plan is generated twice: a sizing pass (no allocations, no descriptors) that only
@@ -243,6 +246,7 @@ class SkipEngine:
                 self.bwd_scratch = self._new(self.bwdp_need)
                 self.wg_scratch = self._new(self.wg_need)
                 self.wgb_scratch = self._new(self.wgb_need)
+                self.ws_scratch = self._new(self.ws_need)
             self.x_nhwc = self._buf(H * W * round_up(Cin_img, 4))
             xin = Act(self.x_nhwc, H, W, Cin_img)
             last = self._plan_scale(0, xin, H, W)
@@ -304,18 +308,18 @@ class SkipEngine:
         assert x.C == r.Cin, (r.name, x.C, r.Cin)
         Ho = (x.H + 2 * r.P - r.ks) // r.stride + 1
         Wo = (x.W + 2 * r.P - r.ks) // r.stride + 1
-        ntiles = self.lib.dip_conv_ntiles(Ho, Wo)
-        if bn is not None:
-            need = ntiles * 3 * round_up(r.Cout, 32)
-            if self._sizing:
-                self.stat_need = max(self.stat_need, need)
+        ksplit, ntiles, wsf = N.conv_plan(Ho, Wo, round_up(x.C, 4), r.Cout, r.ks, r.stride)
         if self._sizing:
+            if bn is not None:
+                self.stat_need = max(self.stat_need, ntiles * 3 * round_up(r.Cout, 32))
+            self.ws_need = max(self.ws_need, wsf)
             return
         Cy = round_up(r.Cout, 4)
         d = N.DipConvDesc(_ptr(x.buf), x.H, x.W, x.Cs, round_up(x.C, 4), x.transform(),
                           _ptr(self.packed, r.fwd_off), _ptr(self.params, r.b_off) if r.b_off >= 0 else None,
                           _ptr(y), Ho, Wo, Cy, r.Cout, 0, r.ks, r.stride, r.pad_mode, r.P, 1, 0,
-                          _ptr(self.stats_scratch) if bn is not None else None)
+                          _ptr(self.stats_scratch) if bn is not None else None,
+                          ksplit, _ptr(self.ws_scratch) if ksplit > 1 else None)
         self.keep.append(d)
         lib = self.lib
         self.fwd_ops.append((lib.dip_conv_igemm, (C.byref(d),), "conv_fwd:" + r.name))
@@ -358,7 +362,7 @@ class SkipEngine:
         nt = self.lib.dip_conv_wgrad_ntiles(Ho, Wo)
         groups = {1: 1, 3: 1, 5: 5}[r.ks]
         wgs_per_split = (CinP // 32) * groups * ((CoutP + 127) // 128)
-        nsplit = max(1, min(nt, 512 // max(1, wgs_per_split)))
+        nsplit = max(1, min(nt, 128, 512 // max(1, wgs_per_split)))
         slab = r.ks * r.ks * CinP * CoutP
         while nsplit > 1 and nsplit * slab > (64 << 20):       # <= 256 MB of partials
             nsplit //= 2
@@ -401,11 +405,14 @@ class SkipEngine:
             ops.append((self.lib.dip_conv_igemm, (C.byref(d),), "dgrad+:" + r.name))
             return accumulate_into
         gbuf = self._buf(Hg * Wg * Cg)
+        ksplit, _, wsf = N.conv_plan(Hg, Wg, round_up(r.Cout, 4), r.Cin, r.ks, 1)
         if self._sizing:
+            self.ws_need = max(self.ws_need, wsf)
             return (gbuf, pad)
         d = N.DipConvDesc(_ptr(dy), Ho, Wo, round_up(r.Cout, 4), round_up(r.Cout, 4),
                           N.DipTransform(None, None, 1.0), _ptr(self.packed, r.dgrad_off), None,
-                          _ptr(gbuf), Hg, Wg, Cg, r.Cin, 0, r.ks, 1, N.PAD_ZERO, off, r.stride, 0, None)
+                          _ptr(gbuf), Hg, Wg, Cg, r.Cin, 0, r.ks, 1, N.PAD_ZERO, off, r.stride, 0, None,
+                          ksplit, _ptr(self.ws_scratch) if ksplit > 1 else None)
         self.keep.append(d)
         ops.append((self.lib.dip_conv_igemm, (C.byref(d),), "dgrad:" + r.name))
         return (gbuf, pad)

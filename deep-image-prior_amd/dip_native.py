@@ -34,7 +34,8 @@ class DipConvDesc(C.Structure):
                 ("Hout", C.c_int32), ("Wout", C.c_int32), ("Cy", C.c_int32), ("Cout", C.c_int32),
                 ("y_pitch", C.c_int32),
                 ("ks", C.c_int32), ("stride", C.c_int32), ("pad_mode", C.c_int32), ("off", C.c_int32),
-                ("dil", C.c_int32), ("accumulate", C.c_int32), ("stats", C.c_void_p)]
+                ("dil", C.c_int32), ("accumulate", C.c_int32), ("stats", C.c_void_p),
+                ("ksplit", C.c_int32), ("ws", C.c_void_p)]
 
 
 class DipWgradDesc(C.Structure):
@@ -67,6 +68,8 @@ _SIGS = {
     "dip_pack_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "dip_conv_igemm": (C.c_int, [C.POINTER(DipConvDesc), C.c_void_p]),
     "dip_conv_ntiles": (C.c_int, [C.c_int, C.c_int]),
+    "dip_conv_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
+                                C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "dip_conv_wgrad": (C.c_int, [C.POINTER(DipWgradDesc), C.c_void_p]),
     "dip_conv_wgrad_ntiles": (C.c_int, [C.c_int, C.c_int]),
     "dip_wgrad_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
@@ -127,3 +130,10 @@ def check(rc: int, what: str = ""):
 
 def round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
+
+
+def conv_plan(Hout, Wout, Cin, Cout, ks, stride):
+    """(ksplit, stats_rows, ws_floats) of dip_conv_plan."""
+    k, rows, wsf = C.c_int(), C.c_int(), C.c_int64()
+    check(lib().dip_conv_plan(Hout, Wout, Cin, Cout, ks, stride, C.byref(k), C.byref(rows), C.byref(wsf)), "conv_plan")
+    return k.value, rows.value, wsf.value

@@ -97,11 +97,19 @@ typedef struct DipConvDesc {
     int32_t y_pitch;             /* pixels per output row in memory (0 -> Wout); lets a 1x1 dgrad
                                     accumulate into the interior of a padded gradient buffer */
     int32_t ks, stride, pad_mode, off, dil, accumulate;
-    float* stats;                /* [ntiles][3][CoutP32] or NULL */
+    float* stats;                /* [stats_rows][3][CoutP32] or NULL (rows: dip_conv_plan) */
+    int32_t ksplit;              /* <= 1: one pass.  > 1: split-K over (channel chunk, tap) units into
+                                    `ws`, then a fixed-order reduction (small images: too few tiles
+                                    to fill 256 CUs otherwise); take the value from dip_conv_plan */
+    float* ws;                   /* split-K workspace, ksplit*Hout*Wout*Cy floats, or NULL */
 } DipConvDesc;
 int dip_conv_igemm(const DipConvDesc* d, void* stream);
-/* number of 8x16 output tiles = rows of the stats partial buffer */
+/* number of 8x16 output tiles */
 int dip_conv_ntiles(int Hout, int Wout);
+/* launch plan of one convolution: split-K factor, rows of the statistics partial buffer and the
+ * split-K workspace size in floats (0 when *ksplit == 1) */
+int dip_conv_plan(int Hout, int Wout, int Cin, int Cout, int ks, int stride, int* ksplit, int* stats_rows,
+                  int64_t* ws_floats);
 
 /* Weight gradient (autograd ConvolutionBackward, weight + bias part):
  *   dW[o][c][tap] = sum_q dy[q][o] * u[src(q,tap)][c],  db[o] = sum_q dy[q][o]

@@ -53,7 +53,7 @@ def transform(a, b, slope):
     return N.DipTransform(t.data_ptr(), t.data_ptr() + 4 * Cs, float(slope)), t
 
 
-def conv_fwd(x, w, bias, stride, pad_mode, tr=(None, None, 1.0), want_stats=False):
+def conv_fwd(x, w, bias, stride, pad_mode, tr=(None, None, 1.0), want_stats=False, split=False):
     """x [1,Cin,H,W], w OIHW -> y [1,Cout,Ho,Wo] (+ stats partial tensor)."""
     lib = N.lib()
     dev = x.device
@@ -66,13 +66,16 @@ def conv_fwd(x, w, bias, stride, pad_mode, tr=(None, None, 1.0), want_stats=Fals
     Cy = round_up(Cout, 4)
     y = torch.full((Ho * Wo * Cy,), float("nan"), dtype=torch.float32, device=dev)
     trd, keep = transform(*tr)
-    ntiles = lib.dip_conv_ntiles(Ho, Wo)
+    ksplit, ntiles, wsf = N.conv_plan(Ho, Wo, round_up(Cin, 4), Cout, ks, stride) if split else \
+        (1, lib.dip_conv_ntiles(Ho, Wo), 0)
+    ws = torch.full((max(wsf, 4),), float("nan"), dtype=torch.float32, device=dev)
     CoutP = round_up(Cout, 32)
     stats = torch.full((ntiles * 3 * CoutP,), float("nan"), dtype=torch.float32, device=dev) if want_stats else None
     bb = bias.contiguous().float() if bias is not None else None
     d = N.DipConvDesc(xb.data_ptr(), H, W, round_up(Cin, 4), round_up(Cin, 4), trd, packed.data_ptr() + 4 * fo,
                       bb.data_ptr() if bb is not None else None, y.data_ptr(), Ho, Wo, Cy, Cout, 0, ks, stride,
-                      pad_mode if P > 0 else N.PAD_ZERO, P, 1, 0, stats.data_ptr() if want_stats else None)
+                      pad_mode if P > 0 else N.PAD_ZERO, P, 1, 0, stats.data_ptr() if want_stats else None,
+                      ksplit, ws.data_ptr() if ksplit > 1 else None)
     N.check(lib.dip_conv_igemm(C.byref(d), stream(dev)), "conv_igemm")
     torch.cuda.synchronize()
     out = from_nhwc(y, Cout, Ho, Wo)
@@ -83,7 +86,7 @@ def conv_fwd(x, w, bias, stride, pad_mode, tr=(None, None, 1.0), want_stats=Fals
     return out
 
 
-def conv_dgrad(dy, w, stride, pad_mode, Hin, Win):
+def conv_dgrad(dy, w, stride, pad_mode, Hin, Win, split=False):
     """dy [1,Cout,Ho,Wo] -> gradient wrt the conv input [1,Cin,Hin,Win] (fold included)."""
     lib = N.lib()
     dev = dy.device
@@ -98,9 +101,11 @@ def conv_dgrad(dy, w, stride, pad_mode, Hin, Win):
     dyb = to_nhwc(dy)
     Cg = round_up(Cin, 4)
     g = torch.full((Hg * Wg * Cg,), float("nan"), dtype=torch.float32, device=dev)
+    ksplit, _, wsf = N.conv_plan(Hg, Wg, round_up(Cout, 4), Cin, ks, 1) if split else (1, 0, 0)
+    ws = torch.full((max(wsf, 4),), float("nan"), dtype=torch.float32, device=dev)
     d = N.DipConvDesc(dyb.data_ptr(), Ho, Wo, round_up(Cout, 4), round_up(Cout, 4), N.DipTransform(None, None, 1.0),
                       packed.data_ptr() + 4 * do, None, g.data_ptr(), Hg, Wg, Cg, Cin, 0, ks, 1, N.PAD_ZERO, off,
-                      stride, 0, None)
+                      stride, 0, None, ksplit, ws.data_ptr() if ksplit > 1 else None)
     N.check(lib.dip_conv_igemm(C.byref(d), stream(dev)), "conv_igemm(dgrad)")
     src = N.DipGradSrc(g.data_ptr(), pad, 1 if pad else 0, Cg, 0)
     gx = torch.empty(1, Cin, Hin, Win, dtype=torch.float32, device=dev)

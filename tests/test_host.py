@@ -52,16 +52,20 @@ def test_planner_launch_lists(built):
     eng = net.__dict__["_dip_engine"]
     assert len(eng.convs) == 26 and len(eng.bns) == 30
     eng.lib = built
-    eng._new = lambda *s: None
     eng._sizing = True
-    for only_sizing in (True,):
-        eng.H = eng.W = 512
-        eng.stat_need = eng.wg_need = eng.wgb_need = eng.bwdp_need = 4
-        eng.fwd_ops, eng.bwd_ops, eng.bwd_input_ops, eng.keep = [], [], [], []
-        from dip_engine import Act
-        last = eng._plan_scale(0, Act(None, 512, 512, 32), 512, 512)
-        assert (last.H, last.W, last.C) == (512, 512, 128)
+    eng._alloc = []
+    eng.H = eng.W = 512
+    eng.stat_need = eng.wg_need = eng.wgb_need = eng.bwdp_need = eng.ws_need = 4
+    eng.fwd_ops, eng.bwd_ops, eng.bwd_input_ops, eng.keep = [], [], [], []
+    from dip_engine import Act
+    last = eng._plan_scale(0, Act(None, 512, 512, 32), 512, 512)
+    assert (last.H, last.W, last.C) == (512, 512, 128)
     assert eng.stat_need >= 2048 * 3 * 128
+    assert eng.ws_need > 4            # the low-resolution scales run split-K
+    import dip_native as N
+    assert N.conv_plan(512, 512, 132, 128, 3, 1) == (1, 2048, 0)
+    k, rows, wsf = N.conv_plan(16, 16, 128, 128, 3, 1)
+    assert k == 36 and wsf == k * 16 * 16 * 128
     with pytest.raises(NotImplementedError):
         eng._build_plan(500, 512, 32)          # ragged Concat crop is not implemented
 

@@ -79,15 +79,16 @@ def _apply_tr(x, a, b, slope, dtype):
     return torch.maximum(t, slope * t)
 
 
+@pytest.mark.parametrize("split", [False, True], ids=["onepass", "splitk"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
-def test_conv_forward_and_stats(dev, case):
+def test_conv_forward_and_stats(dev, case, split):
     Cin, Cout, ks, stride, pad, Hh, Ww, use_tr = case
     x, w, b, a, bb = _mk(case)
     slope = 0.2
     ref64 = _ref_conv(_apply_tr(x, a, bb, slope, torch.float64), w, b, stride, pad, torch.float64)
     ref32 = _ref_conv(_apply_tr(x, a, bb, slope, torch.float32), w, b, stride, pad, torch.float32)
     tr = (a.to(dev), bb.to(dev), slope) if use_tr else (None, None, 1.0)
-    y, stats = H.conv_fwd(x.to(dev), w.to(dev), b.to(dev), stride, pad, tr, want_stats=True)
+    y, stats = H.conv_fwd(x.to(dev), w.to(dev), b.to(dev), stride, pad, tr, want_stats=True, split=split)
     _check("conv_fwd", y, ref64, ref32)
     # BatchNorm partials -> mean / biased variance per channel
     st = stats.cpu().double().numpy()
@@ -101,8 +102,9 @@ def test_conv_forward_and_stats(dev, case):
     assert np.allclose(var, r.var(1, unbiased=False).numpy(), rtol=2e-5)
 
 
+@pytest.mark.parametrize("split", [False, True], ids=["onepass", "splitk"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
-def test_conv_dgrad(dev, case):
+def test_conv_dgrad(dev, case, split):
     Cin, Cout, ks, stride, pad, Hh, Ww, _ = case
     x, w, b, _, _ = _mk(case, 1)
     res = {}
@@ -113,7 +115,7 @@ def test_conv_dgrad(dev, case):
         dy = torch.randn(y.shape, generator=g)
         (y * dy.to(dt)).sum().backward()
         res[dt] = xx.grad
-    gx = H.conv_dgrad(dy.to(dev), w.to(dev), stride, pad, Hh, Ww)
+    gx = H.conv_dgrad(dy.to(dev), w.to(dev), stride, pad, Hh, Ww, split=split)
     _check("conv_dgrad", gx, res[torch.float64], res[torch.float32])
 
 
