@@ -170,7 +170,10 @@ def cpu_baseline(seed=0, budget_s=25.0):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import dip_oracle as O
     from models import get_net
-    cores = os.cpu_count() or 1
+    # torch-CPU conv scaling collapses on many-core hosts: on the 256-thread MI355X host a sweep
+    # (tools/cpu_sweep.py, 256x256) gave 3.47 / 2.38 / 1.25 / 0.59 / 0.011 it/s at 16 / 32 / 64 /
+    # 128 / 256 threads, so the baseline uses the best setting, 16 threads, not all of them.
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     torch.manual_seed(seed)
     net = get_net(32, 'skip', 'reflection', skip_n33d=128, skip_n33u=128, skip_n11=4, num_scales=5,

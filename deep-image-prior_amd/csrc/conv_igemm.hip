@@ -376,7 +376,16 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
         const int p0 = blockIdx.x * ppb, p1 = min(p0 + ppb, npix);
         for (int p = p0 + prow; p < p1; p += rpi) {
             f32x4 v = bias;
-            for (int k = 0; k < ksplit; ++k) v += *reinterpret_cast<const f32x4*>(ws + k * zs + (size_t)p * d.Cy + ch);
+            const float* wp0 = ws + (size_t)p * d.Cy + ch;
+            int k = 0;
+            for (; k + 4 <= ksplit; k += 4) {           // 4 independent loads in flight, fixed add order
+                const f32x4 t0 = *reinterpret_cast<const f32x4*>(wp0 + (size_t)(k + 0) * zs);
+                const f32x4 t1 = *reinterpret_cast<const f32x4*>(wp0 + (size_t)(k + 1) * zs);
+                const f32x4 t2 = *reinterpret_cast<const f32x4*>(wp0 + (size_t)(k + 2) * zs);
+                const f32x4 t3 = *reinterpret_cast<const f32x4*>(wp0 + (size_t)(k + 3) * zs);
+                v += t0; v += t1; v += t2; v += t3;
+            }
+            for (; k < ksplit; ++k) v += *reinterpret_cast<const f32x4*>(wp0 + (size_t)k * zs);
             const int oy = p / d.Wout, ox = p - oy * d.Wout;
             float* o = d.y + ((size_t)oy * pitch + ox) * d.Cy + ch;
             if (d.accumulate) v += *reinterpret_cast<const f32x4*>(o);
@@ -500,9 +509,10 @@ extern "C" int dip_conv_plan(int Hout, int Wout, int Cin, int Cout, int ks, int 
     if (!units) DIP_FAIL("conv_plan: unsupported kernel size / stride");
     int k = 1;
     const int wgs = ntiles * gy;
-    if (wgs <= 256) {
+    if (wgs <= 256) {          // fill ~3 workgroups per CU, but keep >= 2 K-units per slice and <= 24 slices
         k = 768 / wgs;
-        if (k > units) k = units;
+        if (k > units / 2) k = units / 2;
+        if (k > 24) k = 24;
         if (k < 1) k = 1;
     }
     const int Cy = dip_round_up(Cout, 4);

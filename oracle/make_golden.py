@@ -56,6 +56,15 @@ def gen_net(name, cfg):
     cu = _refload.load_ref_common_utils()
     torch.manual_seed(cfg["seed"])
     net = rm.skip(*cfg["args"], **cfg["kw"])
+    # Non-degenerate BatchNorm affine parameters.  At the default init (gamma=1, beta=0) every
+    # BatchNorm that is followed by conv+BatchNorm has an ANALYTICALLY ZERO gamma-gradient (the
+    # loss is invariant to a joint positive rescale of (gamma, beta) and beta=0), so the
+    # reference's value would be pure roundoff and useless as a golden vector.
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0.0, 0.3)
     H, W = cfg["hw"]
     cin, cout = cfg["args"]
     z = cu.get_noise(cin, "meshgrid" if cin == 2 else "noise", (H, W)).float()

@@ -65,7 +65,7 @@ def test_planner_launch_lists(built):
     import dip_native as N
     assert N.conv_plan(512, 512, 132, 128, 3, 1) == (1, 2048, 0)
     k, rows, wsf = N.conv_plan(16, 16, 128, 128, 3, 1)
-    assert k == 36 and wsf == k * 16 * 16 * 128
+    assert k == 18 and wsf == k * 16 * 16 * 128
     with pytest.raises(NotImplementedError):
         eng._build_plan(500, 512, 32)          # ragged Concat crop is not implemented
 

@@ -1,9 +1,10 @@
 """Whole-path parity on a real MI355X: the HIP skip-net (forward + backward + fused Adam) against
 (1) golden vectors produced by the REAL reference (tests/golden, oracle/make_golden.py) and
 (2) the CPU oracle on freshly seeded inputs.  Tolerances follow SURVEY.md section 8(c):
-iteration-1 output >= 100 dB PSNR, loss rel. err <= 1e-5, every gradient tensor rel-L2 <= 1e-4
-(analytically-zero conv biases in front of a BatchNorm excluded), Adam on identical grads
-<= few ulp; trajectories are chaotic, so later iterations are compared on end quality only."""
+iteration-1 output >= 100 dB PSNR, loss rel. err <= 1e-5, every gradient tensor as close to the
+fp64 truth as the reference's own fp32 CPU path (x4 for summation order, + 2e-5 relative floor),
+Adam on identical grads <= few ulp; trajectories are chaotic, so later iterations are compared on
+end quality only."""
 import copy
 import json
 import os
@@ -40,18 +41,31 @@ def _psnr(a, b):
     return O.psnr(np.asarray(a), np.asarray(b))
 
 
-def _grad_report(named_grads, ref, zero_bias_thresh=1e-6):
+def _oracle_grads(spec, sd, z, loss_fn, dtype):
+    """Oracle forward/backward in `dtype` (fp64 = the truth, fp32 = the reference's own noise)."""
+    onet = O.OracleNet(spec, {k: v.to(dtype) for k, v in sd.items()})
+    out = onet(z.to(dtype))
+    loss = loss_fn(out, dtype)
+    loss.backward()
+    return out.detach(), loss.item(), {k: p.grad.detach() for k, p in zip(onet.names, onet.params)}
+
+
+def _grad_report(named_grads, g64, g32, ratio=4.0, floor=2e-5):
+    """Every gradient tensor must be as close to the fp64 truth as the reference's own fp32 CPU
+    path is, up to `ratio` (different summation orders) plus an fp32 roundoff floor:
+        ||g_hip - g64|| <= ratio * ||g_ref32 - g64|| + floor * ||g64||.
+    This is scale-free for the many gradients that are ANALYTICALLY ZERO on this net (conv biases
+    in front of a train-mode BatchNorm; BatchNorm gammas at beta = 0): their fp32 values are
+    roundoff in both implementations and a relative comparison between them is meaningless."""
     worst, worst_k = 0.0, None
     for k, g in named_grads.items():
-        r = torch.as_tensor(ref[k]).double()
+        t = torch.as_tensor(g64[k]).double()
+        r = torch.as_tensor(g32[k]).double()
         g = g.detach().cpu().double()
-        if k.endswith(".bias") and r.dim() == 1 and r.abs().max() < zero_bias_thresh:
-            # conv bias feeding a train-mode BatchNorm: true gradient is 0, the reference value is roundoff
-            assert g.abs().max() < 1e-4, (k, g.abs().max().item())
-            continue
-        e = ((g - r).norm() / (r.norm() + 1e-30)).item()
-        if e > worst:
-            worst, worst_k = e, k
+        e_hip, e_ref = (g - t).norm().item(), (r - t).norm().item()
+        tol = ratio * e_ref + floor * t.norm().item() + 1e-12
+        if e_hip / tol > worst:
+            worst, worst_k = e_hip / tol, f"{k} (err {e_hip:.2e}, ref-fp32 err {e_ref:.2e}, |g| {t.norm().item():.2e})"
     return worst, worst_k
 
 
@@ -78,11 +92,18 @@ def test_golden_reference_vectors(dev, name):
     psnr = _psnr(out.detach().cpu().numpy(), gold["out"])
     rel = abs(loss.item() - float(gold["loss"])) / float(gold["loss"])
     grads = {k: p.grad for k, p in net.named_parameters()}
-    worst, wk = _grad_report(grads, {k: gold["grad/" + k] for k in grads})
-    print(f"{name}: out PSNR {psnr:.1f} dB, loss rel {rel:.2e}, worst grad rel-L2 {worst:.2e} ({wk})")
+    # truth = the oracle in fp64 on the fixture's weights; the reference's fp32 gradients (golden) set the noise scale
+    from test_oracle import _spec
+    learn = {k: v for k, v in sd.items() if k in O.param_shapes(_spec(cfg))}
+    zc, tc, mc = (torch.from_numpy(gold[k]) for k in ("z", "target", "mask"))
+    _, _, g64 = _oracle_grads(_spec(cfg), learn, zc,
+                              lambda o, dt: torch.nn.functional.mse_loss(o * mc.to(dt), tc.to(dt) * mc.to(dt)),
+                              torch.float64)
+    worst, wk = _grad_report(grads, g64, {k: gold["grad/" + k] for k in grads})
+    print(f"{name}: out PSNR {psnr:.1f} dB, loss rel {rel:.2e}, worst grad err/tol {worst:.2f} ({wk})")
     assert psnr >= 100.0, psnr
     assert rel <= 1e-5, rel
-    assert worst <= 1e-4, (worst, wk)
+    assert worst <= 1.0, (worst, wk)
     # BatchNorm running statistics were updated like nn.BatchNorm2d (momentum 0.1)
     for k, v in net.state_dict().items():
         if k.endswith("num_batches_tracked"):
@@ -137,15 +158,14 @@ def test_default_net_64_against_oracle_and_digest(dev):
     o = out.detach().cpu().double()
     assert abs(o.sum().item() - dg["out"]["sum"]) <= 1e-5 * dg["out"]["abssum"]
     assert abs(loss.item() - dg["loss"]) / dg["loss"] <= 1e-5
-    for k, p in net.named_parameters():
-        g, r = p.grad.detach().cpu().double(), dg["grads"][k]
-        if k.endswith(".bias") and r["sq"] ** 0.5 < 1e-6:
-            continue
-        # digest check: L2 norm and 5 samples of every gradient tensor
-        assert abs((g * g).sum().item() ** 0.5 - r["sq"] ** 0.5) <= 2e-4 * r["sq"] ** 0.5 + 1e-12, k
-        idx = torch.linspace(0, g.numel() - 1, 5).long()
-        assert torch.allclose(g.flatten()[idx], torch.tensor(r["samples"]).double(), rtol=2e-3,
-                              atol=2e-4 * (r["sq"] / g.numel()) ** 0.5), k
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items() if k in O.param_shapes(O.default_spec())}
+    lf = lambda o_, dt: torch.nn.functional.mse_loss(o_, target.to(dt))
+    _, _, g64 = _oracle_grads(O.default_spec(), sd, z, lf, torch.float64)
+    _, l32, g32 = _oracle_grads(O.default_spec(), sd, z, lf, torch.float32)
+    assert abs(l32 - dg["loss"]) <= 1e-6 * dg["loss"]           # the oracle reproduces the reference digest
+    worst, wk = _grad_report({k: p.grad for k, p in net.named_parameters()}, g64, g32)
+    print(f"default net 64x64: worst grad err/tol {worst:.2f} ({wk})")
+    assert worst <= 1.0, (worst, wk)
 
 
 @pytest.mark.parametrize("hw,mode,nskip", [((96, 64), "bilinear", 4), ((64, 64), "nearest", 128)])
@@ -160,21 +180,19 @@ def test_against_oracle_fresh_seed(dev, hw, mode, nskip):
     z = torch.rand(1, 32, *hw) * 0.1
     target = torch.rand(1, 3, *hw)
     spec = O.SkipSpec(32, 3, [128] * 5, [128] * 5, [nskip] * 5, pad="reflection", upsample_mode=mode)
-    onet = O.OracleNet(spec, sd)
-    oo = onet(z)
-    lo = torch.nn.functional.mse_loss(oo, target)
-    lo.backward()
+    lf = lambda o_, dt: torch.nn.functional.mse_loss(o_, target.to(dt))
+    _, _, g64 = _oracle_grads(spec, sd, z, lf, torch.float64)
+    oo, lo, g32 = _oracle_grads(spec, sd, z, lf, torch.float32)
     net = net.to(dev)
     out = net(z.to(dev))
     loss = torch.nn.functional.mse_loss(out, target.to(dev))
     loss.backward()
     torch.cuda.synchronize()
-    psnr = _psnr(out.detach().cpu().numpy(), oo.detach().numpy())
-    rel = abs(loss.item() - lo.item()) / lo.item()
-    worst, wk = _grad_report({k: p.grad for k, p in net.named_parameters()},
-                             {k: p.grad for k, p in zip(onet.names, onet.params)})
-    print(f"oracle {hw} {mode} skip{nskip}: PSNR {psnr:.1f} dB, loss rel {rel:.2e}, grad {worst:.2e} ({wk})")
-    assert psnr >= 100.0 and rel <= 1e-5 and worst <= 1e-4, (psnr, rel, worst, wk)
+    psnr = _psnr(out.detach().cpu().numpy(), oo.numpy())
+    rel = abs(loss.item() - lo) / lo
+    worst, wk = _grad_report({k: p.grad for k, p in net.named_parameters()}, g64, g32)
+    print(f"oracle {hw} {mode} skip{nskip}: PSNR {psnr:.1f} dB, loss rel {rel:.2e}, grad err/tol {worst:.2f} ({wk})")
+    assert psnr >= 100.0 and rel <= 1e-5 and worst <= 1.0, (psnr, rel, worst, wk)
 
 
 def test_input_gradient_and_opt_over_input(dev):

@@ -5,7 +5,8 @@ set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-LOG=gpurun_out/round.log
+ROOTD=$(pwd)
+LOG=$ROOTD/gpurun_out/round.log
 : > $LOG
 run() { echo "=== $* ===" | tee -a $LOG; timeout "${TMO:-600}" "$@" >> $LOG 2>&1; echo "--- rc=$? ---" | tee -a $LOG; }
 rocm-smi --showproductname 2>/dev/null | head -8 >> $LOG
@@ -22,6 +23,7 @@ if [ "${SKIP_BENCH:-0}" != "1" ]; then
   tail -3 $LOG | grep '^{' > gpurun_out/bench.json
 fi
 if [ "${DO_PROF:-0}" = "1" ]; then
-  ( cd /tmp && TMO=900 run rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/prof -o trace -- python $OLDPWD/bench.py --steps 10 --warmup 3 --no-cpu-baseline )
+  ( cd /tmp && TMO=900 run rocprofv3 --kernel-trace --stats -d $ROOTD/gpurun_out/prof -o trace -- python $ROOTD/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline )
+  find $ROOTD/gpurun_out/prof -name "*kernel_stats*" | head -3 | tee -a $LOG
 fi
 grep -E "passed|failed|error|rc=" $LOG | tail -40
