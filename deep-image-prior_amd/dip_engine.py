@@ -259,6 +259,7 @@ class SkipEngine:
             self._emit_wgrad(oc, last, self.dy_out, pre)
             du_last = self._emit_dgrad(oc, last, self.dy_out, pre)
             dy_last = self._emit_bn_act_bwd(last, du_last, pre)
+            self.dbg_top = {"du_last": du_last, "dy_last": dy_last, "last": last}
             self.bwd_ops = pre + self._bwd_scale_ops(0, dy_last)
         self.shape_key = (H, W, Cin_img)
 
@@ -296,6 +297,7 @@ class SkipEngine:
             st["u1_y"] = self._buf(H * W * round_up(s.up1.Cout, 4))
             self._emit_conv_fwd(s.up1, u, st["u1_y"], s.up1_bn)
             res = Act(st["u1_y"], H, W, s.up1.Cout, s.up1_bn, self.slope)
+            st["u1"] = res
         st["xin"], st["H"], st["W"] = xin, H, W
         s.st = st
         return res

@@ -186,10 +186,20 @@ def _conv(x, sd, key, k, stride, pad):
     return F.conv2d(x, w, b, stride=stride, padding=to_pad)
 
 
-def _bn_act(x, sd, key, act=True, eps=1e-5):
-    """bn() + act(): BatchNorm2d in TRAIN mode (batch stats), LeakyReLU(0.2)."""
+def _bn_act(x, sd, key, act=True, eps=1e-5, masks=None):
+    """bn() + act(): BatchNorm2d in TRAIN mode (batch stats), LeakyReLU(0.2).
+
+    `masks` (test-only): {bn_key: bool tensor} imposes the LeakyReLU branch pattern of ANOTHER
+    implementation.  LeakyReLU's derivative jumps at 0, so two correct fp32 implementations whose
+    pre-activations differ by roundoff can pick different branches for an element with z ~ 1e-7;
+    that single element changes the gradient by O(1/sqrt(numel)) ~ 1e-3 relative.  With the pattern
+    imposed, the oracle differentiates exactly the piecewise-linear branch the other side took."""
     x = F.batch_norm(x, None, None, sd[key + ".weight"], sd[key + ".bias"], True, 0.1, eps)
-    return F.leaky_relu(x, 0.2) if act else x
+    if not act:
+        return x
+    if masks is not None and key in masks:
+        return torch.where(masks[key], x, 0.2 * x)
+    return F.leaky_relu(x, 0.2)
 
 
 def _concat(inputs):
@@ -204,7 +214,7 @@ def _concat(inputs):
 
 
 def skip_forward(spec: SkipSpec, sd: Dict[str, torch.Tensor], x: torch.Tensor,
-                 taps: Optional[dict] = None) -> torch.Tensor:
+                 taps: Optional[dict] = None, masks: Optional[dict] = None) -> torch.Tensor:
     """Forward of the skip encoder-decoder; ``sd`` is keyed like the reference state_dict.
 
     ``taps`` (optional dict) receives named intermediate tensors for per-layer parity tests.
@@ -216,15 +226,15 @@ def skip_forward(spec: SkipSpec, sd: Dict[str, torch.Tensor], x: torch.Tensor,
         ns = spec.num_channels_skip[i]
         fd, fu = spec.filter_size_down[i], spec.filter_size_up[i]
         d = _conv(x, sd, k.down_a, fd, 2, spec.pad)
-        d = _bn_act(d, sd, k.down_a_bn)
+        d = _bn_act(d, sd, k.down_a_bn, masks=masks)
         d = _conv(d, sd, k.down_b, fd, 1, spec.pad)
-        d = _bn_act(d, sd, k.down_b_bn)
+        d = _bn_act(d, sd, k.down_b_bn, masks=masks)
         if i < spec.n_scales - 1:
             d = scale(i + 1, d)
         d = F.interpolate(d, scale_factor=2, mode=spec.upsample_mode[i])
         if ns:
             s = _conv(x, sd, k.skip_conv, spec.filter_skip_size, 1, spec.pad)
-            s = _bn_act(s, sd, k.skip_bn)
+            s = _bn_act(s, sd, k.skip_bn, masks=masks)
             y = _concat([s, d])
         else:
             y = d
@@ -234,10 +244,10 @@ def skip_forward(spec: SkipSpec, sd: Dict[str, torch.Tensor], x: torch.Tensor,
         y = _conv(y, sd, k.up, fu, 1, spec.pad)
         if taps is not None:
             taps[f"up{i}_raw"] = y
-        y = _bn_act(y, sd, k.up_bn)
+        y = _bn_act(y, sd, k.up_bn, masks=masks)
         if spec.need1x1_up:
             y = _conv(y, sd, k.up1, 1, 1, spec.pad)
-            y = _bn_act(y, sd, k.up1_bn)
+            y = _bn_act(y, sd, k.up1_bn, masks=masks)
         return y
 
     y = scale(0, x)
@@ -357,8 +367,8 @@ class OracleNet(torch.nn.Module):
     def sd(self):
         return {k: p for k, p in zip(self.names, self.params)}
 
-    def forward(self, x, taps=None):
-        return skip_forward(self.spec, self.sd(), x, taps)
+    def forward(self, x, taps=None, masks=None):
+        return skip_forward(self.spec, self.sd(), x, taps, masks)
 
 
 def optimize_adam(parameters, closure, LR, num_iter):

@@ -137,3 +137,24 @@ def conv_wgrad(x, dy, ks, stride, pad_mode, tr=(None, None, 1.0), nsplit=None, b
                                  dw.data_ptr(), db.data_ptr() if bias else None, stream(dev)), "wgrad_reduce")
     torch.cuda.synchronize()
     return dw, (db if bias else None)
+
+
+def lrelu_masks(net, spec):
+    """LeakyReLU branch pattern (z = a*y + b > 0) realised by the HIP forward, keyed by the
+    oracle's BatchNorm key, as CPU bool tensors [1,C,H,W] (see dip_oracle._bn_act)."""
+    import dip_oracle as O
+    eng = net.__dict__["_dip_engine"]
+    keys, _ = O.scale_keys(spec)
+    masks = {}
+    for i, k in enumerate(keys):
+        st = eng.sc[i].st
+        for name, key in (("s_act", k.skip_bn), ("d1", k.down_a_bn), ("d2", k.down_b_bn), ("u", k.up_bn),
+                          ("u1", k.up1_bn)):
+            a = st.get(name)
+            if a is None or key is None:
+                continue
+            state = a.bn.state.view(4, a.Cs)
+            y = a.buf.view(a.H, a.W, a.Cs)
+            z = torch.addcmul(state[3], state[2], y)            # fma(a, y, b), as the kernels do
+            masks[key] = (z[:, :, :a.C] > 0).permute(2, 0, 1)[None].cpu()
+    return masks

@@ -41,16 +41,18 @@ def _psnr(a, b):
     return O.psnr(np.asarray(a), np.asarray(b))
 
 
-def _oracle_grads(spec, sd, z, loss_fn, dtype):
-    """Oracle forward/backward in `dtype` (fp64 = the truth, fp32 = the reference's own noise)."""
+def _oracle_grads(spec, sd, z, loss_fn, dtype, masks=None):
+    """Oracle forward/backward in `dtype` (fp64 = the truth, fp32 = the reference's own noise).
+    `masks`: LeakyReLU branch pattern of the HIP forward (hipops.lrelu_masks) -- the truth for the
+    HIP gradient is the fp64 gradient of the branch pattern it actually realised."""
     onet = O.OracleNet(spec, {k: v.to(dtype) for k, v in sd.items()})
-    out = onet(z.to(dtype))
+    out = onet(z.to(dtype), None, masks)
     loss = loss_fn(out, dtype)
     loss.backward()
     return out.detach(), loss.item(), {k: p.grad.detach() for k, p in zip(onet.names, onet.params)}
 
 
-def _grad_report(named_grads, g64, g32, ratio=4.0, floor=2e-5):
+def _grad_report(named_grads, g64, g32, g64n=None, ratio=4.0, floor=2e-5):
     """Every gradient tensor must be as close to the fp64 truth as the reference's own fp32 CPU
     path is, up to `ratio` (different summation orders) plus an fp32 roundoff floor:
         ||g_hip - g64|| <= ratio * ||g_ref32 - g64|| + floor * ||g64||.
@@ -59,10 +61,11 @@ def _grad_report(named_grads, g64, g32, ratio=4.0, floor=2e-5):
     roundoff in both implementations and a relative comparison between them is meaningless."""
     worst, worst_k = 0.0, None
     for k, g in named_grads.items():
-        t = torch.as_tensor(g64[k]).double()
+        t = torch.as_tensor(g64[k]).double()                      # fp64 truth for the HIP branch pattern
+        tn = torch.as_tensor((g64n or g64)[k]).double()           # fp64 truth for the reference's pattern
         r = torch.as_tensor(g32[k]).double()
         g = g.detach().cpu().double()
-        e_hip, e_ref = (g - t).norm().item(), (r - t).norm().item()
+        e_hip, e_ref = (g - t).norm().item(), (r - tn).norm().item()
         tol = ratio * e_ref + floor * t.norm().item() + 1e-12
         if e_hip / tol > worst:
             worst, worst_k = e_hip / tol, f"{k} (err {e_hip:.2e}, ref-fp32 err {e_ref:.2e}, |g| {t.norm().item():.2e})"
@@ -96,10 +99,11 @@ def test_golden_reference_vectors(dev, name):
     from test_oracle import _spec
     learn = {k: v for k, v in sd.items() if k in O.param_shapes(_spec(cfg))}
     zc, tc, mc = (torch.from_numpy(gold[k]) for k in ("z", "target", "mask"))
-    _, _, g64 = _oracle_grads(_spec(cfg), learn, zc,
-                              lambda o, dt: torch.nn.functional.mse_loss(o * mc.to(dt), tc.to(dt) * mc.to(dt)),
-                              torch.float64)
-    worst, wk = _grad_report(grads, g64, {k: gold["grad/" + k] for k in grads})
+    lf = lambda o, dt: torch.nn.functional.mse_loss(o * mc.to(dt), tc.to(dt) * mc.to(dt))
+    import hipops
+    _, _, g64 = _oracle_grads(_spec(cfg), learn, zc, lf, torch.float64, hipops.lrelu_masks(net, _spec(cfg)))
+    _, _, g64n = _oracle_grads(_spec(cfg), learn, zc, lf, torch.float64)
+    worst, wk = _grad_report(grads, g64, {k: gold["grad/" + k] for k in grads}, g64n)
     print(f"{name}: out PSNR {psnr:.1f} dB, loss rel {rel:.2e}, worst grad err/tol {worst:.2f} ({wk})")
     assert psnr >= 100.0, psnr
     assert rel <= 1e-5, rel
@@ -160,10 +164,12 @@ def test_default_net_64_against_oracle_and_digest(dev):
     assert abs(loss.item() - dg["loss"]) / dg["loss"] <= 1e-5
     sd = {k: v.detach().cpu() for k, v in net.state_dict().items() if k in O.param_shapes(O.default_spec())}
     lf = lambda o_, dt: torch.nn.functional.mse_loss(o_, target.to(dt))
-    _, _, g64 = _oracle_grads(O.default_spec(), sd, z, lf, torch.float64)
+    import hipops
+    _, _, g64 = _oracle_grads(O.default_spec(), sd, z, lf, torch.float64, hipops.lrelu_masks(net, O.default_spec()))
+    _, _, g64n = _oracle_grads(O.default_spec(), sd, z, lf, torch.float64)
     _, l32, g32 = _oracle_grads(O.default_spec(), sd, z, lf, torch.float32)
     assert abs(l32 - dg["loss"]) <= 1e-6 * dg["loss"]           # the oracle reproduces the reference digest
-    worst, wk = _grad_report({k: p.grad for k, p in net.named_parameters()}, g64, g32)
+    worst, wk = _grad_report({k: p.grad for k, p in net.named_parameters()}, g64, g32, g64n)
     print(f"default net 64x64: worst grad err/tol {worst:.2f} ({wk})")
     assert worst <= 1.0, (worst, wk)
 
@@ -181,16 +187,18 @@ def test_against_oracle_fresh_seed(dev, hw, mode, nskip):
     target = torch.rand(1, 3, *hw)
     spec = O.SkipSpec(32, 3, [128] * 5, [128] * 5, [nskip] * 5, pad="reflection", upsample_mode=mode)
     lf = lambda o_, dt: torch.nn.functional.mse_loss(o_, target.to(dt))
-    _, _, g64 = _oracle_grads(spec, sd, z, lf, torch.float64)
+    _, _, g64n = _oracle_grads(spec, sd, z, lf, torch.float64)
     oo, lo, g32 = _oracle_grads(spec, sd, z, lf, torch.float32)
     net = net.to(dev)
     out = net(z.to(dev))
     loss = torch.nn.functional.mse_loss(out, target.to(dev))
     loss.backward()
     torch.cuda.synchronize()
+    import hipops
+    _, _, g64 = _oracle_grads(spec, sd, z, lf, torch.float64, hipops.lrelu_masks(net, spec))
     psnr = _psnr(out.detach().cpu().numpy(), oo.numpy())
     rel = abs(loss.item() - lo) / lo
-    worst, wk = _grad_report({k: p.grad for k, p in net.named_parameters()}, g64, g32)
+    worst, wk = _grad_report({k: p.grad for k, p in net.named_parameters()}, g64, g32, g64n)
     print(f"oracle {hw} {mode} skip{nskip}: PSNR {psnr:.1f} dB, loss rel {rel:.2e}, grad err/tol {worst:.2f} ({wk})")
     assert psnr >= 100.0 and rel <= 1e-5 and worst <= 1.0, (psnr, rel, worst, wk)
 

@@ -80,3 +80,72 @@ print("dy wrt up0_raw: rel err vs oracle64 = %.3e" % ((dyu - ref).norm() / ref.n
 dcat = nhwc(s0.dbg["dcat"], s0.up.Cin)
 refc = taps64["cat0"].grad[0]
 print("dcat0: rel err vs oracle64 = %.3e" % ((dcat - refc).norm() / refc.norm()))
+
+# ---- stage-by-stage check of the top of the backward pass from the engine's own buffers
+top = eng.dbg_top
+last = top["last"]
+C_ = last.C
+gout = (2.0 * (out.detach() - target.to(dev)) / out.numel()).cpu().double()[0]
+o_ = out.detach().cpu().double()[0]
+dyo_ref = gout * o_ * (1 - o_)
+dyo = nhwc(eng.dy_out, 3)
+print("dy_out rel err: %.3e" % ((dyo - dyo_ref).norm() / dyo_ref.norm()))
+Wout = dict(net.named_parameters())["9.1.weight"].detach().cpu().double()[:, :, 0, 0]     # [3,128]
+du_ref = torch.einsum("ohw,oc->chw", dyo, Wout)
+du = nhwc(top["du_last"][0], C_)
+print("du_last (dgrad of out conv) rel err: %.3e" % ((du - du_ref).norm() / du_ref.norm()))
+st1 = last.bn.state.view(4, last.Cs).cpu().double()
+y1 = nhwc(last.buf, C_)
+mean_t = y1.reshape(C_, -1).mean(1); var_t = y1.reshape(C_, -1).var(1, unbiased=False)
+print("state mean err %.3e  rstd rel err %.3e" % ((st1[0, :C_] - mean_t).abs().max(), ((st1[1, :C_] - 1 / torch.sqrt(var_t + 1e-5)) * torch.sqrt(var_t + 1e-5)).abs().max()))
+xh = (y1 - st1[0, :C_].view(-1, 1, 1)) * st1[1, :C_].view(-1, 1, 1)
+zz = st1[2, :C_].view(-1, 1, 1) * y1 + st1[3, :C_].view(-1, 1, 1)
+dz = torch.where(zz > 0, du, 0.2 * du)
+N_ = H * W
+k1 = dz.reshape(C_, -1).sum(1) / N_
+k2 = (dz * xh).reshape(C_, -1).sum(1) / N_
+coef = last.bn.coef.view(2, last.Cs).cpu().double()
+print("coef k1 rel err %.3e  k2 rel err %.3e" % (((coef[0, :C_] - k1).norm() / k1.norm()), ((coef[1, :C_] - k2).norm() / k2.norm())))
+dy_ref = st1[2, :C_].view(-1, 1, 1) * (dz - k1.view(-1, 1, 1) - xh * k2.view(-1, 1, 1))
+dyl = nhwc(top["dy_last"], C_)
+print("dy_last rel err vs fp64 from own buffers: %.3e" % ((dyl - dy_ref).norm() / dy_ref.norm()))
+gam = dict(net.named_parameters())["7.weight"]
+print("dgamma rel err %.3e dbeta rel err %.3e" % (((gam.grad.cpu().double() - k2 * N_).norm() / (k2 * N_).norm()),
+      ((dict(net.named_parameters())["7.bias"].grad.cpu().double() - k1 * N_).norm() / (k1 * N_).norm())))
+print("dgamma vs oracle64 rel %.3e ; own-buffer dgamma vs oracle64 rel %.3e" % (
+      ((gam.grad.cpu().double() - g64["7.weight"]).norm() / g64["7.weight"].norm()), ((k2 * N_ - g64["7.weight"]).norm() / g64["7.weight"].norm())))
+
+# ---- forward intermediates vs the fp64 oracle
+uy_ref = taps64["up0_raw"].detach()[0]
+print("forward up0_raw (conv 3.1 output incl. bias): rel err %.3e, max abs %.3e" % ((uy - uy_ref).norm() / uy_ref.norm(), (uy - uy_ref).abs().max()))
+pc = ((uy - uy_ref).reshape(uy.shape[0], -1).mean(1))
+print("   per-channel mean of the error: max |.| %.3e  (per-channel std of y: %.3e)" % (pc.abs().max(), uy_ref.reshape(uy.shape[0], -1).std(1).mean()))
+cat_ref = taps64["cat0"].detach()[0]
+catb = nhwc(s0.st["cat"], s0.up.Cin)
+print("forward cat0: rel err %.3e" % ((catb - cat_ref).norm() / cat_ref.norm()))
+uact_ref = torch.nn.functional.leaky_relu(torch.nn.functional.batch_norm(
+    taps64["up0_raw"].detach(), None, None, sd["4.weight"].double(), sd["4.bias"].double(), True, 0.1, 1e-5), 0.2)[0]
+print("forward u = lrelu(bn(up0_raw)): rel err %.3e" % ((uact - uact_ref).norm() / uact_ref.norm()))
+dW_mixed = torch.einsum("ohw,chw->oc", dy, uact_ref)
+print("dW(6.1) with OUR dy and ORACLE u: rel err vs oracle64 %.3e" % ((dW_mixed - g64["6.1.weight"][:, :, 0, 0]).norm() / dW.norm()))
+
+# ---- oracle top-of-net replicated in fp64 to get the gradient wrt the raw output of conv 6.1
+import torch.nn.functional as F
+sdd = {k: v.double() for k, v in sd.items()}
+u_o = F.leaky_relu(F.batch_norm(taps64["up0_raw"].detach(), None, None, sdd["4.weight"], sdd["4.bias"], True, 0.1, 1e-5), 0.2)
+y61 = F.conv2d(u_o, sdd["6.1.weight"], sdd["6.1.bias"]).detach().requires_grad_(True)
+act = F.leaky_relu(F.batch_norm(y61, None, None, sdd["7.weight"], sdd["7.bias"], True, 0.1, 1e-5), 0.2)
+act.retain_grad()
+o_ = torch.sigmoid(F.conv2d(act, sdd["9.1.weight"], sdd["9.1.bias"]))
+F.mse_loss(o_, target.double()).backward()
+dy_true = y61.grad[0]
+print("check: einsum(dy_true, u_oracle) vs oracle grad 6.1.weight: %.3e" %
+      ((torch.einsum("ohw,chw->oc", dy_true, u_o[0]) - g64["6.1.weight"][:, :, 0, 0]).norm() / g64["6.1.weight"].norm()))
+print("our u1_y vs oracle y61: rel %.3e" % ((y1 - y61.detach()[0]).norm() / y61.detach().norm()))
+print("our dy_last vs oracle dy: rel %.3e" % ((dyl - dy_true).norm() / dy_true.norm()))
+print("our du_last vs oracle act.grad: rel %.3e" % ((du - act.grad[0]).norm() / act.grad.norm()))
+print("our out vs oracle out: rel %.3e" % ((out.detach().cpu().double()[0] - o_.detach()[0]).norm() / o_.norm()))
+e = (dyl - dy_true)
+print("error structure: per-channel mean of err / rms(dy): %.3e ; corr(err, xhat) per channel max: %.3e" % (
+      (e.reshape(C_, -1).mean(1).abs().max() / dy_true.pow(2).mean().sqrt()),
+      ((e * xh).reshape(C_, -1).mean(1).abs().max() / dy_true.pow(2).mean().sqrt())))
