@@ -6,22 +6,22 @@ namespace {
 
 // ------------------------------------------------------------------------------------------
 // forward finalise: Chan-combine per-tile {count, mean, M2} partials (fp64) -> state + running
-// grid.x = ceil(C/8); block = 256 = 32 tile-rows x 8 channels
+// grid.x = ceil(C/4); block = 256 = 64 tile-rows x 4 channels
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partials, int ntiles,
                                                           int Cstride, int C, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float eps, float momentum,
                                                           float* state, int Cs, float* running_mean,
                                                           float* running_var) {
-    // block = 32 tile-rows x 8 channels.  Two passes of plain fp64 FMAs (no division in the loops):
+    // block = 64 tile-rows x 4 channels.  Two passes of plain fp64 FMAs (no division in the loops):
     //   N = sum n_i, mean = sum n_i m_i / N ;  M2 = sum (M2_i + n_i (m_i - mean)^2)
-    __shared__ double sh[32][8][2];
-    __shared__ double shmean[8];
-    const int cl = threadIdx.x & 7, row = threadIdx.x >> 3;
-    const int c = blockIdx.x * 8 + cl;
+    __shared__ double sh[64][4][2];
+    __shared__ double shmean[4];
+    const int cl = threadIdx.x & 3, row = threadIdx.x >> 2;
+    const int c = blockIdx.x * 4 + cl;
     double n = 0.0, nm = 0.0;
     if (c < C) {
-        for (int t = row; t < ntiles; t += 32) {
+        for (int t = row; t < ntiles; t += 64) {
             const float* p = partials + (size_t)t * 3 * Cstride + c;
             const double ni = (double)p[0];
             n += ni;
@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     sh[row][cl][0] = n; sh[row][cl][1] = nm;
     __syncthreads();
     if (row == 0) {
-        for (int r = 1; r < 32; ++r) { n += sh[r][cl][0]; nm += sh[r][cl][1]; }
+        for (int r = 1; r < 64; ++r) { n += sh[r][cl][0]; nm += sh[r][cl][1]; }
         sh[0][cl][0] = n;
         shmean[cl] = n > 0.0 ? nm / n : 0.0;
     }
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     __syncthreads();
     double M2 = 0.0;
     if (c < C) {
-        for (int t = row; t < ntiles; t += 32) {
+        for (int t = row; t < ntiles; t += 64) {
             const float* p = partials + (size_t)t * 3 * Cstride + c;
             const double dm = (double)p[Cstride] - mean;
             M2 += (double)p[2 * Cstride] + (double)p[0] * dm * dm;
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     sh[row][cl][1] = M2;
     __syncthreads();
     if (row == 0 && c < C) {
-        for (int r = 1; r < 32; ++r) M2 += sh[r][cl][1];
+        for (int r = 1; r < 64; ++r) M2 += sh[r][cl][1];
         const double var = M2 / N;                       // biased (normalisation)
         const float rstd = (float)(1.0 / sqrt(var + (double)eps));
         const float a = gamma[c] * rstd;
@@ -112,14 +112,8 @@ __device__ __forceinline__ f32x4 grad_src4(const DipGradSrc& s, int r, int c, in
 // block-level reduction of per-thread (s1, s2) float4 pairs over prow, written as [blk][2][Cs]
 __device__ __forceinline__ void block_reduce_2(const RowLayout& L, f32x4 s1, f32x4 s2, float* partials, int Cs,
                                                float* sh /* 256*8 floats */) {
-    st4(sh + threadIdx.x * 8, s1);
-    st4(sh + threadIdx.x * 8 + 4, s2);
-    __syncthreads();
+    dip_tree_sum8(sh, L.nc4, L.rpi, L.prow, L.cg, L.active, s1, s2);
     if (L.active && L.prow == 0) {
-        for (int r = 1; r < L.rpi; ++r) {
-            s1 += ld4(sh + (r * L.nc4 + L.cg) * 8);
-            s2 += ld4(sh + (r * L.nc4 + L.cg) * 8 + 4);
-        }
         float* o = partials + (size_t)blockIdx.x * 2 * Cs + L.cg * 4;
         st4(o, s1);
         st4(o + Cs, s2);
@@ -244,7 +238,7 @@ __host__ int pixels_per_block(int npix, int C, int* nblk) {
 extern "C" int dip_bn_finalize(const float* partials, int ntiles, int Cstride, int C, const float* gamma,
                                const float* beta, float eps, float momentum, float* state, int Cs,
                                float* running_mean, float* running_var, void* stream) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(dip_cdiv(C, 8)), dim3(256), 0, (hipStream_t)stream, partials,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(dip_cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, partials,
                        ntiles, Cstride, C, gamma, beta, eps, momentum, state, Cs, running_mean, running_var);
     DIP_CHECK_LAUNCH();
     return 0;

@@ -44,7 +44,10 @@ struct Cfg {
     static constexpr int A_SLOTS = (NPIX * C4MAX + 255) / 256;
     static constexpr int B_SLOTS = (C4MAX * BN + 255) / 256;
     static constexpr int LDS_BYTES = (A_FLOATS + 2 * B_FLOATS + NPIX + 2 * TR_MAX) * 4;
-    static constexpr bool PREFETCH_A = false;   // holding the next halo in VGPRs across the MFMAs spills at BN=128 (scratch reloads drain vmcnt)
+    // Holding the next halo in VGPRs across the MFMAs spills for the 3x3 tiles at BN=128 (and a
+    // scratch reload drains vmcnt, i.e. the weight DMA); the 1x1 tile needs only 5 slots and every
+    // unit of a 1x1 conv is a new chunk, so there the prefetch pays.
+    static constexpr bool PREFETCH_A = (KS == 1);
 };
 
 __device__ __forceinline__ int map_src(int v, int n_in, int dil, int reflect) {
@@ -409,26 +412,13 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
             M2[e] = s2[e] - s1[e] * s1[e] / n;
         }
     }
-    sh[threadIdx.x * 12] = n;
-    *reinterpret_cast<f32x4*>(sh + threadIdx.x * 12 + 4) = mean;
-    *reinterpret_cast<f32x4*>(sh + threadIdx.x * 12 + 8) = M2;
-    __syncthreads();
+    dip_tree_chan4(sh, nc4, rpi, prow, cg, active, n, mean, M2);
     if (active && prow == 0) {
-        float na[4] = {n, n, n, n};
-        for (int r = 1; r < rpi; ++r) {
-            const float* q = sh + (r * nc4 + cg) * 12;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float me = mean[e], Me = M2[e];
-                dip_chan(na[e], me, Me, q[0], q[4 + e], q[8 + e]);
-                mean[e] = me; M2[e] = Me;
-            }
-        }
         float* o = d.stats + (size_t)blockIdx.x * 3 * CoutP + cg * 4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             if (cg * 4 + e < CoutP) {
-                o[e] = na[e]; o[CoutP + e] = mean[e]; o[2 * CoutP + e] = M2[e];
+                o[e] = n; o[CoutP + e] = mean[e]; o[2 * CoutP + e] = M2[e];
             }
         }
     }

@@ -15,14 +15,15 @@
 
 namespace {
 
-template <int KS, int S, int NT>
+template <int KS, int S, int NT, int CB>
 struct WCfg {
     static constexpr int TH = 4, TW = 16, NPX = TH * TW;   // 64 output pixels per step
     static constexpr int HTH = (TH - 1) * S + KS, HTW = (TW - 1) * S + KS;
     static constexpr int NPIX = HTH * HTW;
-    static constexpr int U_FLOATS = NPIX * 32;
+    static constexpr int CW = 32 * CB;                      // input channels per workgroup
+    static constexpr int U_FLOATS = NPIX * CW;
     static constexpr int DY_FLOATS = NPX * 128;
-    static constexpr int U_SLOTS = (NPIX * 8 + 255) / 256;
+    static constexpr int U_SLOTS = (NPIX * (CW / 4) + 255) / 256;
     static constexpr int LDS_BYTES = (U_FLOATS + DY_FLOATS) * 4;
     static constexpr int NGROUPS = (KS * KS + NT - 1) / NT;
 };
@@ -32,10 +33,10 @@ __device__ __forceinline__ int wmap_src(int v, int n_in, int reflect) {
     return (v < 0 || v >= n_in) ? -1 : v;
 }
 
-template <int KS, int S, int NT>
+template <int KS, int S, int NT, int CB>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d, const int ntx, const int ntiles,
                                                             const int CinP, const int CoutP) {
-    using C = WCfg<KS, S, NT>;
+    using C = WCfg<KS, S, NT, CB>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Us = smem;
     float* Ds = smem + C::U_FLOATS;
@@ -47,25 +48,25 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d
     const int half = lane >> 5;
 
     const int split = blockIdx.x;
-    const int cchunk = blockIdx.y;                 // 32 input channels
+    const int cchunk = blockIdx.y;                 // 32*CB input channels
     const int group = blockIdx.z % C::NGROUPS;     // tap group
     const int nblk = blockIdx.z / C::NGROUPS;      // 128 output channels
     const int tap0 = group * NT;
-    const int c0 = cchunk * 32;
+    const int c0 = cchunk * C::CW;
     const int o0 = nblk * 128;
     const bool wave_active = (o0 + wave * 32) < CoutP;
     const bool do_bias = (d.bias_partial != nullptr) && cchunk == 0 && group == 0;
 
-    f32x16 acc[NT];
+    f32x16 acc[NT * CB];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT * CB; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     float bsum = 0.f;
 
     const bool has_tr = d.tr.a != nullptr;
     const float slope = d.tr.slope;
-    const int c4 = tid & 7;                        // this thread's 4-channel group in the staging
+    const int c4 = tid & (C::CW / 4 - 1);          // this thread's 4-channel group in the staging
     const bool cvalid = (c0 + c4 * 4) < d.Cin;
     f32x4 ta = f32x4{1.f, 1.f, 1.f, 1.f}, tb = f32x4{0.f, 0.f, 0.f, 0.f};
     if (has_tr && cvalid) {
@@ -80,8 +81,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d
 #pragma unroll
         for (int i = 0; i < C::U_SLOTS; ++i) {
             const int f = tid + i * 256;
-            if (f < C::NPIX * 8) {
-                const int hp = f >> 3;
+            if (f < C::NPIX * (C::CW / 4)) {
+                const int hp = f / (C::CW / 4);
                 const int hr = hp / C::HTW, hc = hp - hr * C::HTW;
                 const int sr = wmap_src(ty * C::TH * S + hr - d.off, d.Hin, d.pad_mode);
                 const int sc = wmap_src(tx * C::TW * S + hc - d.off, d.Win, d.pad_mode);
@@ -115,14 +116,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d
                 const int r = px >> 4, c = px & 15;
                 const float b = Ds[px * 128 + wave * 32 + l31];
                 bsum += b;
-                const float* ub = Us + ((r * S) * C::HTW + c * S) * 32 + l31;
+                const float* ub = Us + ((r * S) * C::HTW + c * S) * C::CW + l31;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     const int tap = tap0 + t;
                     if (tap < KS * KS) {
                         const int ky = tap / KS, kx = tap - ky * KS;
-                        const float a = ub[(ky * C::HTW + kx) * 32];
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+#pragma unroll
+                        for (int cb = 0; cb < CB; ++cb) {
+                            const float a = ub[(ky * C::HTW + kx) * C::CW + cb * 32];
+                            acc[t * CB + cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t * CB + cb], 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -137,11 +141,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d
             const int tap = tap0 + t;
             if (tap < KS * KS) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (c < CinP)
-                        d.partial[(((size_t)split * (KS * KS) + tap) * CinP + c) * CoutP + o] = acc[t][r];
-                }
+                for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int c = c0 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        if (c < CinP)
+                            d.partial[(((size_t)split * (KS * KS) + tap) * CinP + c) * CoutP + o] = acc[t * CB + cb][r];
+                    }
             }
         }
         if (do_bias) {
@@ -151,11 +157,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d
     }
 }
 
-template <int KS, int S, int NT>
+template <int KS, int S, int NT, int CB>
 int launch(const DipWgradDesc& d, hipStream_t st) {
-    using C = WCfg<KS, S, NT>;
+    using C = WCfg<KS, S, NT, CB>;
     static bool attr_set = false;
-    auto kern = conv_wgrad_kernel<KS, S, NT>;
+    auto kern = conv_wgrad_kernel<KS, S, NT, CB>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
@@ -166,11 +172,100 @@ int launch(const DipWgradDesc& d, hipStream_t st) {
     const int ntiles = ntx * nty;
     const int CinP = dip_round_up(d.Cin, 32), CoutP = dip_round_up(d.Cout, 32);
     if (d.nsplit < 1 || d.nsplit > ntiles) DIP_FAIL("conv_wgrad: nsplit out of range");
-    dim3 grid(d.nsplit, CinP / 32, C::NGROUPS * dip_cdiv(CoutP, 128));
+    dim3 grid(d.nsplit, dip_cdiv(CinP, C::CW), C::NGROUPS * dip_cdiv(CoutP, 128));
     hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, st, d, ntx, ntiles, CinP, CoutP);
     DIP_CHECK_LAUNCH();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------
+// Thin 1x1 weight gradient (Cout <= 8: the 4-channel skip convs and the RGB output conv).
+// HBM-bound streaming kernel on the vector ALU: thread (prow, cg) owns 4 input channels and NO
+// output channels, walks its pixels, and the block tree-reduces over prow.  One slab per block,
+// same layout as the MFMA kernel's slabs, so dip_wgrad_reduce finishes it.
+// ------------------------------------------------------------------------------------------
+template <int NO>
+__global__ __launch_bounds__(256) void thin1x1_wgrad_kernel(const DipWgradDesc d, const int CinP, const int CoutP,
+                                                            const int ppb) {
+    constexpr int W = NO * 4 + NO;                  // per-thread accumulators: dW[o][4] + dbias[o]
+    extern __shared__ __attribute__((aligned(16))) float sh[];
+    const int nc4 = (d.Cin + 3) >> 2;
+    int rpi = 256 / nc4;
+    if (rpi < 1) rpi = 1;
+    const int prow = threadIdx.x / nc4, cg = threadIdx.x - prow * nc4;
+    const bool active = (int)threadIdx.x < rpi * nc4;
+    float acc[W];
+#pragma unroll
+    for (int i = 0; i < W; ++i) acc[i] = 0.f;
+    if (active) {
+        const int ch = cg * 4;
+        const bool has_tr = d.tr.a != nullptr;
+        f32x4 ta = f32x4{1.f, 1.f, 1.f, 1.f}, tb = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (has_tr) {
+            ta = *reinterpret_cast<const f32x4*>(d.tr.a + ch);
+            tb = *reinterpret_cast<const f32x4*>(d.tr.b + ch);
+        }
+        const int npix = d.Hout * d.Wout;
+        const int p0 = blockIdx.x * ppb, p1 = min(p0 + ppb, npix);
+        for (int p = p0 + prow; p < p1; p += rpi) {
+            f32x4 u = *reinterpret_cast<const f32x4*>(d.x + (size_t)p * d.Cx + ch);
+            if (has_tr) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) u[e] = dip_act(fmaf(ta[e], u[e], tb[e]), d.tr.slope);
+            }
+            float g[NO];
+#pragma unroll
+            for (int q = 0; q < NO; q += 4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(d.dy + (size_t)p * d.Cdy + q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[q + e] = t[e];
+            }
+#pragma unroll
+            for (int o = 0; o < NO; ++o) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[o * 4 + e] = fmaf(g[o], u[e], acc[o * 4 + e]);
+                acc[NO * 4 + o] += g[o];
+            }
+        }
+    }
+    float* mine = sh + (size_t)threadIdx.x * W;
+#pragma unroll
+    for (int i = 0; i < W; ++i) mine[i] = acc[i];
+    for (int s = dip_pow2_ceil(rpi) >> 1; s >= 1; s >>= 1) {
+        __syncthreads();
+        if (active && prow < s && prow + s < rpi) {
+            const float* q = sh + (size_t)((prow + s) * nc4 + cg) * W;
+#pragma unroll
+            for (int i = 0; i < W; ++i) { acc[i] += q[i]; mine[i] = acc[i]; }
+        }
+    }
+    if (active && prow == 0) {
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+            if (o < d.Cout) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = cg * 4 + e;
+                    if (c < CinP) d.partial[((size_t)blockIdx.x * CinP + c) * CoutP + o] = acc[o * 4 + e];
+                }
+                if (cg == 0 && d.bias_partial != nullptr) d.bias_partial[(size_t)blockIdx.x * CoutP + o] = acc[NO * 4 + o];
+            }
+        }
+    }
+}
+
+int thin_ppb(int npix, int Cin, int* nblk) {
+    const int nc4 = (Cin + 3) / 4;
+    int rpi = 256 / nc4;
+    if (rpi < 1) rpi = 1;
+    int ppb = dip_cdiv(npix, 1024);
+    if (ppb < rpi * 8) ppb = rpi * 8;
+    *nblk = dip_cdiv(npix, ppb);
+    return ppb;
+}
+
+bool is_thin(int ks, int Cin, int Cout) { return ks == 1 && Cout <= 8 && Cin <= 1024; }
+
 
 // block = 8 split-lanes x 32 consecutive outputs (o fastest -> 128-B coalesced slab reads); each
 // split-lane sums slabs sl, sl+8, ... then the 8 partials are added in a fixed order.
@@ -209,15 +304,53 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 extern "C" int dip_conv_wgrad_ntiles(int Hout, int Wout) { return dip_cdiv(Wout, 16) * dip_cdiv(Hout, 4); }
 
+// Number of partial slabs (= nsplit of DipWgradDesc) the weight-gradient kernels should be run
+// with: ~512 workgroups in flight for the MFMA kernels, one slab per block for the thin kernel,
+// and never more than 256 MB of slabs.
+extern "C" int dip_wgrad_plan(int Hout, int Wout, int Cin, int Cout, int ks, int stride, int* nsplit) {
+    (void)stride;
+    if (is_thin(ks, Cin, Cout)) {
+        int nblk;
+        thin_ppb(Hout * Wout, Cin, &nblk);
+        *nsplit = nblk;
+        return 0;
+    }
+    const int CinP = dip_round_up(Cin, 32), CoutP = dip_round_up(Cout, 32);
+    const int nt = dip_conv_wgrad_ntiles(Hout, Wout);
+    const int cw = (ks == 1) ? 128 : 32;
+    const int groups = (ks == 5) ? 5 : 1;
+    const int per_split = dip_cdiv(CinP, cw) * groups * dip_cdiv(CoutP, 128);
+    int n = 512 / per_split;
+    if (n < 1) n = 1;
+    if (n > nt) n = nt;
+    const long long slab = (long long)ks * ks * CinP * CoutP;
+    while (n > 1 && (long long)n * slab > (64ll << 20)) n /= 2;
+    *nsplit = n;
+    return 0;
+}
+
 extern "C" int dip_conv_wgrad(const DipWgradDesc* dp, void* stream) {
     const DipWgradDesc& d = *dp;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if ((d.Cx & 3) || (d.Cdy & 3)) DIP_FAIL("conv_wgrad: channel strides must be multiples of 4");
-    if (d.ks == 1 && d.stride == 1) return launch<1, 1, 1>(d, st);
-    if (d.ks == 3 && d.stride == 1) return launch<3, 1, 9>(d, st);
-    if (d.ks == 3 && d.stride == 2) return launch<3, 2, 9>(d, st);
-    if (d.ks == 5 && d.stride == 1) return launch<5, 1, 5>(d, st);
-    if (d.ks == 5 && d.stride == 2) return launch<5, 2, 5>(d, st);
+    if (is_thin(d.ks, d.Cin, d.Cout)) {
+        int nblk;
+        const int ppb = thin_ppb(d.Hout * d.Wout, d.Cin, &nblk);
+        if (nblk != d.nsplit) DIP_FAIL("conv_wgrad: thin 1x1 path needs nsplit from dip_wgrad_plan");
+        const int CinP = dip_round_up(d.Cin, 32), CoutP = dip_round_up(d.Cout, 32);
+        if (d.Cout <= 4) {
+            hipLaunchKernelGGL(thin1x1_wgrad_kernel<4>, dim3(nblk), dim3(256), 256 * 20 * 4, st, d, CinP, CoutP, ppb);
+        } else {
+            hipLaunchKernelGGL(thin1x1_wgrad_kernel<8>, dim3(nblk), dim3(256), 256 * 40 * 4, st, d, CinP, CoutP, ppb);
+        }
+        DIP_CHECK_LAUNCH();
+        return 0;
+    }
+    if (d.ks == 1 && d.stride == 1) return launch<1, 1, 1, 4>(d, st);
+    if (d.ks == 3 && d.stride == 1) return launch<3, 1, 9, 1>(d, st);
+    if (d.ks == 3 && d.stride == 2) return launch<3, 2, 9, 1>(d, st);
+    if (d.ks == 5 && d.stride == 1) return launch<5, 1, 5, 1>(d, st);
+    if (d.ks == 5 && d.stride == 2) return launch<5, 2, 5, 1>(d, st);
     DIP_FAIL("conv_wgrad: unsupported kernel size / stride");
 }
 

@@ -72,3 +72,59 @@ __device__ __forceinline__ int dip_xcd_remap(int bid, int nwg) {
     int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + idx;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Block-level tree reductions for the NHWC streaming kernels.  Thread (prow, cg) owns 4 channels;
+// the `rpi` threads that share a channel group `cg` are combined in log2(rpi) steps through LDS
+// (a single thread looping over 255 partners was measured at 80-90 us for thin, 4-channel tensors).
+// `sh` holds 12 floats per thread; the result ends up in the registers of the prow == 0 threads.
+// Deterministic: fixed pairing order.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int dip_pow2_ceil(int x) {
+    int p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+__device__ __forceinline__ void dip_tree_chan4(float* sh, int nc4, int rpi, int prow, int cg, bool active, float& n,
+                                               f32x4& mean, f32x4& M2) {
+    float* mine = sh + (size_t)threadIdx.x * 12;
+    mine[0] = n;
+    *reinterpret_cast<f32x4*>(mine + 4) = mean;
+    *reinterpret_cast<f32x4*>(mine + 8) = M2;
+    for (int s = dip_pow2_ceil(rpi) >> 1; s >= 1; s >>= 1) {
+        __syncthreads();
+        if (active && prow < s && prow + s < rpi) {
+            const float* q = sh + (size_t)((prow + s) * nc4 + cg) * 12;
+            const float nb = q[0];
+            float na = n;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float ne = n, me = mean[e], Me = M2[e];
+                dip_chan(ne, me, Me, nb, q[4 + e], q[8 + e]);
+                mean[e] = me; M2[e] = Me; na = ne;
+            }
+            n = na;
+            mine[0] = n;
+            *reinterpret_cast<f32x4*>(mine + 4) = mean;
+            *reinterpret_cast<f32x4*>(mine + 8) = M2;
+        }
+    }
+}
+
+__device__ __forceinline__ void dip_tree_sum8(float* sh, int nc4, int rpi, int prow, int cg, bool active, f32x4& s1,
+                                              f32x4& s2) {
+    float* mine = sh + (size_t)threadIdx.x * 8;
+    *reinterpret_cast<f32x4*>(mine) = s1;
+    *reinterpret_cast<f32x4*>(mine + 4) = s2;
+    for (int s = dip_pow2_ceil(rpi) >> 1; s >= 1; s >>= 1) {
+        __syncthreads();
+        if (active && prow < s && prow + s < rpi) {
+            const float* q = sh + (size_t)((prow + s) * nc4 + cg) * 8;
+            s1 += *reinterpret_cast<const f32x4*>(q);
+            s2 += *reinterpret_cast<const f32x4*>(q + 4);
+            *reinterpret_cast<f32x4*>(mine) = s1;
+            *reinterpret_cast<f32x4*>(mine + 4) = s2;
+        }
+    }
+}

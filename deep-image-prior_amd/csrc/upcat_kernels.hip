@@ -97,24 +97,10 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const DipUpcatDesc d, in
             M2[e] = s2[e] - s1[e] * s1[e] / n;
         }
     }
-    sh[threadIdx.x * 12] = n;
-    st4(sh + threadIdx.x * 12 + 4, mean);
-    st4(sh + threadIdx.x * 12 + 8, M2);
-    __syncthreads();
+    dip_tree_chan4(sh, L.nc4, L.rpi, L.prow, L.cg, L.active, n, mean, M2);
     if (L.active && L.prow == 0) {
-        float na[4] = {n, n, n, n};
-        for (int r = 1; r < L.rpi; ++r) {
-            const float* q = sh + (r * L.nc4 + L.cg) * 12;
-            const float nb = q[0];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float me = mean[e], Me = M2[e];
-                dip_chan(na[e], me, Me, nb, q[4 + e], q[8 + e]);
-                mean[e] = me; M2[e] = Me;
-            }
-        }
         float* o = d.stats + (size_t)blockIdx.x * 3 * d.Cs_cat + L.cg * 4;
-        st4(o, f32x4{na[0], na[1], na[2], na[3]});
+        st4(o, f32x4{n, n, n, n});
         st4(o + d.Cs_cat, mean);
         st4(o + 2 * d.Cs_cat, M2);
     }
@@ -192,14 +178,8 @@ __global__ __launch_bounds__(256) void upsample_bwd_stats_kernel(const float* __
             st4(dz + (size_t)p * Cdz + ch, g);
         }
     }
-    st4(sh + threadIdx.x * 8, s1);
-    st4(sh + threadIdx.x * 8 + 4, s2);
-    __syncthreads();
+    dip_tree_sum8(sh, L.nc4, L.rpi, L.prow, L.cg, L.active, s1, s2);
     if (L.active && L.prow == 0) {
-        for (int r = 1; r < L.rpi; ++r) {
-            s1 += ld4(sh + (r * L.nc4 + L.cg) * 8);
-            s2 += ld4(sh + (r * L.nc4 + L.cg) * 8 + 4);
-        }
         float* o = partials + (size_t)blockIdx.x * 2 * Cs + L.cg * 4;
         st4(o, s1);
         st4(o + Cs, s2);

@@ -105,6 +105,8 @@ class SkipEngine:
         self.slope = act_slope
         self.nscales = len(scales)
         self.fwd_id = 0
+        self._side = None
+        self.two_streams = True
         self.device = None
         self.shape_key = None
         self.lib = None
@@ -361,13 +363,8 @@ class SkipEngine:
         Ho = (x.H + 2 * r.P - r.ks) // r.stride + 1
         Wo = (x.W + 2 * r.P - r.ks) // r.stride + 1
         CinP, CoutP = round_up(r.Cin, 32), round_up(r.Cout, 32)
-        nt = self.lib.dip_conv_wgrad_ntiles(Ho, Wo)
-        groups = {1: 1, 3: 1, 5: 5}[r.ks]
-        wgs_per_split = (CinP // 32) * groups * ((CoutP + 127) // 128)
-        nsplit = max(1, min(nt, 128, 512 // max(1, wgs_per_split)))
+        nsplit = N.wgrad_plan(Ho, Wo, r.Cin, r.Cout, r.ks, r.stride)
         slab = r.ks * r.ks * CinP * CoutP
-        while nsplit > 1 and nsplit * slab > (64 << 20):       # <= 256 MB of partials
-            nsplit //= 2
         if self._sizing:
             self.wg_need = max(self.wg_need, nsplit * slab)
             self.wgb_need = max(self.wgb_need, nsplit * CoutP)
@@ -516,6 +513,36 @@ class SkipEngine:
             if rc:
                 check(rc, name)
 
+    def _run_backward_two_streams(self, ops, main):
+        """Backward launch list on two HIP streams: the weight-gradient kernels (+ their slab
+        reductions) of a layer depend only on that layer's dy and the stored activations, not on the
+        data-gradient / BatchNorm-backward chain that continues to the next layer.  They go to a
+        side stream (fork: event after the op that produced dy; join: one event at the end), so the
+        partial last round of workgroups of one kernel overlaps with the other stream's work
+        instead of idling CUs.  Slab scratch is only ever touched by the side stream."""
+        if self._side is None or self._side.device != self.device:
+            self._side = torch.cuda.Stream(self.device)
+            self._fork_events = {}
+            self._join_event = torch.cuda.Event()
+        side = self._side
+        mptr, sptr = main.cuda_stream, side.cuda_stream
+        check = N.check
+        prev_side = False
+        for k, (fn, args, name) in enumerate(ops):
+            on_side = name.startswith(("wgrad:", "wgred:"))
+            if on_side and not prev_side:
+                ev = self._fork_events.get(k)
+                if ev is None:
+                    ev = self._fork_events[k] = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+            rc = fn(*args, sptr if on_side else mptr)
+            if rc:
+                check(rc, name)
+            prev_side = on_side
+        self._join_event.record(side)
+        main.wait_event(self._join_event)
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if x.dim() != 4 or x.shape[0] != 1:
             raise NotImplementedError("dip-amd: input must be [1,C,H,W] (train-mode BatchNorm couples a batch; "
@@ -573,7 +600,10 @@ class SkipEngine:
                                "closure evaluations as utils/common_utils.optimize does")
         N.check(lib.dip_head_bwd(g.data_ptr(), self.last_out.data_ptr(), _ptr(self.dy_out), self.n_out, H * W,
                                  round_up(self.n_out, 4), 1 if self.need_sigmoid else 0, stream), "head_bwd")
-        self._run(self.bwd_ops, stream)
+        if self.two_streams:
+            self._run_backward_two_streams(self.bwd_ops, torch.cuda.current_stream(dev))
+        else:
+            self._run(self.bwd_ops, stream)
         gx = None
         if need_input_grad:
             self._run(self.bwd_input_ops, stream)

@@ -72,6 +72,7 @@ _SIGS = {
                                 C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "dip_conv_wgrad": (C.c_int, [C.POINTER(DipWgradDesc), C.c_void_p]),
     "dip_conv_wgrad_ntiles": (C.c_int, [C.c_int, C.c_int]),
+    "dip_wgrad_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "dip_wgrad_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                    C.c_void_p, C.c_void_p]),
     "dip_bn_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
@@ -137,3 +138,9 @@ def conv_plan(Hout, Wout, Cin, Cout, ks, stride):
     k, rows, wsf = C.c_int(), C.c_int(), C.c_int64()
     check(lib().dip_conv_plan(Hout, Wout, Cin, Cout, ks, stride, C.byref(k), C.byref(rows), C.byref(wsf)), "conv_plan")
     return k.value, rows.value, wsf.value
+
+
+def wgrad_plan(Hout, Wout, Cin, Cout, ks, stride):
+    n = C.c_int()
+    check(lib().dip_wgrad_plan(Hout, Wout, Cin, Cout, ks, stride, C.byref(n)), "wgrad_plan")
+    return n.value

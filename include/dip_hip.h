@@ -130,6 +130,9 @@ typedef struct DipWgradDesc {
 int dip_conv_wgrad(const DipWgradDesc* d, void* stream);
 /* number of 4x16 output tiles walked by the wgrad workgroups (upper bound for nsplit) */
 int dip_conv_wgrad_ntiles(int Hout, int Wout);
+/* nsplit (number of partial slabs) to run dip_conv_wgrad with; mandatory for 1x1 convs with
+ * Cout <= 8, which take a thin vector-ALU streaming kernel with one slab per block */
+int dip_wgrad_plan(int Hout, int Wout, int Cin, int Cout, int ks, int stride, int* nsplit);
 int dip_wgrad_reduce(const float* partial, const float* bias_partial, int nsplit, int ks, int Cin,
                      int Cout, float* dw /*OIHW*/, float* dbias /*or NULL*/, void* stream);
 

@@ -123,7 +123,9 @@ def conv_wgrad(x, dy, ks, stride, pad_mode, tr=(None, None, 1.0), nsplit=None, b
     xb, dyb = to_nhwc(x), to_nhwc(dy)
     CinP, CoutP = round_up(Cin, 32), round_up(Cout, 32)
     nt = lib.dip_conv_wgrad_ntiles(Ho, Wo)
-    nsplit = nsplit or max(1, min(nt, 7))
+    planned = N.wgrad_plan(Ho, Wo, Cin, Cout, ks, stride)
+    thin = ks == 1 and Cout <= 8
+    nsplit = planned if (thin or nsplit == "plan") else (nsplit or max(1, min(nt, 7)))
     partial = torch.full((nsplit * ks * ks * CinP * CoutP,), float("nan"), dtype=torch.float32, device=dev)
     bpart = torch.full((nsplit * CoutP,), float("nan"), dtype=torch.float32, device=dev)
     trd, keep = transform(*tr)

@@ -119,8 +119,9 @@ def test_conv_dgrad(dev, case, split):
     _check("conv_dgrad", gx, res[torch.float64], res[torch.float32])
 
 
+@pytest.mark.parametrize("nsplit", [None, "plan"], ids=["nsplit7", "planned"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
-def test_conv_wgrad(dev, case):
+def test_conv_wgrad(dev, case, nsplit):
     Cin, Cout, ks, stride, pad, Hh, Ww, use_tr = case
     x, w, b, a, bb = _mk(case, 2)
     slope = 0.2
@@ -134,7 +135,7 @@ def test_conv_wgrad(dev, case):
         (y * dy.to(dt)).sum().backward()
         res[dt] = (ww.grad, bias.grad)
     tr = (a.to(dev), bb.to(dev), slope) if use_tr else (None, None, 1.0)
-    dw, db = H.conv_wgrad(x.to(dev), dy.to(dev), ks, stride, pad, tr)
+    dw, db = H.conv_wgrad(x.to(dev), dy.to(dev), ks, stride, pad, tr, nsplit=nsplit)
     _check("conv_wgrad.dw", dw, res[torch.float64][0], res[torch.float32][0], floor=4e-6)
     _check("conv_wgrad.db", db, res[torch.float64][1], res[torch.float32][1], floor=4e-6)
 
