@@ -18,6 +18,7 @@ fallback: a missing libdip_hip.so or an unsupported option raises.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional
 
 import torch
@@ -106,7 +107,7 @@ class SkipEngine:
         self.nscales = len(scales)
         self.fwd_id = 0
         self._side = None
-        self.two_streams = True
+        self.two_streams = os.environ.get("DIP_TWO_STREAMS", "1") != "0"
         self.device = None
         self.shape_key = None
         self.lib = None

@@ -198,7 +198,9 @@ def _bn_act(x, sd, key, act=True, eps=1e-5, masks=None):
     if not act:
         return x
     if masks is not None and key in masks:
-        return torch.where(masks[key], x, 0.2 * x)
+        # multiply by a constant slope map (1 on the positive branch, 0.2 on the other)
+        slope = masks[key].contiguous().to(x.dtype) * 0.8 + 0.2
+        return x * slope
     return F.leaky_relu(x, 0.2)
 
 

@@ -158,5 +158,5 @@ def lrelu_masks(net, spec):
             state = a.bn.state.view(4, a.Cs)
             y = a.buf.view(a.H, a.W, a.Cs)
             z = torch.addcmul(state[3], state[2], y)            # fma(a, y, b), as the kernels do
-            masks[key] = (z[:, :, :a.C] > 0).permute(2, 0, 1)[None].cpu()
+            masks[key] = (z[:, :, :a.C] > 0).permute(2, 0, 1)[None].contiguous().cpu()
     return masks
