@@ -27,22 +27,28 @@ namespace {
 
 constexpr int TR_MAX = 512;   // max input channels whose BN coefficients are cached in LDS
 
-template <int KS, int S, int CCH, int BN>
+// EXTRA: a 5th 32-wide column block (N = 160 = 128 + 32) is spread over the four waves, one extra
+// 32x32 sub-tile each (wave (wm,wn) takes pixel sub-tile 2*wm+wn, whose A fragment it already
+// holds).  This is the data gradient of the 132-channel decoder convs: +25 % MFMAs instead of a
+// second launch that re-stages the whole input for 4 useful columns.  Needs Cin % CCH == 0 (no
+// merged tail chunk: the LDS budget is spent on the wider weight slab) and no statistics.
+template <int KS, int S, int CCH, int BN, bool EXTRA = false>
 struct Cfg {
     static constexpr int TH = 8, TW = 16;
     static constexpr int HTH = (TH - 1) * S + KS, HTW = (TW - 1) * S + KS;
     static constexpr int NPIX = HTH * HTW;
-    static constexpr int CMAX = CCH + 8;
+    static constexpr int CMAX = EXTRA ? CCH : CCH + 8;
+    static constexpr int BNB = EXTRA ? BN + 32 : BN;   // columns in the LDS weight slab
     static constexpr int C4MAX = CMAX / 4;
     static constexpr int LDP = CMAX + 4;  // == 4 (mod 8): 16 distinct 16-B slots per 16 pixels
     static constexpr int A_FLOATS = NPIX * LDP;
-    static constexpr int B_FLOATS = CMAX * BN;
+    static constexpr int B_FLOATS = CMAX * BNB;
     static constexpr int WN = (BN >= 64) ? 2 : 1;
     static constexpr int WM = 4 / WN;
     static constexpr int MS = 4 / WM;
     static constexpr int NS = BN / 32 / WN;
     static constexpr int A_SLOTS = (NPIX * C4MAX + 255) / 256;
-    static constexpr int B_SLOTS = (C4MAX * BN + 255) / 256;
+    static constexpr int B_SLOTS = (C4MAX * BNB + 255) / 256;
     static constexpr int LDS_BYTES = (A_FLOATS + 2 * B_FLOATS + NPIX + 2 * TR_MAX) * 4;
     // Holding the next halo in VGPRs across the MFMAs spills for the 3x3 tiles at BN=128 (and a
     // scratch reload drains vmcnt, i.e. the weight DMA); the 1x1 tile needs only 5 slots and every
@@ -79,11 +85,12 @@ __device__ __forceinline__ void lds_dma16(const float* gsrc, float* lds_dst_wave
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-template <int KS, int S, int CCH, int BN>
+template <int KS, int S, int CCH, int BN, bool EXTRA>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const DipConvDesc d, const int ntx, const int ntiles,
                                                             const int CoutP, const int n_base, const int ksplit,
                                                             float* __restrict__ ws) {
-    using C = Cfg<KS, S, CCH, BN>;
+    using C = Cfg<KS, S, CCH, BN, EXTRA>;
+    constexpr int BNB = C::BNB;
     constexpr int KK = KS * KS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
@@ -139,6 +146,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const DipConvDesc d,
         for (int j = 0; j < C::NS; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    f32x16 accx;                                   // EXTRA: sub-tile (2*wm + wn) x columns [BN, BN+32)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accx[r] = 0.f;
 
     // LDS read bases (floats)
     int apix[C::MS];
@@ -186,12 +196,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const DipConvDesc d,
     };
     auto dmaB = [&](int u, float* Bdst) {   // LDS-DMA of unit u's weight slab (linear image)
         const int ch = u / KK, tap = u - ch * KK;
-        const int cb = ch * CCH, nb4 = (chunk_cc(ch) >> 2) * BN;
+        const int cb = ch * CCH, nb4 = (chunk_cc(ch) >> 2) * BNB;
 #pragma unroll
         for (int i = 0; i < C::B_SLOTS; ++i) {
             const int f = tid + i * 256;
             if (f < nb4) {
-                const int c4 = f / BN, n = f - c4 * BN;
+                const int c4 = f / BNB, n = f - c4 * BNB;
                 const int nn = min(n0 + n, CoutP - 1);   // columns past CoutP are never stored
                 const float* src = d.wp + ((size_t)(tap * cin4 + (cb >> 2) + c4) * CoutP + nn) * 4;
                 float* dst = Bdst + (i * 256 + wave * 64) * 4;   // wave-uniform base, lane*16 B added by HW
@@ -204,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const DipConvDesc d,
 #pragma unroll
         for (int ms = 0; ms < C::MS; ++ms) a[ms] = *reinterpret_cast<const f32x4*>(Ab + apix[ms]);
 #pragma unroll
-        for (int ns = 0; ns < C::NS; ++ns) b[ns] = *reinterpret_cast<const f32x4*>(Bb + half * (BN * 4) + bcol[ns]);
+        for (int ns = 0; ns < C::NS; ++ns) b[ns] = *reinterpret_cast<const f32x4*>(Bb + half * (BNB * 4) + bcol[ns]);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -212,6 +222,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const DipConvDesc d,
 #pragma unroll
                 for (int ns = 0; ns < C::NS; ++ns)
                     acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ms][j], b[ns][j], acc[ms][ns], 0, 0, 0);
+        if constexpr (EXTRA) {
+            const f32x4 bx = *reinterpret_cast<const f32x4*>(Bb + half * (BNB * 4) + (BN + l31) * 4);
+            const f32x4 ax = wn ? a[C::MS - 1] : a[0];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) accx = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[j], bx[j], accx, 0, 0, 0);
+        }
     };
     auto mma4 = [&](const float* Ab, const float* Bb) {   // 4-channel tail: lanes 0-31 ch 0,1; 32-63 ch 2,3
         f32x2 a[C::MS], b[C::NS];
@@ -251,11 +267,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const DipConvDesc d,
         const float* Ab = As + (ky * C::HTW + kx) * C::LDP;
         if (cc == CCH) {
 #pragma unroll
-            for (int kk = 0; kk < CCH / 8; ++kk) mma8(Ab + kk * 8, Bcur + kk * 2 * (BN * 4));
+            for (int kk = 0; kk < CCH / 8; ++kk) mma8(Ab + kk * 8, Bcur + kk * 2 * (BNB * 4));
         } else {
             const int kk8 = cc >> 3;
-            for (int kk = 0; kk < kk8; ++kk) mma8(Ab + kk * 8, Bcur + kk * 2 * (BN * 4));
-            if (cc & 4) mma4(Ab + (cc - 4), Bcur + ((cc - 4) >> 2) * (BN * 4));
+            for (int kk = 0; kk < kk8; ++kk) mma8(Ab + kk * 8, Bcur + kk * 2 * (BNB * 4));
+            if (cc & 4) mma4(Ab + (cc - 4), Bcur + ((cc - 4) >> 2) * (BNB * 4));
         }
         if (newchunk) {
             __syncthreads();               // every wave is done reading the old halo
@@ -285,6 +301,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const DipConvDesc d,
                     if (oy < d.Hout && ox < d.Wout && n < d.Cy)
                         wz[((size_t)oy * d.Wout + ox) * d.Cy + n] = acc[ms][ns][r];
                 }
+            }
+        }
+        if constexpr (EXTRA) {
+            const int n = n0 + BN + l31, sub = wm * C::MS + wn;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int oy = ty * C::TH + 2 * sub + (m >> 4), ox = tx * C::TW + (m & 15);
+                if (oy < d.Hout && ox < d.Wout && n < d.Cy) wz[((size_t)oy * d.Wout + ox) * d.Cy + n] = accx[r];
             }
         }
         return;
@@ -318,6 +343,21 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const DipConvDesc d,
                     st_s1[ns] += dv;
                     st_s2[ns] += dv * dv;
                 }
+            }
+        }
+    }
+    if constexpr (EXTRA) {
+        const int n = n0 + BN + l31, sub = wm * C::MS + wn;
+        const float bias = (d.bias != nullptr && n < d.Cout) ? d.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int oy = ty * C::TH + 2 * sub + (m >> 4), ox = tx * C::TW + (m & 15);
+            if (oy < d.Hout && ox < d.Wout && n < d.Cy) {
+                float* p = d.y + ((size_t)oy * pitch + ox) * d.Cy + n;
+                float v = accx[r] + bias;
+                if (d.accumulate) v += *p;
+                *p = v;
             }
         }
     }
@@ -434,11 +474,11 @@ int finish_ppb(int npix, int Cy, int* nblk) {
     return ppb;
 }
 
-template <int KS, int S, int CCH, int BN>
+template <int KS, int S, int CCH, int BN, bool EXTRA = false>
 int launch(const DipConvDesc& d, hipStream_t st, int n_base, int grid_y, int ksplit, float* ws) {
-    using C = Cfg<KS, S, CCH, BN>;
+    using C = Cfg<KS, S, CCH, BN, EXTRA>;
     static bool attr_set = false;
-    auto kern = conv_igemm_kernel<KS, S, CCH, BN>;
+    auto kern = conv_igemm_kernel<KS, S, CCH, BN, EXTRA>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
@@ -461,6 +501,10 @@ int launch_bn(const DipConvDesc& d, hipStream_t st, int ksplit, float* ws) {
     const int CoutP = dip_round_up(d.Cout, 32);
     const int nfull = CoutP / 128, rem = CoutP - nfull * 128;
     int rc = 0;
+    if constexpr (KS == 3 && S == 1) {
+        if (nfull == 1 && rem == 32 && d.stats == nullptr && (d.Cin % CCH) == 0)
+            return launch<KS, S, CCH, 128, true>(d, st, 0, 1, ksplit, ws);      // N = 160 in one pass
+    }
     if (nfull) rc = launch<KS, S, CCH, 128>(d, st, 0, nfull, ksplit, ws);
     if (rc || !rem) return rc;
     if (rem <= 32) return launch<KS, S, CCH, 32>(d, st, nfull * 128, 1, ksplit, ws);

@@ -321,8 +321,8 @@ extern "C" int dip_wgrad_plan(int Hout, int Wout, int Cin, int Cout, int ks, int
     const int groups = (ks == 5) ? 5 : 1;
     const int per_split = dip_cdiv(CinP, cw) * groups * dip_cdiv(CoutP, 128);
     int n = 512 / per_split;
+    if (n > nt / 4) n = nt / 4;        // >= 4 pixel tiles per workgroup: amortise its slab write + the reduce
     if (n < 1) n = 1;
-    if (n > nt) n = nt;
     const long long slab = (long long)ks * ks * CinP * CoutP;
     while (n > 1 && (long long)n * slab > (64ll << 20)) n /= 2;
     *nsplit = n;

@@ -253,7 +253,7 @@ def test_end_quality_matches_cpu_oracle(dev):
 
     def run(net_, device, opt):
         zt, tgt = z.to(device), torch.from_numpy(noisy)[None].to(device)
-        state = {"i": 0, "avg": None, "loss": None}
+        state = {"i": 0, "avg": None, "loss": None, "tail": []}
 
         def closure():
             out = net_(zt + noises[state["i"]].to(device))
@@ -262,11 +262,12 @@ def test_end_quality_matches_cpu_oracle(dev):
             loss.backward()
             state["i"] += 1
             state["loss"] = loss.detach()
+            if state["i"] > iters - 20:            # single-iteration PSNR jitters by ~1 dB: average the tail
+                state["tail"].append(_psnr(clean, out.detach().cpu().numpy()[0]))
             return loss
 
         opt(closure)
-        out = net_(zt).detach().cpu().numpy()[0]
-        return _psnr(clean, out), _psnr(clean, state["avg"].cpu().numpy()[0]), state["loss"].item()
+        return float(np.mean(state["tail"])), _psnr(clean, state["avg"].cpu().numpy()[0]), state["loss"].item()
 
     spec = O.SkipSpec(8, 3, [32] * 3, [32] * 3, [4] * 3, pad="reflection", upsample_mode="bilinear")
     onet = O.OracleNet(spec, sd)
