@@ -22,6 +22,7 @@
 // serially; blockIdx.z then splits the unit range (split-K) into a workspace and
 // splitk_finish_kernel sums the slices in a fixed order, adds the bias and emits the statistics.
 #include "dip_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -563,6 +564,9 @@ extern "C" int dip_conv_plan(int Hout, int Wout, int Cin, int Cout, int ks, int 
     return 0;
 }
 
+extern "C" int dip_conv_dma_eligible(const DipConvDesc* dp);
+extern "C" int dip_conv_igemm_dma(const DipConvDesc* dp, int ksplit, void* stream);
+
 extern "C" int dip_conv_igemm(const DipConvDesc* dp, void* stream) {
     const DipConvDesc& d = *dp;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -576,7 +580,11 @@ extern "C" int dip_conv_igemm(const DipConvDesc* dp, void* stream) {
         if (ksplit > units) DIP_FAIL("conv_igemm: ksplit exceeds the number of K units");
     }
     int rc;
-    if (d.ks == 1 && d.stride == 1) rc = launch_bn<1, 1, 32>(d, st, ksplit, d.ws);
+    static const bool no_dma = getenv("DIP_CONV_NO_DMA") != nullptr;      // A/B switch for profiling
+    const int CoutP_ = dip_round_up(d.Cout, 32);
+    const bool extra_case = d.ks == 3 && d.stride == 1 && CoutP_ == 160 && d.stats == nullptr && (d.Cin % 32) == 0;
+    if (!no_dma && !extra_case && dip_conv_dma_eligible(dp)) rc = dip_conv_igemm_dma(dp, ksplit, stream);
+    else if (d.ks == 1 && d.stride == 1) rc = launch_bn<1, 1, 32>(d, st, ksplit, d.ws);
     else if (d.ks == 3 && d.stride == 1) rc = launch_bn<3, 1, 32>(d, st, ksplit, d.ws);
     else if (d.ks == 3 && d.stride == 2) rc = launch_bn<3, 2, 16>(d, st, ksplit, d.ws);
     else if (d.ks == 5 && d.stride == 1) rc = launch_bn<5, 1, 16>(d, st, ksplit, d.ws);

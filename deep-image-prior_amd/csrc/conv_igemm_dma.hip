@@ -1,0 +1,398 @@
+// Implicit-GEMM convolution, fully asynchronous staging variant (stride 1, 1x1 and 3x3).
+//
+// Same tile / wave / MFMA layout as conv_igemm.hip (8x16 pixels x BN channels per 4-wave
+// workgroup, two workgroups per CU), but NOTHING is staged through registers any more:
+//   * the input halo tile of the NEXT channel chunk is copied global->LDS by LDS-DMA
+//     (global_load_lds_dwordx4) into a second halo buffer while the current chunk's 9 taps run;
+//   * the producer's BatchNorm-apply + LeakyReLU is applied to the A fragment after its
+//     ds_read_b128 (8 VALU ops per 16 MFMAs, hidden under the matrix pipe) instead of before the
+//     LDS write, because a DMA cannot transform;
+//   * zero padding (data gradients) is a DMA from a 16-byte zero page.
+// LDS-DMA writes are lane-linear (dest = wave base + lane*16 B), so the halo image cannot be padded
+// against bank conflicts; instead the 16-byte slot index is XOR-swizzled with the pixel index on the
+// SOURCE side (slot (hp, s) holds channel group s ^ (hp & 7)) and un-swizzled on the read.
+// LDS: 2 x 23.0 KB halo + 2 x 16 KB weights + tables = 79.95 KB -> still two workgroups per CU.
+// Restrictions (checked by the dispatcher): stride 1, ks in {1,3}, Cin <= 288 when a transform is
+// fused, and no (zero padding + transform) combination (the pad value would have to be 0 AFTER the
+// transform): those cases take the register-staged kernel in conv_igemm.hip.
+#include "dip_common.h"
+
+namespace {
+
+constexpr int TRN = 288;
+
+__device__ __attribute__((aligned(16))) float g_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
+
+template <int KS, int BN>
+struct DCfg {
+    static constexpr int TH = 8, TW = 16;
+    static constexpr int HTH = TH - 1 + KS, HTW = TW - 1 + KS;
+    static constexpr int NPIX = HTH * HTW;
+    static constexpr int CCH = 32;
+    static constexpr int A_BUF = NPIX * 32;                 // floats per halo buffer (8 slots of 16 B per pixel)
+    static constexpr int B_BUF = CCH * BN;                  // floats per weight slab
+    static constexpr int WN = (BN >= 64) ? 2 : 1;
+    static constexpr int WM = 4 / WN;
+    static constexpr int MS = 4 / WM;
+    static constexpr int NS = BN / 32 / WN;
+    static constexpr int A_SLOTS = (NPIX * 8 + 255) / 256;
+    static constexpr int B_SLOTS = (8 * BN + 255) / 256;
+    static constexpr int LDS_BYTES = (2 * A_BUF + 2 * B_BUF + NPIX + 2 * TRN) * 4;
+};
+
+__device__ __forceinline__ int map_src(int v, int n_in, int dil, int reflect) {
+    const int nv = (n_in - 1) * dil + 1;
+    if (reflect) v = dip_reflect(v, nv);
+    if (v < 0 || v >= nv) return -1;
+    if (dil == 2) {
+        if (v & 1) return -1;
+        v >>= 1;
+    }
+    return v;
+}
+
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ void lds_dma16(const float* gsrc, float* lds_dst_wave_uniform) {
+    const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t)lds_dst_wave_uniform);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(base)
+                 : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+template <int KS, int BN, bool TR>
+__global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDesc d, const int ntx, const int ntiles,
+                                                                const int CoutP, const int n_base, const int ksplit,
+                                                                float* __restrict__ ws) {
+    using C = DCfg<KS, BN>;
+    constexpr int KK = KS * KS;
+    constexpr int CCH = C::CCH;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                                   // 2 halo buffers
+    float* Bs = smem + 2 * C::A_BUF;                    // 2 weight slabs
+    int* srcoff = reinterpret_cast<int*>(Bs + 2 * C::B_BUF);
+    float* tra = reinterpret_cast<float*>(srcoff + C::NPIX);
+    float* trb = tra + TRN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int half = lane >> 5;
+    const int wn = wave % C::WN;
+    const int wm = wave / C::WN;
+
+    const int tile = dip_xcd_remap(blockIdx.x, ntiles);
+    const int ty = tile / ntx, tx = tile - ty * ntx;
+    const int n0 = n_base + blockIdx.y * BN;
+
+    for (int hp = tid; hp < C::NPIX; hp += 256) {
+        const int hr = hp / C::HTW, hc = hp - hr * C::HTW;
+        const int sr = map_src(ty * C::TH + hr - d.off, d.Hin, d.dil, d.pad_mode);
+        const int sc = map_src(tx * C::TW + hc - d.off, d.Win, d.dil, d.pad_mode);
+        srcoff[hp] = (sr < 0 || sc < 0) ? -1 : (sr * d.Win + sc);
+    }
+    constexpr bool has_tr = TR;          // compile-time: keeps the 4 k-steps of a unit in one basic block
+    const float slope = d.tr.slope;
+    if constexpr (TR) {
+        for (int c = tid; c < d.Cin; c += 256) {
+            tra[c] = d.tr.a[c];
+            trb[c] = d.tr.b[c];
+        }
+    }
+
+    const int nchunks = (d.Cin + CCH - 1) / CCH;
+    const int last_cc = d.Cin - (nchunks - 1) * CCH;
+    const int cin4 = d.Cin >> 2;
+    const int nunits = nchunks * KK;
+    const int z = blockIdx.z;
+    const int u0 = (int)(((long long)z * nunits) / ksplit);
+    const int u1 = (int)(((long long)(z + 1) * nunits) / ksplit);
+    const int ch0 = u0 / KK;
+
+    f32x16 acc[C::MS][C::NS];
+#pragma unroll
+    for (int i = 0; i < C::MS; ++i)
+#pragma unroll
+        for (int j = 0; j < C::NS; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int hp0[C::MS];
+#pragma unroll
+    for (int ms = 0; ms < C::MS; ++ms) {
+        const int sub = wm * C::MS + ms;
+        const int r = 2 * sub + (l31 >> 4), c = l31 & 15;
+        hp0[ms] = r * C::HTW + c;
+    }
+    int bcol[C::NS];
+#pragma unroll
+    for (int ns = 0; ns < C::NS; ++ns) bcol[ns] = ((wn * C::NS + ns) * 32 + l31) * 4;
+
+    auto chunk_cc = [&](int ch) { return (ch == nchunks - 1) ? last_cc : CCH; };
+    auto dmaA = [&](int ch, float* Adst) {  // halo tile of chunk ch: slot (hp, s) <- channel group s ^ (hp & 7)
+        const int cb = ch * CCH, c4n = chunk_cc(ch) >> 2;
+#pragma unroll
+        for (int i = 0; i < C::A_SLOTS; ++i) {
+            const int f = tid + i * 256;
+            const int hp = f >> 3;
+            const int c4 = (f & 7) ^ (hp & 7);
+            if (hp < C::NPIX && c4 < c4n) {
+                const int so = srcoff[hp];
+                const float* src = so >= 0 ? d.x + (size_t)so * d.Cx + cb + c4 * 4 : g_zero_page;
+                lds_dma16(src, Adst + (i * 256 + wave * 64) * 4);
+            }
+        }
+    };
+    auto dmaB = [&](int u, float* Bdst) {
+        const int ch = u / KK, tap = u - ch * KK;
+        const int cb = ch * CCH, nb4 = (chunk_cc(ch) >> 2) * BN;
+#pragma unroll
+        for (int i = 0; i < C::B_SLOTS; ++i) {
+            const int f = tid + i * 256;
+            if (f < nb4) {
+                const int c4 = f / BN, n = f - c4 * BN;
+                const int nn = min(n0 + n, CoutP - 1);
+                const float* src = d.wp + ((size_t)(tap * cin4 + (cb >> 2) + c4) * CoutP + nn) * 4;
+                lds_dma16(src, Bdst + (i * 256 + wave * 64) * 4);
+            }
+        }
+    };
+
+    // ---- prologue ----
+    __syncthreads();
+    dmaA(ch0, As);
+    dmaB(u0, Bs);
+    dma_wait();
+    __syncthreads();
+
+    for (int u = u0; u < u1; ++u) {
+        const int ch = u / KK, tap = u - ch * KK;
+        const int ky = tap / KS, kx = tap - ky * KS;
+        const int cc = chunk_cc(ch), cb = ch * CCH;
+        const float* Acur = As + ((ch - ch0) & 1) * C::A_BUF;
+        float* Anxt = As + ((ch - ch0 + 1) & 1) * C::A_BUF;
+        const float* Bcur = Bs + ((u - u0) & 1) * C::B_BUF;
+        float* Bnxt = Bs + ((u - u0 + 1) & 1) * C::B_BUF;
+        const bool more = (u + 1) < u1;
+        if (more) dmaB(u + 1, Bnxt);
+        // first unit this workgroup runs in chunk ch: start fetching the next chunk's halo
+        if ((u == u0 || tap == 0) && (ch + 1) * KK < u1) dmaA(ch + 1, Anxt);
+
+        int abase[C::MS], sw[C::MS];
+#pragma unroll
+        for (int ms = 0; ms < C::MS; ++ms) {
+            const int hp = hp0[ms] + ky * C::HTW + kx;
+            abase[ms] = hp * 32;
+            sw[ms] = hp & 7;
+        }
+        auto mma8 = [&](int kk) {
+            const int c4 = 2 * kk + half;
+            f32x4 a[C::MS], b[C::NS];
+#pragma unroll
+            for (int ms = 0; ms < C::MS; ++ms)
+                a[ms] = *reinterpret_cast<const f32x4*>(Acur + abase[ms] + ((c4 ^ sw[ms]) << 2));
+#pragma unroll
+            for (int ns = 0; ns < C::NS; ++ns)
+                b[ns] = *reinterpret_cast<const f32x4*>(Bcur + c4 * (BN * 4) + bcol[ns]);
+            if constexpr (has_tr) {
+                const f32x4 ta = *reinterpret_cast<const f32x4*>(tra + cb + c4 * 4);
+                const f32x4 tb = *reinterpret_cast<const f32x4*>(trb + cb + c4 * 4);
+#pragma unroll
+                for (int ms = 0; ms < C::MS; ++ms)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a[ms][e] = dip_act(fmaf(ta[e], a[ms][e], tb[e]), slope);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int ms = 0; ms < C::MS; ++ms)
+#pragma unroll
+                    for (int ns = 0; ns < C::NS; ++ns)
+                        acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ms][j], b[ns][j], acc[ms][ns], 0, 0, 0);
+        };
+        auto mma4 = [&]() {       // tail group c4t: lanes 0-31 take its channels 0,1; lanes 32-63 channels 2,3
+            const int c4t = (cc - 4) >> 2;
+            f32x2 a[C::MS], b[C::NS];
+#pragma unroll
+            for (int ms = 0; ms < C::MS; ++ms)
+                a[ms] = *reinterpret_cast<const f32x2*>(Acur + abase[ms] + ((c4t ^ sw[ms]) << 2) + 2 * half);
+#pragma unroll
+            for (int ns = 0; ns < C::NS; ++ns)
+                b[ns] = *reinterpret_cast<const f32x2*>(Bcur + c4t * (BN * 4) + bcol[ns] + 2 * half);
+            if constexpr (has_tr) {
+                const f32x2 ta = *reinterpret_cast<const f32x2*>(tra + cb + c4t * 4 + 2 * half);
+                const f32x2 tb = *reinterpret_cast<const f32x2*>(trb + cb + c4t * 4 + 2 * half);
+#pragma unroll
+                for (int ms = 0; ms < C::MS; ++ms)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) a[ms][e] = dip_act(fmaf(ta[e], a[ms][e], tb[e]), slope);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int ms = 0; ms < C::MS; ++ms)
+#pragma unroll
+                    for (int ns = 0; ns < C::NS; ++ns)
+                        acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ms][j], b[ns][j], acc[ms][ns], 0, 0, 0);
+        };
+        if (cc == CCH) {
+#pragma unroll
+            for (int kk = 0; kk < CCH / 8; ++kk) mma8(kk);
+        } else {
+            const int kk8 = cc >> 3;
+            for (int kk = 0; kk < kk8; ++kk) mma8(kk);
+            if (cc & 4) mma4();
+        }
+        if (more) {
+            dma_wait();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue (identical to conv_igemm.hip) ----
+    if (ksplit > 1) {
+        float* wz = ws + (size_t)z * d.Hout * d.Wout * d.Cy;
+#pragma unroll
+        for (int ns = 0; ns < C::NS; ++ns) {
+            const int n = n0 + (wn * C::NS + ns) * 32 + l31;
+#pragma unroll
+            for (int ms = 0; ms < C::MS; ++ms) {
+                const int sub = wm * C::MS + ms;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int oy = ty * C::TH + 2 * sub + (m >> 4);
+                    const int ox = tx * C::TW + (m & 15);
+                    if (oy < d.Hout && ox < d.Wout && n < d.Cy)
+                        wz[((size_t)oy * d.Wout + ox) * d.Cy + n] = acc[ms][ns][r];
+                }
+            }
+        }
+        return;
+    }
+    const int pitch = d.y_pitch > 0 ? d.y_pitch : d.Wout;
+    float st_n[C::NS], st_k[C::NS], st_s1[C::NS], st_s2[C::NS];
+#pragma unroll
+    for (int ns = 0; ns < C::NS; ++ns) {
+        const int n = n0 + (wn * C::NS + ns) * 32 + l31;
+        const float bias = (d.bias != nullptr && n < d.Cout) ? d.bias[n] : 0.f;
+        st_n[ns] = 0.f; st_k[ns] = 0.f; st_s1[ns] = 0.f; st_s2[ns] = 0.f;
+#pragma unroll
+        for (int ms = 0; ms < C::MS; ++ms) {
+            const int sub = wm * C::MS + ms;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int oy = ty * C::TH + 2 * sub + (m >> 4);
+                const int ox = tx * C::TW + (m & 15);
+                const bool valid = (oy < d.Hout) && (ox < d.Wout);
+                float v = acc[ms][ns][r] + bias;
+                if (valid && n < d.Cy) {
+                    float* p = d.y + ((size_t)oy * pitch + ox) * d.Cy + n;
+                    if (d.accumulate) v += *p;
+                    *p = v;
+                }
+                if (valid) {
+                    if (st_n[ns] == 0.f) st_k[ns] = v;
+                    const float dv = v - st_k[ns];
+                    st_n[ns] += 1.f;
+                    st_s1[ns] += dv;
+                    st_s2[ns] += dv * dv;
+                }
+            }
+        }
+    }
+    if (d.stats != nullptr) {
+        __syncthreads();
+        float* red = smem;
+#pragma unroll
+        for (int ns = 0; ns < C::NS; ++ns) {
+            float cn = st_n[ns];
+            float mean = cn > 0.f ? st_k[ns] + st_s1[ns] / cn : 0.f;
+            float M2 = cn > 0.f ? st_s2[ns] - st_s1[ns] * st_s1[ns] / cn : 0.f;
+            const float on = __shfl_xor(cn, 32), om = __shfl_xor(mean, 32), oM = __shfl_xor(M2, 32);
+            dip_chan(cn, mean, M2, on, om, oM);
+            if (half == 0) {
+                float* q = red + ((wm * (C::WN * C::NS * 32)) + (wn * C::NS + ns) * 32 + l31) * 3;
+                q[0] = cn; q[1] = mean; q[2] = M2;
+            }
+        }
+        __syncthreads();
+        if (tid < BN) {
+            float cn = 0.f, mean = 0.f, M2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < C::WM; ++w) {
+                const float* q = red + (w * (C::WN * C::NS * 32) + tid) * 3;
+                dip_chan(cn, mean, M2, q[0], q[1], q[2]);
+            }
+            const int n = n0 + tid;
+            if (n < CoutP) {
+                float* o = d.stats + (size_t)tile * 3 * CoutP + n;
+                o[0] = cn; o[CoutP] = mean; o[2 * CoutP] = M2;
+            }
+        }
+    }
+}
+
+template <int KS, int BN, bool TR>
+int launch_tr(const DipConvDesc& d, hipStream_t st, int n_base, int grid_y, int ksplit, float* ws) {
+    using C = DCfg<KS, BN>;
+    static bool attr_set = false;
+    auto kern = conv_igemm_dma_kernel<KS, BN, TR>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e != hipSuccess) { dip_set_error(hipGetErrorString(e)); return (int)e; }
+        attr_set = true;
+    }
+    const int ntx = dip_cdiv(d.Wout, C::TW), nty = dip_cdiv(d.Hout, C::TH);
+    const int ntiles = ntx * nty;
+    const int CoutP = dip_round_up(d.Cout, 32);
+    dim3 grid(ntiles, grid_y, ksplit);
+    hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, st, d, ntx, ntiles, CoutP, n_base, ksplit, ws);
+    DIP_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int KS, int BN>
+int launch(const DipConvDesc& d, hipStream_t st, int n_base, int grid_y, int ksplit, float* ws) {
+    return d.tr.a != nullptr ? launch_tr<KS, BN, true>(d, st, n_base, grid_y, ksplit, ws)
+                             : launch_tr<KS, BN, false>(d, st, n_base, grid_y, ksplit, ws);
+}
+
+template <int KS>
+int launch_bn(const DipConvDesc& d, hipStream_t st, int ksplit, float* ws) {
+    const int CoutP = dip_round_up(d.Cout, 32);
+    const int nfull = CoutP / 128, rem = CoutP - nfull * 128;
+    int rc = 0;
+    if (nfull) rc = launch<KS, 128>(d, st, 0, nfull, ksplit, ws);
+    if (rc || !rem) return rc;
+    if (rem <= 32) return launch<KS, 32>(d, st, nfull * 128, 1, ksplit, ws);
+    if (rem <= 64) return launch<KS, 64>(d, st, nfull * 128, 1, ksplit, ws);
+    return launch<KS, 128>(d, st, nfull * 128, 1, ksplit, ws);
+}
+
+}  // namespace
+
+// true when this variant can run the descriptor (see the restrictions in the file header)
+extern "C" int dip_conv_dma_eligible(const DipConvDesc* dp) {
+    const DipConvDesc& d = *dp;
+    if (d.stride != 1 || (d.ks != 1 && d.ks != 3)) return 0;
+    const bool has_tr = d.tr.a != nullptr;
+    if (has_tr && d.Cin > TRN) return 0;
+    // zero padding with a fused transform: the pad value must be 0 AFTER the transform
+    const bool pads = d.ks > 1 || d.off != 0 || d.dil != 1;
+    if (has_tr && pads && d.pad_mode != DIP_PAD_REFLECT) return 0;
+    return 1;
+}
+
+extern "C" int dip_conv_igemm_dma(const DipConvDesc* dp, int ksplit, void* stream) {
+    const DipConvDesc& d = *dp;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (d.ks == 1) return launch_bn<1>(d, st, ksplit, d.ws);
+    return launch_bn<3>(d, st, ksplit, d.ws);
+}
