@@ -4,17 +4,17 @@
 // workgroup, two workgroups per CU), but NOTHING is staged through registers any more:
 //   * the input halo tile of the NEXT channel chunk is copied global->LDS by LDS-DMA
 //     (global_load_lds_dwordx4) into a second halo buffer while the current chunk's 9 taps run;
-//   * the producer's BatchNorm-apply + LeakyReLU is applied to the A fragment after its
-//     ds_read_b128 (8 VALU ops per 16 MFMAs, hidden under the matrix pipe) instead of before the
-//     LDS write, because a DMA cannot transform;
+//   * the producer's BatchNorm-apply + LeakyReLU cannot ride on a DMA, so it is applied to the
+//     landed halo in LDS (see below);
 //   * zero padding (data gradients) is a DMA from a 16-byte zero page.
 // LDS-DMA writes are lane-linear (dest = wave base + lane*16 B), so the halo image cannot be padded
 // against bank conflicts; instead the 16-byte slot index is XOR-swizzled with the pixel index on the
 // SOURCE side (slot (hp, s) holds channel group s ^ (hp & 7)) and un-swizzled on the read.
 // LDS: 2 x 23.0 KB halo + 2 x 16 KB weights + tables = 79.95 KB -> still two workgroups per CU.
+// 3x3: the producer transform is applied IN PLACE in LDS, once per chunk, by the thread that DMA'd
+// the slot (after its own vmcnt(0)); 1x1: at the fragment read.
 // Restrictions (checked by the dispatcher): stride 1, ks in {1,3}, Cin <= 288 when a transform is
-// fused, and no (zero padding + transform) combination (the pad value would have to be 0 AFTER the
-// transform): those cases take the register-staged kernel in conv_igemm.hip.
+// fused; everything else takes the register-staged kernel in conv_igemm.hip.
 #include "dip_common.h"
 
 namespace {
@@ -95,7 +95,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
         const int sc = map_src(tx * C::TW + hc - d.off, d.Win, d.dil, d.pad_mode);
         srcoff[hp] = (sr < 0 || sc < 0) ? -1 : (sr * d.Win + sc);
     }
-    constexpr bool has_tr = TR;          // compile-time: keeps the 4 k-steps of a unit in one basic block
+    // 3x3: the thread that DMA'd a slot transforms it IN PLACE once its own DMA has landed (after its
+    // own vmcnt(0), before the unit's barrier) -- 1/18 of the VALU work of transforming at every
+    // fragment read, no extra barrier, and zero-padded slots simply stay zero.
+    // 1x1: every unit is a new chunk, so the transform stays at the fragment read (2x redundancy only).
+    constexpr bool has_tr = TR && (KS == 1);      // transform at fragment read
+    constexpr bool tr_inplace = TR && (KS != 1);
     const float slope = d.tr.slope;
     if constexpr (TR) {
         for (int c = tid; c < d.Cin; c += 256) {
@@ -147,6 +152,24 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
             }
         }
     };
+    auto trA = [&](int ch, float* Abuf) {   // in-place BatchNorm+LeakyReLU of this thread's own slots
+        const int cb = ch * CCH, c4n = chunk_cc(ch) >> 2;
+#pragma unroll
+        for (int i = 0; i < C::A_SLOTS; ++i) {
+            const int f = tid + i * 256;
+            const int hp = f >> 3;
+            const int c4 = (f & 7) ^ (hp & 7);
+            if (hp < C::NPIX && c4 < c4n && srcoff[hp] >= 0) {
+                float* p = Abuf + f * 4;
+                f32x4 v = *reinterpret_cast<const f32x4*>(p);
+                const f32x4 ta = *reinterpret_cast<const f32x4*>(tra + cb + c4 * 4);
+                const f32x4 tb = *reinterpret_cast<const f32x4*>(trb + cb + c4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = dip_act(fmaf(ta[e], v[e], tb[e]), slope);
+                *reinterpret_cast<f32x4*>(p) = v;
+            }
+        }
+    };
     auto dmaB = [&](int u, float* Bdst) {
         const int ch = u / KK, tap = u - ch * KK;
         const int cb = ch * CCH, nb4 = (chunk_cc(ch) >> 2) * BN;
@@ -167,6 +190,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
     dmaA(ch0, As);
     dmaB(u0, Bs);
     dma_wait();
+    if constexpr (tr_inplace) trA(ch0, As);
     __syncthreads();
 
     for (int u = u0; u < u1; ++u) {
@@ -180,7 +204,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
         const bool more = (u + 1) < u1;
         if (more) dmaB(u + 1, Bnxt);
         // first unit this workgroup runs in chunk ch: start fetching the next chunk's halo
-        if ((u == u0 || tap == 0) && (ch + 1) * KK < u1) dmaA(ch + 1, Anxt);
+        const bool fetch_next = (u == u0 || tap == 0) && (ch + 1) * KK < u1;
+        if (fetch_next) dmaA(ch + 1, Anxt);
 
         int abase[C::MS], sw[C::MS];
 #pragma unroll
@@ -249,6 +274,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
         }
         if (more) {
             dma_wait();
+            if constexpr (tr_inplace) {
+                if (fetch_next) trA(ch + 1, Anxt);
+            }
             __syncthreads();
         }
     }
@@ -384,9 +412,9 @@ extern "C" int dip_conv_dma_eligible(const DipConvDesc* dp) {
     if (d.stride != 1 || (d.ks != 1 && d.ks != 3)) return 0;
     const bool has_tr = d.tr.a != nullptr;
     if (has_tr && d.Cin > TRN) return 0;
-    // zero padding with a fused transform: the pad value must be 0 AFTER the transform
-    const bool pads = d.ks > 1 || d.off != 0 || d.dil != 1;
-    if (has_tr && pads && d.pad_mode != DIP_PAD_REFLECT) return 0;
+    // 1x1 transforms at the fragment read: a zero-padded or dilated gather would turn pad zeros into
+    // act(b) there (never happens for the 1x1 convs of this net: off == 0, dil == 1)
+    if (has_tr && d.ks == 1 && (d.off != 0 || d.dil != 1)) return 0;
     return 1;
 }
 
