@@ -61,6 +61,15 @@ __device__ __forceinline__ void lds_dma16(const float* gsrc, float* lds_dst_wave
                  : "v"(gsrc), "s"(base)
                  : "memory");
 }
+// saddr form: 64-bit wave-uniform base in SGPRs + 32-bit per-lane byte offset; LDS base in m0.
+// Two SALU moves + the load: the per-unit weight DMA costs ~15 instructions per wave.
+__device__ __forceinline__ void lds_dma16_s(const void* sbase, unsigned voff, unsigned m0val) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(m0val)
+                 : "memory");
+}
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 template <int KS, int BN, bool TR>
@@ -138,17 +147,40 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
     for (int ns = 0; ns < C::NS; ++ns) bcol[ns] = ((wn * C::NS + ns) * 32 + l31) * 4;
 
     auto chunk_cc = [&](int ch) { return (ch == nchunks - 1) ? last_cc : CCH; };
-    auto dmaA = [&](int ch, float* Adst) {  // halo tile of chunk ch: slot (hp, s) <- channel group s ^ (hp & 7)
-        const int cb = ch * CCH, c4n = chunk_cc(ch) >> 2;
+    const unsigned lds_base = (unsigned)(size_t)(lptr_t)smem;            // LDS byte address of smem
+    const unsigned lds_piece = (unsigned)wave * 1024u;                    // this wave's 1 KiB inside a 4 KiB piece row
+
+    __syncthreads();                       // srcoff / tr tables visible
+    // Per-thread DMA geometry, computed once: byte offsets relative to a per-unit / per-chunk
+    // wave-uniform base, so the issue inside the K loop is two SALU moves + one VMEM instruction.
+    constexpr unsigned NONE = 0xffffffffu;
+    unsigned aoff[C::A_SLOTS];             // halo piece i: (src_pixel*Cx + c4*4)*4 bytes, NONE = zero pad
+    int ac4[C::A_SLOTS];                   // its channel group (un-swizzled), -1 = no such slot
+#pragma unroll
+    for (int i = 0; i < C::A_SLOTS; ++i) {
+        const int f = tid + i * 256;
+        const int hp = f >> 3;
+        const int c4 = (f & 7) ^ (hp & 7);
+        ac4[i] = hp < C::NPIX ? c4 : -1;
+        const int so = hp < C::NPIX ? srcoff[hp] : -1;
+        aoff[i] = so >= 0 ? (unsigned)(so * d.Cx + c4 * 4) * 4u : NONE;
+    }
+    unsigned boff[C::B_SLOTS];             // weight piece i: ((c4*CoutP + column)*4)*4 bytes
+#pragma unroll
+    for (int i = 0; i < C::B_SLOTS; ++i) {
+        const int f = tid + i * 256;
+        const int c4 = f / BN, n = f - c4 * BN;
+        boff[i] = (unsigned)((c4 * CoutP + min(n0 + n, CoutP - 1)) * 4) * 4u;
+    }
+    auto dmaA = [&](int ch, int abuf) {    // halo tile of chunk ch: slot (hp, s) <- channel group s ^ (hp & 7)
+        const int c4n = chunk_cc(ch) >> 2;
+        const float* sb = d.x + ch * CCH;
+        const unsigned m0b = lds_base + (unsigned)(abuf * C::A_BUF) * 4u + lds_piece;
 #pragma unroll
         for (int i = 0; i < C::A_SLOTS; ++i) {
-            const int f = tid + i * 256;
-            const int hp = f >> 3;
-            const int c4 = (f & 7) ^ (hp & 7);
-            if (hp < C::NPIX && c4 < c4n) {
-                const int so = srcoff[hp];
-                const float* src = so >= 0 ? d.x + (size_t)so * d.Cx + cb + c4 * 4 : g_zero_page;
-                lds_dma16(src, Adst + (i * 256 + wave * 64) * 4);
+            if (ac4[i] >= 0 && ac4[i] < c4n) {
+                if (aoff[i] != NONE) lds_dma16_s(sb, aoff[i], m0b + i * 4096u);
+                else lds_dma16_s(g_zero_page, 0u, m0b + i * 4096u);
             }
         }
     };
@@ -156,42 +188,35 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
         const int cb = ch * CCH, c4n = chunk_cc(ch) >> 2;
 #pragma unroll
         for (int i = 0; i < C::A_SLOTS; ++i) {
-            const int f = tid + i * 256;
-            const int hp = f >> 3;
-            const int c4 = (f & 7) ^ (hp & 7);
-            if (hp < C::NPIX && c4 < c4n && srcoff[hp] >= 0) {
-                float* p = Abuf + f * 4;
+            if (ac4[i] >= 0 && ac4[i] < c4n && aoff[i] != NONE) {
+                float* p = Abuf + (tid + i * 256) * 4;
                 f32x4 v = *reinterpret_cast<const f32x4*>(p);
-                const f32x4 ta = *reinterpret_cast<const f32x4*>(tra + cb + c4 * 4);
-                const f32x4 tb = *reinterpret_cast<const f32x4*>(trb + cb + c4 * 4);
+                const f32x4 ta = *reinterpret_cast<const f32x4*>(tra + cb + ac4[i] * 4);
+                const f32x4 tb = *reinterpret_cast<const f32x4*>(trb + cb + ac4[i] * 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = dip_act(fmaf(ta[e], v[e], tb[e]), slope);
                 *reinterpret_cast<f32x4*>(p) = v;
             }
         }
     };
-    auto dmaB = [&](int u, float* Bdst) {
+    auto dmaB = [&](int u, int bbuf) {
         const int ch = u / KK, tap = u - ch * KK;
-        const int cb = ch * CCH, nb4 = (chunk_cc(ch) >> 2) * BN;
+        const int nb4 = (chunk_cc(ch) >> 2) * BN;
+        const float* sb = d.wp + ((size_t)(tap * cin4 + ((ch * CCH) >> 2)) * CoutP) * 4;
+        const unsigned m0b = lds_base + (unsigned)(2 * C::A_BUF + bbuf * C::B_BUF) * 4u + lds_piece;
 #pragma unroll
         for (int i = 0; i < C::B_SLOTS; ++i) {
-            const int f = tid + i * 256;
-            if (f < nb4) {
-                const int c4 = f / BN, n = f - c4 * BN;
-                const int nn = min(n0 + n, CoutP - 1);
-                const float* src = d.wp + ((size_t)(tap * cin4 + (cb >> 2) + c4) * CoutP + nn) * 4;
-                lds_dma16(src, Bdst + (i * 256 + wave * 64) * 4);
-            }
+            if (tid + i * 256 < nb4) lds_dma16_s(sb, boff[i], m0b + i * 4096u);
         }
     };
 
     // ---- prologue ----
-    __syncthreads();
-    dmaA(ch0, As);
-    dmaB(u0, Bs);
+    dmaA(ch0, 0);
+    dmaB(u0, 0);
     dma_wait();
     if constexpr (tr_inplace) trA(ch0, As);
     __syncthreads();
+    bool tr_pending = false;               // next chunk's halo has landed (own pieces) but is not transformed yet
 
     for (int u = u0; u < u1; ++u) {
         const int ch = u / KK, tap = u - ch * KK;
@@ -200,13 +225,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
         const float* Acur = As + ((ch - ch0) & 1) * C::A_BUF;
         float* Anxt = As + ((ch - ch0 + 1) & 1) * C::A_BUF;
         const float* Bcur = Bs + ((u - u0) & 1) * C::B_BUF;
-        float* Bnxt = Bs + ((u - u0 + 1) & 1) * C::B_BUF;
         const bool more = (u + 1) < u1;
-        if (more) dmaB(u + 1, Bnxt);
-        // first unit this workgroup runs in chunk ch: start fetching the next chunk's halo
         const bool fetch_next = (u == u0 || tap == 0) && (ch + 1) * KK < u1;
-        if (fetch_next) dmaA(ch + 1, Anxt);
-
+        const int abuf_n = (ch - ch0 + 1) & 1, bbuf_n = (u - u0 + 1) & 1;
         int abase[C::MS], sw[C::MS];
 #pragma unroll
         for (int ms = 0; ms < C::MS; ++ms) {
@@ -264,10 +285,22 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
                     for (int ns = 0; ns < C::NS; ++ns)
                         acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ms][j], b[ns][j], acc[ms][ns], 0, 0, 0);
         };
+        // The DMA issue (asm volatile = scheduling barrier) sits BEHIND the first 16 MFMAs of the unit,
+        // whose 1024 cycles cover it; issued first it was a ~0.4 us serial prefix per unit.
+        auto issue = [&]() {
+            if (more) dmaB(u + 1, bbuf_n);
+            if (fetch_next) dmaA(ch + 1, abuf_n);
+            if constexpr (tr_inplace) {
+                if (tr_pending) { trA(ch + 1, Anxt); tr_pending = false; }
+            }
+        };
         if (cc == CCH) {
+            mma8(0);
+            issue();
 #pragma unroll
-            for (int kk = 0; kk < CCH / 8; ++kk) mma8(kk);
+            for (int kk = 1; kk < CCH / 8; ++kk) mma8(kk);
         } else {
+            issue();
             const int kk8 = cc >> 3;
             for (int kk = 0; kk < kk8; ++kk) mma8(kk);
             if (cc & 4) mma4();
@@ -275,7 +308,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
         if (more) {
             dma_wait();
             if constexpr (tr_inplace) {
-                if (fetch_next) trA(ch + 1, Anxt);
+                if (fetch_next) {
+                    // own pieces have landed; transform now if the next unit already needs the halo,
+                    // otherwise in the shadow of the next unit's first MFMA block
+                    if (tap == KK - 1) trA(ch + 1, Anxt);
+                    else tr_pending = true;
+                }
             }
             __syncthreads();
         }
