@@ -22,6 +22,7 @@
 // serially; blockIdx.z then splits the unit range (split-K) into a workspace and
 // splitk_finish_kernel sums the slices in a fixed order, adds the bias and emits the statistics.
 #include "dip_common.h"
+#include "conv_epilogue.h"
 #include <stdlib.h>
 
 namespace {
@@ -315,83 +316,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const DipConvDesc d,
         }
         return;
     }
-    const int pitch = d.y_pitch > 0 ? d.y_pitch : d.Wout;
-    float st_n[C::NS], st_k[C::NS], st_s1[C::NS], st_s2[C::NS];
-#pragma unroll
-    for (int ns = 0; ns < C::NS; ++ns) {
-        const int n = n0 + (wn * C::NS + ns) * 32 + l31;
-        const float bias = (d.bias != nullptr && n < d.Cout) ? d.bias[n] : 0.f;
-        st_n[ns] = 0.f; st_k[ns] = 0.f; st_s1[ns] = 0.f; st_s2[ns] = 0.f;
-#pragma unroll
-        for (int ms = 0; ms < C::MS; ++ms) {
-            const int sub = wm * C::MS + ms;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int oy = ty * C::TH + 2 * sub + (m >> 4);
-                const int ox = tx * C::TW + (m & 15);
-                const bool valid = (oy < d.Hout) && (ox < d.Wout);
-                float v = acc[ms][ns][r] + bias;
-                if (valid && n < d.Cy) {
-                    float* p = d.y + ((size_t)oy * pitch + ox) * d.Cy + n;
-                    if (d.accumulate) v += *p;
-                    *p = v;
-                }
-                if (valid) {  // shifted sums (shift = first value seen): cancellation-free variance
-                    if (st_n[ns] == 0.f) st_k[ns] = v;
-                    const float dv = v - st_k[ns];
-                    st_n[ns] += 1.f;
-                    st_s1[ns] += dv;
-                    st_s2[ns] += dv * dv;
-                }
-            }
-        }
-    }
+    const DipEpi epi = dip_epi_make(d, ty, tx, C::TH, C::TW);
     if constexpr (EXTRA) {
-        const int n = n0 + BN + l31, sub = wm * C::MS + wn;
+        const int n = n0 + BN + l31;
         const float bias = (d.bias != nullptr && n < d.Cout) ? d.bias[n] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int oy = ty * C::TH + 2 * sub + (m >> 4), ox = tx * C::TW + (m & 15);
-            if (oy < d.Hout && ox < d.Wout && n < d.Cy) {
-                float* p = d.y + ((size_t)oy * pitch + ox) * d.Cy + n;
-                float v = accx[r] + bias;
-                if (d.accumulate) v += *p;
-                *p = v;
-            }
-        }
+        dip_epi_store16(epi, accx, wm * C::MS + wn, n, bias, half);
     }
-    if (d.stats != nullptr) {
-        __syncthreads();  // LDS A/B no longer needed; reuse as reduction scratch
-        float* red = smem;  // [WM][WN*NS*32][3]
-#pragma unroll
-        for (int ns = 0; ns < C::NS; ++ns) {
-            float cn = st_n[ns];
-            float mean = cn > 0.f ? st_k[ns] + st_s1[ns] / cn : 0.f;
-            float M2 = cn > 0.f ? st_s2[ns] - st_s1[ns] * st_s1[ns] / cn : 0.f;
-            const float on = __shfl_xor(cn, 32), om = __shfl_xor(mean, 32), oM = __shfl_xor(M2, 32);
-            dip_chan(cn, mean, M2, on, om, oM);
-            if (half == 0) {
-                float* q = red + ((wm * (C::WN * C::NS * 32)) + (wn * C::NS + ns) * 32 + l31) * 3;
-                q[0] = cn; q[1] = mean; q[2] = M2;
-            }
-        }
-        __syncthreads();
-        if (tid < BN) {
-            float cn = 0.f, mean = 0.f, M2 = 0.f;
-#pragma unroll
-            for (int w = 0; w < C::WM; ++w) {
-                const float* q = red + (w * (C::WN * C::NS * 32) + tid) * 3;
-                dip_chan(cn, mean, M2, q[0], q[1], q[2]);
-            }
-            const int n = n0 + tid;
-            if (n < CoutP) {
-                float* o = d.stats + (size_t)tile * 3 * CoutP + n;
-                o[0] = cn; o[CoutP] = mean; o[2 * CoutP] = M2;
-            }
-        }
-    }
+    dip_conv_epilogue<C, BN>(d, acc, epi, n0, wn, wm, l31, half, tid, tile, CoutP, smem);
 }
 
 // Sum the split-K slices (fixed order), add bias, store (honouring y_pitch / accumulate) and emit

@@ -16,6 +16,8 @@
 // Restrictions (checked by the dispatcher): stride 1, ks in {1,3}, Cin <= 288 when a transform is
 // fused; everything else takes the register-staged kernel in conv_igemm.hip.
 #include "dip_common.h"
+#include "conv_epilogue.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -71,12 +73,50 @@ __device__ __forceinline__ void lds_dma16_s(const void* sbase, unsigned voff, un
                  : "memory");
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// wait until at most n (wave-uniform, 0..8) of this wave's loads are still in flight
+__device__ __forceinline__ void dma_wait_keep(int n) {
+    switch (n) {
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+#ifdef DIP_CLK_PROFILE
+// debug build only: per-workgroup shader-clock totals of the K-loop segments (wave 0)
+__device__ unsigned long long g_prof[8192 * 16];
+__device__ unsigned g_trace[128 * 8];
+// ordered against the MFMAs through fake read-write operands on the accumulators
+#define PROBE(i)                                                                                         \
+    do {                                                                                                 \
+        unsigned long long t__;                                                                          \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)"                                              \
+                     : "=s"(t__), "+v"(acc[0][0]), "+v"(acc[C::MS - 1][C::NS - 1]), "+v"(acc[0][C::NS - 1]), \
+                       "+v"(acc[C::MS - 1][0])                                                           \
+                     :                                                                                   \
+                     : "memory");                                                                        \
+        prof[i] += t__ - tlast;                                                                          \
+        if (blockIdx.x == 0 && tid == 0 && u - u0 < 128) g_trace[(u - u0) * 8 + i] = (unsigned)(t__ - tlast); \
+        tlast = t__;                                                                                     \
+    } while (0)
+#else
+#define PROBE(i) do { } while (0)
+#endif
 
 template <int KS, int BN, bool TR>
 __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDesc d, const int ntx, const int ntiles,
                                                                 const int CoutP, const int n_base, const int ksplit,
                                                                 float* __restrict__ ws) {
     using C = DCfg<KS, BN>;
+#ifdef DIP_CLK_PROFILE
+    const unsigned long long wall0 = wall_clock64(), clk0 = clock64();
+#endif
     constexpr int KK = KS * KS;
     constexpr int CCH = C::CCH;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -109,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
     // fragment read, no extra barrier, and zero-padded slots simply stay zero.
     // 1x1: every unit is a new chunk, so the transform stays at the fragment read (2x redundancy only).
     constexpr bool has_tr = TR && (KS == 1);      // transform at fragment read
-    constexpr bool tr_inplace = TR && (KS != 1);
+    const bool fix_inplace = (KS != 1) && (TR || d.pad_mode != DIP_PAD_REFLECT || d.dil != 1);
     const float slope = d.tr.slope;
     if constexpr (TR) {
         for (int c = tid; c < d.Cin; c += 256) {
@@ -179,23 +219,33 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
 #pragma unroll
         for (int i = 0; i < C::A_SLOTS; ++i) {
             if (ac4[i] >= 0 && ac4[i] < c4n) {
-                if (aoff[i] != NONE) lds_dma16_s(sb, aoff[i], m0b + i * 4096u);
-                else lds_dma16_s(g_zero_page, 0u, m0b + i * 4096u);
+                if constexpr (KS == 1) {
+                    if (aoff[i] != NONE) lds_dma16_s(sb, aoff[i], m0b + i * 4096u);
+                    else lds_dma16_s(g_zero_page, 0u, m0b + i * 4096u);
+                } else {
+                    // exactly ONE instruction per slot and wave (the unit-end wait counts them): a padded
+                    // lane copies 16 valid bytes from offset 0 and fixA() zeroes the slot afterwards
+                    lds_dma16_s(sb, aoff[i] != NONE ? aoff[i] : 0u, m0b + i * 4096u);
+                }
             }
         }
     };
-    auto trA = [&](int ch, float* Abuf) {   // in-place BatchNorm+LeakyReLU of this thread's own slots
-        const int cb = ch * CCH, c4n = chunk_cc(ch) >> 2;
+    auto fixA = [&](int ch, float* Abuf) {  // in-place pass over this thread's own landed slots:
+        const int cb = ch * CCH, c4n = chunk_cc(ch) >> 2;   // BatchNorm+LeakyReLU, or zero for padding
 #pragma unroll
         for (int i = 0; i < C::A_SLOTS; ++i) {
-            if (ac4[i] >= 0 && ac4[i] < c4n && aoff[i] != NONE) {
+            if (ac4[i] >= 0 && ac4[i] < c4n) {
                 float* p = Abuf + (tid + i * 256) * 4;
-                f32x4 v = *reinterpret_cast<const f32x4*>(p);
-                const f32x4 ta = *reinterpret_cast<const f32x4*>(tra + cb + ac4[i] * 4);
-                const f32x4 tb = *reinterpret_cast<const f32x4*>(trb + cb + ac4[i] * 4);
+                if (aoff[i] == NONE) {
+                    *reinterpret_cast<f32x4*>(p) = f32x4{0.f, 0.f, 0.f, 0.f};
+                } else if constexpr (TR) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(p);
+                    const f32x4 ta = *reinterpret_cast<const f32x4*>(tra + cb + ac4[i] * 4);
+                    const f32x4 tb = *reinterpret_cast<const f32x4*>(trb + cb + ac4[i] * 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = dip_act(fmaf(ta[e], v[e], tb[e]), slope);
-                *reinterpret_cast<f32x4*>(p) = v;
+                    for (int e = 0; e < 4; ++e) v[e] = dip_act(fmaf(ta[e], v[e], tb[e]), slope);
+                    *reinterpret_cast<f32x4*>(p) = v;
+                }
             }
         }
     };
@@ -214,9 +264,21 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
     dmaA(ch0, 0);
     dmaB(u0, 0);
     dma_wait();
-    if constexpr (tr_inplace) trA(ch0, As);
+    if (fix_inplace) fixA(ch0, As);
     __syncthreads();
-    bool tr_pending = false;               // next chunk's halo has landed (own pieces) but is not transformed yet
+    // Halo DMAs of this wave per chunk (wave-uniform).  The unit that issues the next chunk's halo
+    // waits only for its weights: loads retire in order and the halo is issued AFTER the weights, so
+    // vmcnt(nA) leaves exactly the halo in flight (it comes from HBM and used to stall that unit for
+    // ~10k cycles, 1050 cycles per unit on average).
+    int nA = 0;
+#pragma unroll
+    for (int i = 0; i < C::A_SLOTS; ++i) nA += (wave * 64 + i * 256 < C::NPIX * 8) ? 1 : 0;
+    int a_state = 0;                       // next halo: 0 none/ready, 1 in flight, 2 landed but not fixed up yet
+#ifdef DIP_CLK_PROFILE
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long tstart = clock64();
+    unsigned long long tlast = tstart;
+#endif
 
     for (int u = u0; u < u1; ++u) {
         const int ch = u / KK, tap = u - ch * KK;
@@ -290,15 +352,20 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
         auto issue = [&]() {
             if (more) dmaB(u + 1, bbuf_n);
             if (fetch_next) dmaA(ch + 1, abuf_n);
-            if constexpr (tr_inplace) {
-                if (tr_pending) { trA(ch + 1, Anxt); tr_pending = false; }
+            if (a_state == 2) {            // landed one unit ago: fix it up in the shadow of the MFMAs
+                if (fix_inplace) fixA(ch + 1, Anxt);
+                a_state = 0;
             }
         };
+        PROBE(0);
         if (cc == CCH) {
             mma8(0);
+            PROBE(1);
             issue();
+            PROBE(2);
 #pragma unroll
             for (int kk = 1; kk < CCH / 8; ++kk) mma8(kk);
+            PROBE(3);
         } else {
             issue();
             const int kk8 = cc >> 3;
@@ -306,20 +373,30 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
             if (cc & 4) mma4();
         }
         if (more) {
-            dma_wait();
-            if constexpr (tr_inplace) {
-                if (fetch_next) {
-                    // own pieces have landed; transform now if the next unit already needs the halo,
-                    // otherwise in the shadow of the next unit's first MFMA block
-                    if (tap == KK - 1) trA(ch + 1, Anxt);
-                    else tr_pending = true;
-                }
+            const bool need_now = (tap == KK - 1);          // the next unit reads the next halo
+            if (fetch_next && !need_now && KS != 1) {
+                dma_wait_keep(nA);
+                a_state = 1;
+            } else {
+                dma_wait();
+                if (fetch_next || a_state == 1) a_state = 2;
             }
+            PROBE(4);
+            if (need_now && a_state == 2) {
+                if (fix_inplace) fixA(ch + 1, Anxt);
+                a_state = 0;
+            }
+            PROBE(5);
             __syncthreads();
+            PROBE(6);
         }
     }
+#ifdef DIP_CLK_PROFILE
+    const unsigned long long clk_kend = clock64();
+    prof[7] = clk_kend - tstart;
+#endif
 
-    // ---- epilogue (identical to conv_igemm.hip) ----
+    // ---- epilogue (conv_epilogue.h) ----
     if (ksplit > 1) {
         float* wz = ws + (size_t)z * d.Hout * d.Wout * d.Cy;
 #pragma unroll
@@ -340,68 +417,21 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
         }
         return;
     }
-    const int pitch = d.y_pitch > 0 ? d.y_pitch : d.Wout;
-    float st_n[C::NS], st_k[C::NS], st_s1[C::NS], st_s2[C::NS];
-#pragma unroll
-    for (int ns = 0; ns < C::NS; ++ns) {
-        const int n = n0 + (wn * C::NS + ns) * 32 + l31;
-        const float bias = (d.bias != nullptr && n < d.Cout) ? d.bias[n] : 0.f;
-        st_n[ns] = 0.f; st_k[ns] = 0.f; st_s1[ns] = 0.f; st_s2[ns] = 0.f;
-#pragma unroll
-        for (int ms = 0; ms < C::MS; ++ms) {
-            const int sub = wm * C::MS + ms;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int oy = ty * C::TH + 2 * sub + (m >> 4);
-                const int ox = tx * C::TW + (m & 15);
-                const bool valid = (oy < d.Hout) && (ox < d.Wout);
-                float v = acc[ms][ns][r] + bias;
-                if (valid && n < d.Cy) {
-                    float* p = d.y + ((size_t)oy * pitch + ox) * d.Cy + n;
-                    if (d.accumulate) v += *p;
-                    *p = v;
-                }
-                if (valid) {
-                    if (st_n[ns] == 0.f) st_k[ns] = v;
-                    const float dv = v - st_k[ns];
-                    st_n[ns] += 1.f;
-                    st_s1[ns] += dv;
-                    st_s2[ns] += dv * dv;
-                }
-            }
-        }
+    const DipEpi epi = dip_epi_make(d, ty, tx, C::TH, C::TW);
+    dip_conv_epilogue<C, BN>(d, acc, epi, n0, wn, wm, l31, half, tid, tile, CoutP, smem);
+#ifdef DIP_CLK_PROFILE
+    __syncthreads();
+    if (tid == 0 && blockIdx.x < 8192) {
+        unsigned long long* o = g_prof + (size_t)blockIdx.x * 16;
+        for (int i = 0; i < 8; ++i) o[i] = prof[i];
+        o[8] = wall0;
+        o[9] = wall_clock64();
+        o[10] = __builtin_amdgcn_s_getreg(63492);      // HW_ID
+        o[11] = __builtin_amdgcn_s_getreg(63508);      // XCC_ID
+        o[12] = tstart - clk0;                          // prologue cycles
+        o[13] = clock64() - clk_kend;                   // epilogue cycles
     }
-    if (d.stats != nullptr) {
-        __syncthreads();
-        float* red = smem;
-#pragma unroll
-        for (int ns = 0; ns < C::NS; ++ns) {
-            float cn = st_n[ns];
-            float mean = cn > 0.f ? st_k[ns] + st_s1[ns] / cn : 0.f;
-            float M2 = cn > 0.f ? st_s2[ns] - st_s1[ns] * st_s1[ns] / cn : 0.f;
-            const float on = __shfl_xor(cn, 32), om = __shfl_xor(mean, 32), oM = __shfl_xor(M2, 32);
-            dip_chan(cn, mean, M2, on, om, oM);
-            if (half == 0) {
-                float* q = red + ((wm * (C::WN * C::NS * 32)) + (wn * C::NS + ns) * 32 + l31) * 3;
-                q[0] = cn; q[1] = mean; q[2] = M2;
-            }
-        }
-        __syncthreads();
-        if (tid < BN) {
-            float cn = 0.f, mean = 0.f, M2 = 0.f;
-#pragma unroll
-            for (int w = 0; w < C::WM; ++w) {
-                const float* q = red + (w * (C::WN * C::NS * 32) + tid) * 3;
-                dip_chan(cn, mean, M2, q[0], q[1], q[2]);
-            }
-            const int n = n0 + tid;
-            if (n < CoutP) {
-                float* o = d.stats + (size_t)tile * 3 * CoutP + n;
-                o[0] = cn; o[CoutP] = mean; o[2 * CoutP] = M2;
-            }
-        }
-    }
+#endif
 }
 
 template <int KS, int BN, bool TR>
@@ -455,6 +485,15 @@ extern "C" int dip_conv_dma_eligible(const DipConvDesc* dp) {
     if (has_tr && d.ks == 1 && (d.off != 0 || d.dil != 1)) return 0;
     return 1;
 }
+
+#ifdef DIP_CLK_PROFILE
+extern "C" int dip_debug_trace_read(void* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_trace), sizeof(unsigned) * 128 * 8);
+}
+extern "C" int dip_debug_prof_read(void* dst, int nwg) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_prof), (size_t)nwg * 16 * sizeof(unsigned long long));
+}
+#endif
 
 extern "C" int dip_conv_igemm_dma(const DipConvDesc* dp, int ksplit, void* stream) {
     const DipConvDesc& d = *dp;
