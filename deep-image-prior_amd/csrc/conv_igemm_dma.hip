@@ -18,10 +18,26 @@
 #include "dip_common.h"
 #include "conv_epilogue.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
 constexpr int TRN = 288;
+
+// compile-time loop: f(std::integral_constant<int, I>{}) for I in [I0, N)
+template <int I, int N>
+struct SFor {
+    template <class F>
+    static __device__ __forceinline__ void run(F&& f) {
+        f(std::integral_constant<int, I>{});
+        SFor<I + 1, N>::run(f);
+    }
+};
+template <int N>
+struct SFor<N, N> {
+    template <class F>
+    static __device__ __forceinline__ void run(F&&) {}
+};
 
 __device__ __attribute__((aligned(16))) float g_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
 
@@ -65,7 +81,14 @@ __device__ __forceinline__ void lds_dma16(const float* gsrc, float* lds_dst_wave
 }
 // saddr form: 64-bit wave-uniform base in SGPRs + 32-bit per-lane byte offset; LDS base in m0.
 // Two SALU moves + the load: the per-unit weight DMA costs ~15 instructions per wave.
-__device__ __forceinline__ void lds_dma16_s(const void* sbase, unsigned voff, unsigned m0val) {
+__device__ __forceinline__ void lds_dma16_s(const void* sbase_in, unsigned voff, unsigned m0val_in) {
+    // the operands are workgroup-uniform by construction; tell the register allocator so
+    const unsigned long long sb64 = (unsigned long long)sbase_in;
+    const unsigned sb_hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(sb64 >> 32));
+    const unsigned sb_lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)sb64);     // (the builtin returns int)
+    const unsigned long long sb_u = ((unsigned long long)sb_hi << 32) | (unsigned long long)sb_lo;
+    const void* sbase = (const void*)sb_u;
+    const unsigned m0val = __builtin_amdgcn_readfirstlane(m0val_in);
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
@@ -92,19 +115,7 @@ __device__ __forceinline__ void dma_wait_keep(int n) {
 // debug build only: per-workgroup shader-clock totals of the K-loop segments (wave 0)
 __device__ unsigned long long g_prof[8192 * 16];
 __device__ unsigned g_trace[128 * 8];
-// ordered against the MFMAs through fake read-write operands on the accumulators
-#define PROBE(i)                                                                                         \
-    do {                                                                                                 \
-        unsigned long long t__;                                                                          \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)"                                              \
-                     : "=s"(t__), "+v"(acc[0][0]), "+v"(acc[C::MS - 1][C::NS - 1]), "+v"(acc[0][C::NS - 1]), \
-                       "+v"(acc[C::MS - 1][0])                                                           \
-                     :                                                                                   \
-                     : "memory");                                                                        \
-        prof[i] += t__ - tlast;                                                                          \
-        if (blockIdx.x == 0 && tid == 0 && u - u0 < 128) g_trace[(u - u0) * 8 + i] = (unsigned)(t__ - tlast); \
-        tlast = t__;                                                                                     \
-    } while (0)
+#define PROBE(i) do { } while (0)
 #else
 #define PROBE(i) do { } while (0)
 #endif
@@ -260,6 +271,51 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
         }
     };
 
+    // One DMA piece each, so the K loop can drop them between MFMAs (a block of DMA issue code
+    // between two MFMA clusters leaves the matrix pipe idle: the wave issues in order).
+    auto dmaA_slot = [&](auto I, const float* sb, unsigned m0b, int c4n) {
+        constexpr int i = decltype(I)::value;
+        if constexpr (i < C::A_SLOTS) {
+            if constexpr (KS == 1) {
+                if (ac4[i] >= 0 && ac4[i] < c4n) {
+                    if (aoff[i] != NONE) lds_dma16_s(sb, aoff[i], m0b + i * 4096u);
+                    else lds_dma16_s(g_zero_page, 0u, m0b + i * 4096u);
+                }
+            } else {
+                // full chunks only (c4n == 8): every lane of a full slot copies; a padded lane copies 16
+                // valid bytes from offset 0 and fixA zeroes the slot.  ONE instruction per slot and wave.
+                const unsigned vo = aoff[i] != NONE ? aoff[i] : 0u;
+                if constexpr ((i + 1) * 256 <= C::NPIX * 8) {
+                    lds_dma16_s(sb, vo, m0b + i * 4096u);
+                } else {
+                    if (ac4[i] >= 0) lds_dma16_s(sb, vo, m0b + i * 4096u);
+                }
+            }
+        }
+    };
+    auto dmaB_slot = [&](auto I, const float* sb, unsigned m0b) {     // full chunks: 8*BN pieces == B_SLOTS*256
+        constexpr int i = decltype(I)::value;
+        if constexpr (i < C::B_SLOTS) lds_dma16_s(sb, boff[i], m0b + i * 4096u);
+    };
+    auto fixA_slot = [&](auto I, int cb, float* Abuf) {               // full chunks
+        constexpr int i = decltype(I)::value;
+        if constexpr (i < C::A_SLOTS) {
+            if (ac4[i] >= 0) {
+                float* p = Abuf + (tid + i * 256) * 4;
+                if (aoff[i] == NONE) {
+                    *reinterpret_cast<f32x4*>(p) = f32x4{0.f, 0.f, 0.f, 0.f};
+                } else if constexpr (TR) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(p);
+                    const f32x4 ta = *reinterpret_cast<const f32x4*>(tra + cb + ac4[i] * 4);
+                    const f32x4 tb = *reinterpret_cast<const f32x4*>(trb + cb + ac4[i] * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = dip_act(fmaf(ta[e], v[e], tb[e]), slope);
+                    *reinterpret_cast<f32x4*>(p) = v;
+                }
+            }
+        }
+    };
+
     // ---- prologue ----
     dmaA(ch0, 0);
     dmaB(u0, 0);
@@ -268,8 +324,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
     __syncthreads();
     // Halo DMAs of this wave per chunk (wave-uniform).  The unit that issues the next chunk's halo
     // waits only for its weights: loads retire in order and the halo is issued AFTER the weights, so
-    // vmcnt(nA) leaves exactly the halo in flight (it comes from HBM and used to stall that unit for
-    // ~10k cycles, 1050 cycles per unit on average).
+    // vmcnt(nA) leaves exactly the halo in flight.
     int nA = 0;
 #pragma unroll
     for (int i = 0; i < C::A_SLOTS; ++i) nA += (wave * 64 + i * 256 < C::NPIX * 8) ? 1 : 0;
@@ -277,103 +332,84 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
 #ifdef DIP_CLK_PROFILE
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long tstart = clock64();
-    unsigned long long tlast = tstart;
 #endif
 
-    for (int u = u0; u < u1; ++u) {
-        const int ch = u / KK, tap = u - ch * KK;
-        const int ky = tap / KS, kx = tap - ky * KS;
-        const int cc = chunk_cc(ch), cb = ch * CCH;
-        const float* Acur = As + ((ch - ch0) & 1) * C::A_BUF;
-        float* Anxt = As + ((ch - ch0 + 1) & 1) * C::A_BUF;
-        const float* Bcur = Bs + ((u - u0) & 1) * C::B_BUF;
-        const bool more = (u + 1) < u1;
-        const bool fetch_next = (u == u0 || tap == 0) && (ch + 1) * KK < u1;
-        const int abuf_n = (ch - ch0 + 1) & 1, bbuf_n = (u - u0 + 1) & 1;
-        int abase[C::MS], sw[C::MS];
+    // One K step of 8 channels: the fragments of both operands (lane = 4 consecutive channels of its
+    // pixel / column -> 4 MFMAs per ds_read_b128 pair).
+    struct Frag {
+        f32x4 a[C::MS], b[C::NS], ta, tb;
+    };
+    int abase[C::MS], sw[C::MS];
+    auto set_tap = [&](int ky, int kx) {
 #pragma unroll
         for (int ms = 0; ms < C::MS; ++ms) {
             const int hp = hp0[ms] + ky * C::HTW + kx;
             abase[ms] = hp * 32;
             sw[ms] = hp & 7;
         }
-        auto mma8 = [&](int kk) {
-            const int c4 = 2 * kk + half;
-            f32x4 a[C::MS], b[C::NS];
+    };
+    auto read_frag = [&](Frag& f, const float* Acur, const float* Bcur, int cb, int kk) {
+        const int c4 = 2 * kk + half;
 #pragma unroll
-            for (int ms = 0; ms < C::MS; ++ms)
-                a[ms] = *reinterpret_cast<const f32x4*>(Acur + abase[ms] + ((c4 ^ sw[ms]) << 2));
+        for (int ms = 0; ms < C::MS; ++ms)
+            f.a[ms] = *reinterpret_cast<const f32x4*>(Acur + abase[ms] + ((c4 ^ sw[ms]) << 2));
 #pragma unroll
-            for (int ns = 0; ns < C::NS; ++ns)
-                b[ns] = *reinterpret_cast<const f32x4*>(Bcur + c4 * (BN * 4) + bcol[ns]);
-            if constexpr (has_tr) {
-                const f32x4 ta = *reinterpret_cast<const f32x4*>(tra + cb + c4 * 4);
-                const f32x4 tb = *reinterpret_cast<const f32x4*>(trb + cb + c4 * 4);
-#pragma unroll
-                for (int ms = 0; ms < C::MS; ++ms)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) a[ms][e] = dip_act(fmaf(ta[e], a[ms][e], tb[e]), slope);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int ms = 0; ms < C::MS; ++ms)
-#pragma unroll
-                    for (int ns = 0; ns < C::NS; ++ns)
-                        acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ms][j], b[ns][j], acc[ms][ns], 0, 0, 0);
-        };
-        auto mma4 = [&]() {       // tail group c4t: lanes 0-31 take its channels 0,1; lanes 32-63 channels 2,3
-            const int c4t = (cc - 4) >> 2;
-            f32x2 a[C::MS], b[C::NS];
-#pragma unroll
-            for (int ms = 0; ms < C::MS; ++ms)
-                a[ms] = *reinterpret_cast<const f32x2*>(Acur + abase[ms] + ((c4t ^ sw[ms]) << 2) + 2 * half);
-#pragma unroll
-            for (int ns = 0; ns < C::NS; ++ns)
-                b[ns] = *reinterpret_cast<const f32x2*>(Bcur + c4t * (BN * 4) + bcol[ns] + 2 * half);
-            if constexpr (has_tr) {
-                const f32x2 ta = *reinterpret_cast<const f32x2*>(tra + cb + c4t * 4 + 2 * half);
-                const f32x2 tb = *reinterpret_cast<const f32x2*>(trb + cb + c4t * 4 + 2 * half);
-#pragma unroll
-                for (int ms = 0; ms < C::MS; ++ms)
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) a[ms][e] = dip_act(fmaf(ta[e], a[ms][e], tb[e]), slope);
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int ms = 0; ms < C::MS; ++ms)
-#pragma unroll
-                    for (int ns = 0; ns < C::NS; ++ns)
-                        acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ms][j], b[ns][j], acc[ms][ns], 0, 0, 0);
-        };
-        // The DMA issue (asm volatile = scheduling barrier) sits BEHIND the first 16 MFMAs of the unit,
-        // whose 1024 cycles cover it; issued first it was a ~0.4 us serial prefix per unit.
-        auto issue = [&]() {
-            if (more) dmaB(u + 1, bbuf_n);
-            if (fetch_next) dmaA(ch + 1, abuf_n);
-            if (a_state == 2) {            // landed one unit ago: fix it up in the shadow of the MFMAs
-                if (fix_inplace) fixA(ch + 1, Anxt);
-                a_state = 0;
-            }
-        };
-        PROBE(0);
-        if (cc == CCH) {
-            mma8(0);
-            PROBE(1);
-            issue();
-            PROBE(2);
-#pragma unroll
-            for (int kk = 1; kk < CCH / 8; ++kk) mma8(kk);
-            PROBE(3);
-        } else {
-            issue();
-            const int kk8 = cc >> 3;
-            for (int kk = 0; kk < kk8; ++kk) mma8(kk);
-            if (cc & 4) mma4();
+        for (int ns = 0; ns < C::NS; ++ns)
+            f.b[ns] = *reinterpret_cast<const f32x4*>(Bcur + c4 * (BN * 4) + bcol[ns]);
+        if constexpr (has_tr) {
+            f.ta = *reinterpret_cast<const f32x4*>(tra + cb + c4 * 4);
+            f.tb = *reinterpret_cast<const f32x4*>(trb + cb + c4 * 4);
         }
-        if (more) {
-            const bool need_now = (tap == KK - 1);          // the next unit reads the next halo
+    };
+    // 16 MFMAs of one fragment set; step(J) runs after the 4 MFMAs of channel J
+    auto mma_frag = [&](Frag& f, auto&& step) {
+        if constexpr (has_tr) {
+#pragma unroll
+            for (int ms = 0; ms < C::MS; ++ms)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) f.a[ms][e] = dip_act(fmaf(f.ta[e], f.a[ms][e], f.tb[e]), slope);
+        }
+        SFor<0, 4>::run([&](auto J) {
+            constexpr int j = decltype(J)::value;
+#pragma unroll
+            for (int ms = 0; ms < C::MS; ++ms)
+#pragma unroll
+                for (int ns = 0; ns < C::NS; ++ns)
+                    acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[ms][j], f.b[ns][j], acc[ms][ns], 0, 0, 0);
+            step(J);
+        });
+    };
+
+    // incremental bookkeeping (no divisions in the loop)
+    int ch = ch0, tap = u0 - ch0 * KK;
+    int ky = tap / KS, kx = tap - ky * KS;
+    int abuf = 0, bbuf = 0;
+    const size_t wtap = (size_t)cin4 * CoutP * 4;                     // floats between taps in the packed weights
+    const float* wcur = d.wp + (size_t)tap * wtap + (size_t)(ch * (CCH / 4)) * CoutP * 4;
+    bool have_f0 = false;
+    Frag F0;
+    set_tap(ky, kx);
+
+    for (int u = u0; u < u1; ++u) {
+        const int cc = chunk_cc(ch), cb = ch * CCH;
+        const float* Acur = As + abuf * C::A_BUF;
+        float* Anxt = As + (abuf ^ 1) * C::A_BUF;
+        const float* Bcur = Bs + bbuf * C::B_BUF;
+        const bool more = (u + 1) < u1;
+        const bool fetch_next = (u == u0 || tap == 0) && (ch + 1) * KK < u1;
+        const bool last_tap = (tap == KK - 1);
+        // next unit
+        const int ch_n = last_tap ? ch + 1 : ch;
+        const float* wnext = last_tap ? d.wp + (size_t)((ch + 1) * (CCH / 4)) * CoutP * 4 : wcur + wtap;
+        const unsigned m0B = lds_base + (unsigned)(2 * C::A_BUF + (bbuf ^ 1) * C::B_BUF) * 4u + lds_piece;
+        const unsigned m0A = lds_base + (unsigned)((abuf ^ 1) * C::A_BUF) * 4u + lds_piece;
+        const float* asrc = d.x + (ch + 1) * CCH;
+        const bool nextB_full = more && chunk_cc(ch_n) == CCH;
+        const bool nextA_full = fetch_next && chunk_cc(ch + 1) == CCH;
+
+        auto unit_end = [&]() {             // publish the next unit's operands
+            if (!more) return;
+            const bool need_now = last_tap;                  // the next unit reads the next halo
             if (fetch_next && !need_now && KS != 1) {
                 dma_wait_keep(nA);
                 a_state = 1;
@@ -381,14 +417,102 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
                 dma_wait();
                 if (fetch_next || a_state == 1) a_state = 2;
             }
-            PROBE(4);
             if (need_now && a_state == 2) {
                 if (fix_inplace) fixA(ch + 1, Anxt);
                 a_state = 0;
             }
-            PROBE(5);
             __syncthreads();
-            PROBE(6);
+        };
+        auto advance = [&]() {              // bookkeeping of unit u+1 (valid only if more)
+            wcur = wnext;
+            bbuf ^= 1;
+            if (last_tap) { ch += 1; tap = 0; ky = 0; kx = 0; abuf ^= 1; }
+            else { tap += 1; kx += 1; if (kx == KS) { kx = 0; ky += 1; } }
+            set_tap(ky, kx);
+        };
+
+        if (cc == CCH) {
+            Frag F1, F2, F3;
+            if (!have_f0) read_frag(F0, Acur, Bcur, cb, 0);
+            read_frag(F1, Acur, Bcur, cb, 1);
+            mma_frag(F0, [&](auto J) {                       // weights of unit u+1
+                if (nextB_full) dmaB_slot(J, wnext, m0B);
+            });
+            if (more && !nextB_full) dmaB(u + 1, bbuf ^ 1);  // ragged last chunk: generic issue
+            read_frag(F2, Acur, Bcur, cb, 2);
+            mma_frag(F1, [&](auto J) {                       // halo of chunk ch+1, pieces 0..3
+                if (nextA_full) dmaA_slot(J, asrc, m0A, 8);
+            });
+            read_frag(F3, Acur, Bcur, cb, 3);
+            mma_frag(F2, [&](auto J) {                       // pieces 4..7
+                constexpr int j = decltype(J)::value;
+                if (nextA_full) dmaA_slot(std::integral_constant<int, 4 + j>{}, asrc, m0A, 8);
+            });
+            if (fetch_next && !nextA_full) dmaA(ch + 1, abuf ^ 1);
+            unit_end();
+            // The last 16 MFMAs of this unit run AFTER the barrier (their operands are in registers):
+            // they cover the next unit's first LDS reads and, one unit after its halo has landed,
+            // the in-place fix-up of that halo.
+            const bool do_fix = more && a_state == 2;
+            const int cb_n = (ch + 1) * CCH;
+            const bool fix_full = chunk_cc(ch + 1) == CCH;
+            const bool pre = more && chunk_cc(ch_n) == CCH;
+            if (more) advance();
+            if (pre) read_frag(F0, As + abuf * C::A_BUF, Bs + bbuf * C::B_BUF, ch * CCH, 0);
+            have_f0 = pre;
+            mma_frag(F3, [&](auto J) {
+                constexpr int j = decltype(J)::value;
+                if (do_fix && fix_inplace && fix_full) {
+                    fixA_slot(J, cb_n, Anxt);
+                    fixA_slot(std::integral_constant<int, 4 + j>{}, cb_n, Anxt);
+                }
+            });
+            if (do_fix) {
+                if (fix_inplace && !fix_full) fixA(cb_n / CCH, Anxt);
+                a_state = 0;
+            }
+        } else {
+            // ragged last chunk (cc < 32): issue first, then a rolled loop
+            if (more) dmaB(u + 1, bbuf ^ 1);
+            if (fetch_next) dmaA(ch + 1, abuf ^ 1);
+            if (a_state == 2) {
+                if (fix_inplace) fixA(ch + 1, Anxt);
+                a_state = 0;
+            }
+            const int kk8 = cc >> 3;
+            for (int kk = 0; kk < kk8; ++kk) {
+                Frag f;
+                read_frag(f, Acur, Bcur, cb, kk);
+                mma_frag(f, [&](auto) {});
+            }
+            if (cc & 4) {       // tail group c4t: lanes 0-31 take its channels 0,1; lanes 32-63 channels 2,3
+                const int c4t = (cc - 4) >> 2;
+                f32x2 a2[C::MS], b2[C::NS];
+#pragma unroll
+                for (int ms = 0; ms < C::MS; ++ms)
+                    a2[ms] = *reinterpret_cast<const f32x2*>(Acur + abase[ms] + ((c4t ^ sw[ms]) << 2) + 2 * half);
+#pragma unroll
+                for (int ns = 0; ns < C::NS; ++ns)
+                    b2[ns] = *reinterpret_cast<const f32x2*>(Bcur + c4t * (BN * 4) + bcol[ns] + 2 * half);
+                if constexpr (has_tr) {
+                    const f32x2 ta = *reinterpret_cast<const f32x2*>(tra + cb + c4t * 4 + 2 * half);
+                    const f32x2 tb = *reinterpret_cast<const f32x2*>(trb + cb + c4t * 4 + 2 * half);
+#pragma unroll
+                    for (int ms = 0; ms < C::MS; ++ms)
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) a2[ms][e] = dip_act(fmaf(ta[e], a2[ms][e], tb[e]), slope);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int ms = 0; ms < C::MS; ++ms)
+#pragma unroll
+                        for (int ns = 0; ns < C::NS; ++ns)
+                            acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[ms][j], b2[ns][j], acc[ms][ns], 0, 0, 0);
+            }
+            unit_end();
+            if (more) advance();
+            have_f0 = false;
         }
     }
 #ifdef DIP_CLK_PROFILE
