@@ -136,32 +136,69 @@ def profile_ops(eng, reps=3):
     return {k: float(np.mean(v)) for k, v in acc.items()}
 
 
+DOMINANT = "conv_igemm_dma_kernel<3,128,*>"
+
+
+def dominant_ops(eng):
+    """Names of the launch-list entries that run the dominant kernel: 3x3 convolutions (forward and
+    data gradient) that dip_conv_igemm dispatches to the LDS-DMA implicit-GEMM kernel, 128-column
+    tile (dip_conv_variant == 1).  The 132-channel data gradients (N = 160 variant of
+    conv_igemm_kernel) and the stride-2 forwards are other kernels and are not counted."""
+    import dip_native as N
+    lib = N.lib()
+    names, nbytes = [], 0.0
+    for ops in (eng.fwd_ops, eng.bwd_ops):
+        for fn, args, name in ops:
+            kind = name.partition(":")[0]
+            if kind not in ("conv_fwd", "dgrad", "dgrad+"):
+                continue
+            d = args[0]._obj
+            if d.ks == 3 and d.Cout >= 128 and lib.dip_conv_variant(args[0]) == 1:
+                names.append(name)
+                # compulsory traffic of the launch: input and packed weights read once, output written once
+                nbytes += 4.0 * (d.Hin * d.Win * d.Cin + 9 * d.Cin * d.Cout + d.Hout * d.Wout * d.Cout)
+    return names, nbytes
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (profiles/r01_pmc_traffic.json, produced by tools/pmc_traffic.py); None when absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            t = json.load(f)
+        return t if t.get("kernel") == DOMINANT else None
+    except (OSError, ValueError):
+        return None
+
+
 def roofline(eng, per_op_ms):
-    """Dominant kernel = conv_igemm_kernel<3,1,32,128>: every 3x3 stride-1 forward conv and every
-    data-gradient launch of a 3x3 conv (the stride-2 ones run as a dilated stride-1 gather)."""
+    """Dominant kernel = conv_igemm_dma_kernel<3,128,*> (all its launches of one iteration, see
+    dominant_ops).  achieved = their algorithmic FLOPs (2*Cout*Ho*Wo*Cin*9 per launch)
+    / their HIP-event time on the engine's stream."""
     fl = conv_flops(eng)
-    tot_f = tot_ms = 0.0
-    n = 0
-    by_name = {r.name: r for r in eng.convs}
-    for name, ms in per_op_ms.items():
-        kind, _, lname = name.partition(":")
-        r = by_name.get(lname)
-        if r is None or r.ks != 3:
-            continue
-        if (kind == "conv_fwd" and r.stride == 1) or kind == "dgrad":
-            tot_f += fl[name]
-            tot_ms += ms
-            n += 1
+    names, alg_bytes = dominant_ops(eng)
+    tot_f = sum(fl[n] for n in names)
+    tot_ms = sum(per_op_ms[n] for n in names)
+    n = len(names)
     ach = tot_f / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
     big = per_op_ms.get("conv_fwd:s0.up")
-    return {"bound": "mfma", "kernel": "conv_igemm_kernel<3,1,32,128> (3x3 s1 fwd + 3x3 dgrad, all scales)",
+    # every MFMA conv launch (forward, data and weight gradient, all kernels) for the whole-path figure
+    all_f = sum(f for k, f in fl.items() if k in per_op_ms)
+    all_ms = sum(ms for k, ms in per_op_ms.items() if k in fl)
+    pmc = pmc_traffic()
+    return {"bound": "mfma", "kernel": DOMINANT + " (3x3 stride-1 forward + 3x3 data-gradient launches)",
             "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+            "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+            "traffic": pmc["traffic_bytes_per_launch"] if pmc else None,
             "launches_per_step": n, "avg_launch_us": round(1e3 * tot_ms / max(n, 1), 1),
-            "algorithmic_gflop_per_step": round(tot_f / 1e9, 2),
+            "algorithmic_gflop_per_launch": round(tot_f / 1e9 / max(n, 1), 2),
+            "algorithmic_bytes_per_launch": round(alg_bytes / max(n, 1)),
+            "measured_mfma_ceiling_tflops": 151.9,      # tools/ubench/mfma_peak.hip on this chip (2 waves/SIMD)
             "largest_layer": {"name": "3.1 (132->128 3x3 @512^2) forward", "gflop": round(fl["conv_fwd:s0.up"] / 1e9, 2),
                               "us": round(1e3 * big, 1) if big else None,
-                              "tflops": round(fl["conv_fwd:s0.up"] / (big * 1e-3) / 1e12, 2) if big else None}}
+                              "tflops": round(fl["conv_fwd:s0.up"] / (big * 1e-3) / 1e12, 2) if big else None},
+            "all_conv_launches": {"gflop_per_step": round(all_f / 1e9, 1), "ms_per_step_serial": round(all_ms, 3),
+                                  "tflops": round(all_f / (all_ms * 1e-3) / 1e12, 2) if all_ms > 0 else None}}
 
 
 def cpu_baseline(seed=0, budget_s=25.0):

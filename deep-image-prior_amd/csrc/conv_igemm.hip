@@ -498,6 +498,18 @@ extern "C" int dip_conv_plan(int Hout, int Wout, int Cin, int Cout, int ks, int 
 extern "C" int dip_conv_dma_eligible(const DipConvDesc* dp);
 extern "C" int dip_conv_igemm_dma(const DipConvDesc* dp, int ksplit, void* stream);
 
+extern "C" int dip_conv_variant(const DipConvDesc* dp) {
+    const DipConvDesc& d = *dp;
+    static const bool no_dma = getenv("DIP_CONV_NO_DMA") != nullptr;      // A/B switches for profiling
+    static const bool no_extra = getenv("DIP_CONV_NO_EXTRA") != nullptr;
+    const int CoutP = dip_round_up(d.Cout, 32);
+    // N = 160 (132 real channels): one pass with a fifth 32-column block spread over the four waves
+    // beats a 128-column plus a 32-column launch of the DMA kernel (measured equal end to end)
+    if (!no_extra && d.ks == 3 && d.stride == 1 && CoutP == 160 && d.stats == nullptr && (d.Cin % 32) == 0) return 2;
+    if (!no_dma && dip_conv_dma_eligible(dp)) return 1;
+    return 0;
+}
+
 extern "C" int dip_conv_igemm(const DipConvDesc* dp, void* stream) {
     const DipConvDesc& d = *dp;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -511,10 +523,7 @@ extern "C" int dip_conv_igemm(const DipConvDesc* dp, void* stream) {
         if (ksplit > units) DIP_FAIL("conv_igemm: ksplit exceeds the number of K units");
     }
     int rc;
-    static const bool no_dma = getenv("DIP_CONV_NO_DMA") != nullptr;      // A/B switch for profiling
-    const int CoutP_ = dip_round_up(d.Cout, 32);
-    const bool extra_case = d.ks == 3 && d.stride == 1 && CoutP_ == 160 && d.stats == nullptr && (d.Cin % 32) == 0;
-    if (!no_dma && !extra_case && dip_conv_dma_eligible(dp)) rc = dip_conv_igemm_dma(dp, ksplit, stream);
+    if (dip_conv_variant(dp) == 1) rc = dip_conv_igemm_dma(dp, ksplit, stream);
     else if (d.ks == 1 && d.stride == 1) rc = launch_bn<1, 1, 32>(d, st, ksplit, d.ws);
     else if (d.ks == 3 && d.stride == 1) rc = launch_bn<3, 1, 32>(d, st, ksplit, d.ws);
     else if (d.ks == 3 && d.stride == 2) rc = launch_bn<3, 2, 16>(d, st, ksplit, d.ws);

@@ -68,6 +68,7 @@ _SIGS = {
     "dip_pack_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "dip_conv_igemm": (C.c_int, [C.POINTER(DipConvDesc), C.c_void_p]),
     "dip_conv_ntiles": (C.c_int, [C.c_int, C.c_int]),
+    "dip_conv_variant": (C.c_int, [C.POINTER(DipConvDesc)]),
     "dip_conv_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
                                 C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "dip_conv_wgrad": (C.c_int, [C.POINTER(DipWgradDesc), C.c_void_p]),

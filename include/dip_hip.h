@@ -110,6 +110,11 @@ int dip_conv_ntiles(int Hout, int Wout);
  * split-K workspace size in floats (0 when *ksplit == 1) */
 int dip_conv_plan(int Hout, int Wout, int Cin, int Cout, int ks, int stride, int* ksplit, int* stats_rows,
                   int64_t* ws_floats);
+/* which kernel dip_conv_igemm launches for `d` (diagnostic; bench.py attributes its HIP-event times
+ * with it): 0 = conv_igemm_kernel (operands staged through registers: stride 2, 5x5),
+ * 1 = conv_igemm_dma_kernel (LDS-DMA staging: stride-1 1x1 / 3x3), 2 = conv_igemm_kernel N=160 variant
+ * (3x3 data gradients towards a 132-channel tensor) */
+int dip_conv_variant(const DipConvDesc* d);
 
 /* Weight gradient (autograd ConvolutionBackward, weight + bias part):
  *   dW[o][c][tap] = sum_q dy[q][o] * u[src(q,tap)][c],  db[o] = sum_q dy[q][o]

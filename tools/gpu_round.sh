@@ -26,4 +26,12 @@ if [ "${DO_PROF:-0}" = "1" ]; then
   ( cd /tmp && TMO=900 run rocprofv3 --kernel-trace --stats -d $ROOTD/gpurun_out/prof1 -o trace -- env DIP_TWO_STREAMS=0 python $ROOTD/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline )
   ( cd /tmp && TMO=900 run rocprofv3 --kernel-trace --stats -d $ROOTD/gpurun_out/prof2 -o trace -- python $ROOTD/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline )
 fi
+if [ "${DO_PMC:-0}" = "1" ]; then
+  # counters in their own passes (no trace domains besides --kernel-trace); the library is preloaded
+  # because rocprofv3's counter service crashes on code objects that are dlopen()ed after start-up
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    ( cd /tmp && TMO=600 run rocprofv3 --kernel-trace --pmc $ctr -d $ROOTD/gpurun_out/pmc_$ctr -o pmc -- env LD_PRELOAD=$ROOTD/deep-image-prior_amd/lib/libdip_hip.so python $ROOTD/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline )
+  done
+  python tools/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE > gpurun_out/pmc_traffic.json 2>> $LOG
+fi
 grep -E "passed|failed|error|rc=" $LOG | tail -40
