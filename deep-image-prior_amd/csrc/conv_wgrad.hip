@@ -12,8 +12,13 @@
 // Each workgroup finally writes ONE partial slab; dip_wgrad_reduce sums the slabs in a fixed
 // order (deterministic, no float atomics) straight into the OIHW gradient arena.
 #include "dip_common.h"
+#include <stdlib.h>
 
 namespace {
+
+// marks halo entries outside the image while they wait in registers: they must become 0, not
+// act(b), when the producer transform is applied on the way to LDS
+constexpr float PADV = -3.0e38f;
 
 template <int KS, int S, int NT, int CB>
 struct WCfg {
@@ -74,10 +79,81 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d
         tb = *reinterpret_cast<const f32x4*>(d.tr.b + c0 + c4 * 4);
     }
 
-    for (int tile = split; tile < ntiles; tile += d.nsplit) {
+    // Per-lane A-operand offsets (floats, relative to the K step's pixel) of the active accumulators.
+    // Normal chunk: accumulator t = tap tap0+t, row = input channel l31.
+    // Ragged 4-channel tail chunk of a 3x3 conv (the skip branch of a 132-channel concat): rows are
+    // (tap, channel) pairs -- taps 0..7 in accumulator 0, tap 8 in rows 0..3 of accumulator 1 -- so the
+    // chunk costs 2 MFMAs per K step instead of 9 with 28 of 32 rows idle.
+    constexpr bool CAN_PACK = (KS == 3) && (NT == 9) && (CB == 1);
+    const bool pack = CAN_PACK && (d.Cin - c0 <= 4);
+    // accumulators 0 and 1 read through per-lane offsets so that the packed chunk shares the loop
+    int aoff0 = l31, aoff1 = C::CW + l31;                        // taps 0 and 1, row = channel l31
+    if (pack) {
+        const int ptap = l31 >> 2, pch = l31 & 3;
+        aoff0 = ((ptap / 3) * C::HTW + (ptap % 3)) * C::CW + pch;
+        aoff1 = (2 * C::HTW + 2) * C::CW + pch;
+    }
+
+    // Software pipeline over the pixel tiles: the global loads of tile t+1 are issued before the
+    // MFMAs of tile t and parked in registers (12 x 16 B per thread); they are written to LDS after
+    // the barrier that ends tile t's reads.  Without it a workgroup alternated between a load phase
+    // and an MFMA phase and only the co-resident workgroup could fill the gaps.
+    f32x4 ureg[C::U_SLOTS], dreg[8];
+    auto fetch = [&](int tile) {
         const int ty = tile / ntx, tx = tile - ty * ntx;
-        __syncthreads();
-        // ---- stage the input halo (32 channels) ----
+#pragma unroll
+        for (int i = 0; i < C::U_SLOTS; ++i) {
+            const int f = tid + i * 256;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (f < C::NPIX * (C::CW / 4)) {
+                const int hp = f / (C::CW / 4);
+                const int hr = hp / C::HTW, hc = hp - hr * C::HTW;
+                const int sr = wmap_src(ty * C::TH * S + hr - d.off, d.Hin, d.pad_mode);
+                const int sc = wmap_src(tx * C::TW * S + hc - d.off, d.Win, d.pad_mode);
+                if (sr >= 0 && sc >= 0 && cvalid)
+                    v = *reinterpret_cast<const f32x4*>(d.x + ((size_t)sr * d.Win + sc) * d.Cx + c0 + c4 * 4);
+                else
+                    v = f32x4{PADV, PADV, PADV, PADV};
+            }
+            ureg[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int f = tid + i * 256;           // float4 index: pixel = f >> 5, o4 = f & 31
+            const int px = f >> 5, o4 = f & 31;
+            const int oy = ty * C::TH + (px >> 4), ox = tx * C::TW + (px & 15);
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int o = o0 + o4 * 4;
+            if (oy < d.Hout && ox < d.Wout && o < d.Cdy)
+                v = *reinterpret_cast<const f32x4*>(d.dy + ((size_t)oy * d.Wout + ox) * d.Cdy + o);
+            dreg[i] = v;
+        }
+    };
+    auto commit = [&]() {                  // registers -> LDS, producer BatchNorm+LeakyReLU on the way
+#pragma unroll
+        for (int i = 0; i < C::U_SLOTS; ++i) {
+            const int f = tid + i * 256;
+            if (f < C::NPIX * (C::CW / 4)) {
+                f32x4 v = ureg[i];
+                if (has_tr) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (v[e] == PADV) ? 0.f : dip_act(fmaf(ta[e], v[e], tb[e]), slope);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (v[e] == PADV) ? 0.f : v[e];
+                }
+                *reinterpret_cast<f32x4*>(Us + f * 4) = v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(Ds + (tid + i * 256) * 4) = dreg[i];
+    };
+
+    // (the stride-2 and 5x5 halos are too large to park next to the accumulators without spilling:
+    // those variants stage global -> LDS directly, slot by slot)
+    constexpr bool PF = (KS <= 3) && (S == 1);
+    auto stage_direct = [&](int tile) {
+        const int ty = tile / ntx, tx = tile - ty * ntx;
 #pragma unroll
         for (int i = 0; i < C::U_SLOTS; ++i) {
             const int f = tid + i * 256;
@@ -97,10 +173,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d
                 *reinterpret_cast<f32x4*>(Us + f * 4) = v;
             }
         }
-        // ---- stage the dy tile: 64 pixels x 128 channels ----
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int f = tid + i * 256;           // float4 index: pixel = f >> 5, o4 = f & 31
+            const int f = tid + i * 256;
             const int px = f >> 5, o4 = f & 31;
             const int oy = ty * C::TH + (px >> 4), ox = tx * C::TW + (px & 15);
             f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -109,23 +184,49 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d
                 v = *reinterpret_cast<const f32x4*>(d.dy + ((size_t)oy * d.Wout + ox) * d.Cdy + o);
             *reinterpret_cast<f32x4*>(Ds + f * 4) = v;
         }
+    };
+    if (PF && split < ntiles) fetch(split);
+    for (int tile = split; tile < ntiles; tile += d.nsplit) {
+        __syncthreads();                   // every wave is done with the previous tile
+        if constexpr (PF) commit(); else stage_direct(tile);
         __syncthreads();
+        if (PF && tile + d.nsplit < ntiles) fetch(tile + d.nsplit);
         if (wave_active) {
-            for (int s = 0; s < C::NPX / 2; ++s) {
-                const int px = 2 * s + half;
-                const int r = px >> 4, c = px & 15;
-                const float b = Ds[px * 128 + wave * 32 + l31];
-                bsum += b;
-                const float* ub = Us + ((r * S) * C::HTW + c * S) * C::CW + l31;
+            if constexpr (CAN_PACK) {
+#pragma unroll 2
+                for (int s = 0; s < C::NPX / 2; ++s) {
+                    const int px = 2 * s + half;
+                    const int r = px >> 4, c = px & 15;
+                    const float b = Ds[px * 128 + wave * 32 + l31];
+                    bsum += b;
+                    const float* ub = Us + ((r * S) * C::HTW + c * S) * C::CW;
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ub[aoff0], b, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ub[aoff1], b, acc[1], 0, 0, 0);
+                    if (!pack) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const int tap = tap0 + t;
-                    if (tap < KS * KS) {
-                        const int ky = tap / KS, kx = tap - ky * KS;
+                        for (int t = 2; t < 9; ++t)
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ub[((t / 3) * C::HTW + (t % 3)) * C::CW + l31], b,
+                                                                          acc[t], 0, 0, 0);
+                    }
+                }
+            } else {
+#pragma unroll 2
+                for (int s = 0; s < C::NPX / 2; ++s) {
+                    const int px = 2 * s + half;
+                    const int r = px >> 4, c = px & 15;
+                    const float b = Ds[px * 128 + wave * 32 + l31];
+                    bsum += b;
+                    const float* ub = Us + ((r * S) * C::HTW + c * S) * C::CW + l31;
 #pragma unroll
-                        for (int cb = 0; cb < CB; ++cb) {
-                            const float a = ub[(ky * C::HTW + kx) * C::CW + cb * 32];
-                            acc[t * CB + cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t * CB + cb], 0, 0, 0);
+                    for (int t = 0; t < NT; ++t) {
+                        const int tap = tap0 + t;
+                        if (tap < KS * KS) {
+                            const int ky = tap / KS, kx = tap - ky * KS;
+#pragma unroll
+                            for (int cb = 0; cb < CB; ++cb) {
+                                const float a = ub[(ky * C::HTW + kx) * C::CW + cb * 32];
+                                acc[t * CB + cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t * CB + cb], 0, 0, 0);
+                            }
                         }
                     }
                 }
@@ -134,7 +235,24 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d
     }
 
     // ---- write this workgroup's partial slab ----
-    if (wave_active) {
+    if (pack) {
+      if (wave_active) {
+        const int o = o0 + wave * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * half;       // row = tap * 4 + channel
+            const int c = c0 + (m & 3);
+            if (c < CinP) {
+                d.partial[(((size_t)split * 9 + (m >> 2)) * CinP + c) * CoutP + o] = acc[0][r];
+                if (m < 4) d.partial[(((size_t)split * 9 + 8) * CinP + c) * CoutP + o] = acc[(NT * CB > 1) ? 1 : 0][r];
+            }
+        }
+        if (do_bias) {
+            const float tot = bsum + __shfl_xor(bsum, 32);
+            if (half == 0) d.bias_partial[(size_t)split * CoutP + o] = tot;
+        }
+      }
+    } else if (wave_active) {
         const int o = o0 + wave * 32 + l31;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -319,7 +437,11 @@ extern "C" int dip_wgrad_plan(int Hout, int Wout, int Cin, int Cout, int ks, int
     const int nt = dip_conv_wgrad_ntiles(Hout, Wout);
     const int cw = (ks == 1) ? 128 : 32;
     const int groups = (ks == 5) ? 5 : 1;
-    const int per_split = dip_cdiv(CinP, cw) * groups * dip_cdiv(CoutP, 128);
+    int chunks = dip_cdiv(CinP, cw);
+    // a ragged <= 4-channel tail of a 3x3 conv runs the packed variant (2 of 9 MFMAs): its
+    // workgroups are light, so fill the chip with the full chunks' workgroups
+    if (ks == 3 && chunks > 1 && Cin - (chunks - 1) * 32 <= 4) chunks -= 1;
+    const int per_split = chunks * groups * dip_cdiv(CoutP, 128);
     int n = 512 / per_split;
     if (n > nt / 4) n = nt / 4;        // >= 4 pixel tiles per workgroup: amortise its slab write + the reduce
     if (n < 1) n = 1;

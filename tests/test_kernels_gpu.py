@@ -56,6 +56,7 @@ CONV_CASES = [
     (48, 128, 3, 1, REFLECT, 8, 16, True),       # 32 + 16 chunks
     (72, 64, 3, 1, REFLECT, 8, 16, True),        # 32 + merged 40
     (64, 160, 3, 1, REFLECT, 8, 16, False),      # N = 128 + 32 split launch
+    (36, 64, 3, 2, ZERO, 16, 32, True),          # 32 + 4-channel tail, stride 2 (packed weight-gradient chunk)
 ]
 
 
