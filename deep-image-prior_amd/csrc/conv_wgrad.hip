@@ -376,7 +376,7 @@ int thin_ppb(int npix, int Cin, int* nblk) {
     const int nc4 = (Cin + 3) / 4;
     int rpi = 256 / nc4;
     if (rpi < 1) rpi = 1;
-    int ppb = dip_cdiv(npix, 1024);
+    int ppb = dip_cdiv(npix, 512);      // <= 512 slabs: the slab reduction reads nblk x CinP x CoutP floats
     if (ppb < rpi * 8) ppb = rpi * 8;
     *nblk = dip_cdiv(npix, ppb);
     return ppb;

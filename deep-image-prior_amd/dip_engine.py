@@ -236,6 +236,7 @@ class SkipEngine:
                 "models/common.py:29-37 of the reference, is not implemented)")
         self.H, self.W, self.Cimg = H, W, Cin_img
         self.stat_need = self.wg_need = self.wgb_need = self.bwdp_need = self.ws_need = 4
+        self.stat2_need = self.ws2_need = 4            # scratch of the skip-branch convs (side stream)
         self._alloc = []
         oc = self.out_conv
         self.n_out = oc.Cout
@@ -250,6 +251,8 @@ class SkipEngine:
                 self.wg_scratch = self._new(self.wg_need)
                 self.wgb_scratch = self._new(self.wgb_need)
                 self.ws_scratch = self._new(self.ws_need)
+                self.stats_scratch2 = self._new(self.stat2_need)
+                self.ws_scratch2 = self._new(self.ws2_need)
             self.x_nhwc = self._buf(H * W * round_up(Cin_img, 4))
             xin = Act(self.x_nhwc, H, W, Cin_img)
             last = self._plan_scale(0, xin, H, W)
@@ -314,23 +317,33 @@ class SkipEngine:
         Ho = (x.H + 2 * r.P - r.ks) // r.stride + 1
         Wo = (x.W + 2 * r.P - r.ks) // r.stride + 1
         ksplit, ntiles, wsf = N.conv_plan(Ho, Wo, round_up(x.C, 4), r.Cout, r.ks, r.stride)
+        # the skip-branch convs run on the side stream next to the encoder convs of their scale
+        # (_run_two_streams), so they get scratch of their own
+        side = r.name.endswith("skip_conv")
         if self._sizing:
-            if bn is not None:
-                self.stat_need = max(self.stat_need, ntiles * 3 * round_up(r.Cout, 32))
-            self.ws_need = max(self.ws_need, wsf)
+            if side:
+                if bn is not None:
+                    self.stat2_need = max(self.stat2_need, ntiles * 3 * round_up(r.Cout, 32))
+                self.ws2_need = max(self.ws2_need, wsf)
+            else:
+                if bn is not None:
+                    self.stat_need = max(self.stat_need, ntiles * 3 * round_up(r.Cout, 32))
+                self.ws_need = max(self.ws_need, wsf)
             return
+        stats_scratch = self.stats_scratch2 if side else self.stats_scratch
+        ws_scratch = self.ws_scratch2 if side else self.ws_scratch
         Cy = round_up(r.Cout, 4)
         d = N.DipConvDesc(_ptr(x.buf), x.H, x.W, x.Cs, round_up(x.C, 4), x.transform(),
                           _ptr(self.packed, r.fwd_off), _ptr(self.params, r.b_off) if r.b_off >= 0 else None,
                           _ptr(y), Ho, Wo, Cy, r.Cout, 0, r.ks, r.stride, r.pad_mode, r.P, 1, 0,
-                          _ptr(self.stats_scratch) if bn is not None else None,
-                          ksplit, _ptr(self.ws_scratch) if ksplit > 1 else None)
+                          _ptr(stats_scratch) if bn is not None else None,
+                          ksplit, _ptr(ws_scratch) if ksplit > 1 else None)
         self.keep.append(d)
         lib = self.lib
         self.fwd_ops.append((lib.dip_conv_igemm, (C.byref(d),), "conv_fwd:" + r.name))
         if bn is not None:
             m = bn.module
-            args = (_ptr(self.stats_scratch), ntiles, round_up(r.Cout, 32), bn.C, _ptr(self.params, bn.gamma_off),
+            args = (_ptr(stats_scratch), ntiles, round_up(r.Cout, 32), bn.C, _ptr(self.params, bn.gamma_off),
                     _ptr(self.params, bn.beta_off), float(m.eps), float(m.momentum if m.momentum is not None else 0.1),
                     _ptr(bn.state), bn.Cs,
                     _ptr(self.bnbuf, bn.rm_off) if bn.rm_off >= 0 else None,
@@ -514,35 +527,60 @@ class SkipEngine:
             if rc:
                 check(rc, name)
 
-    def _run_backward_two_streams(self, ops, main):
-        """Backward launch list on two HIP streams: the weight-gradient kernels (+ their slab
-        reductions) of a layer depend only on that layer's dy and the stored activations, not on the
-        data-gradient / BatchNorm-backward chain that continues to the next layer.  They go to a
-        side stream (fork: event after the op that produced dy; join: one event at the end), so the
-        partial last round of workgroups of one kernel overlaps with the other stream's work
-        instead of idling CUs.  Slab scratch is only ever touched by the side stream."""
+    def _run_two_streams(self, ops, main, on_side_fn, join_before_fn, key):
+        """Launch list on two HIP streams.
+        Backward: the weight-gradient kernels (+ their slab reductions) of a layer depend only on that
+        layer's dy and the stored activations, not on the data-gradient / BatchNorm-backward chain
+        that continues to the next layer.  Forward: the 1x1 skip-branch conv (+ its BatchNorm
+        finalisation) of a scale depends only on the scale's input and is needed again at the
+        scale's concat, so it runs next to the encoder convs (scratch of its own).
+        Fork: an event on the main stream in front of a run of side ops; join: main waits for the
+        side stream in front of every op `join_before_fn` selects and at the end.  The side work
+        fills the partially occupied last round of workgroups / the latency-bound low-resolution
+        kernels of the main stream instead of idling CUs."""
         if self._side is None or self._side.device != self.device:
             self._side = torch.cuda.Stream(self.device)
-            self._fork_events = {}
-            self._join_event = torch.cuda.Event()
+            self._events = {}
         side = self._side
         mptr, sptr = main.cuda_stream, side.cuda_stream
         check = N.check
+        events = self._events
+
+        def event(tag):
+            ev = events.get(tag)
+            if ev is None:
+                ev = events[tag] = torch.cuda.Event()
+            return ev
+
         prev_side = False
+        pending = False                       # side work the main stream has not joined yet
         for k, (fn, args, name) in enumerate(ops):
-            on_side = name.startswith(("wgrad:", "wgred:"))
+            on_side = on_side_fn(name)
             if on_side and not prev_side:
-                ev = self._fork_events.get(k)
-                if ev is None:
-                    ev = self._fork_events[k] = torch.cuda.Event()
+                ev = event((key, "fork", k))
                 ev.record(main)
                 side.wait_event(ev)
+            if not on_side and pending and join_before_fn(name):
+                ev = event((key, "join", k))
+                ev.record(side)
+                main.wait_event(ev)
+                pending = False
             rc = fn(*args, sptr if on_side else mptr)
             if rc:
                 check(rc, name)
+            pending = pending or on_side
             prev_side = on_side
-        self._join_event.record(side)
-        main.wait_event(self._join_event)
+        if pending:
+            ev = event((key, "join", -1))
+            ev.record(side)
+            main.wait_event(ev)
+
+    def _run_backward_two_streams(self, ops, main):
+        self._run_two_streams(ops, main, lambda n: n.startswith(("wgrad:", "wgred:")), lambda n: False, "bwd")
+
+    def _run_forward_two_streams(self, ops, main):
+        self._run_two_streams(ops, main, lambda n: n.endswith((".skip_conv", ".skip_bn")),
+                              lambda n: n.startswith("upcat:"), "fwd")
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if x.dim() != 4 or x.shape[0] != 1:
@@ -570,7 +608,10 @@ class SkipEngine:
                                      self.pack_max, stream), "pack_weights")
         N.check(lib.dip_nchw_to_nhwc(xs.data_ptr(), _ptr(self.x_nhwc), Cimg, H * W, round_up(Cimg, 4), stream),
                 "nchw_to_nhwc")
-        self._run(self.fwd_ops, stream)
+        if self.two_streams:
+            self._run_forward_two_streams(self.fwd_ops, torch.cuda.current_stream(dev))
+        else:
+            self._run(self.fwd_ops, stream)
         out = torch.empty((1, self.n_out, H, W), dtype=torch.float32, device=dev)
         N.check(lib.dip_head_fwd(_ptr(self.y_out), out.data_ptr(), self.n_out, H * W, round_up(self.n_out, 4),
                                  1 if self.need_sigmoid else 0, stream), "head_fwd")
