@@ -14,8 +14,13 @@ for n, c, s, a, mi, ma in rows:
     print(f"{n[:78]:78s} {c:6d} {c/steps:10.1f} {s/1e3:9.2f} {s/steps/1e3:8.3f} {a:9.1f} {mi:8.1f} {ma:9.1f} {100*s/tot:6.2f}")
 print()
 print("# per launch geometry of the MFMA kernels (grid in workgroups)")
-for pat in ("conv_igemm_kernel", "conv_wgrad_kernel"):
+for pat in ("conv_igemm_dma_kernel", "conv_igemm_kernel", "conv_wgrad_kernel"):
     for r in cur.execute("select name, grid_x/workgroup_x, grid_y, grid_z, count(*), avg(end-start)/1e3, min(end-start)/1e3, max(end-start)/1e3 "
                          "from kernels where name like ? group by 1,2,3,4 order by 6 desc", ("%" + pat + "%",)):
         n = re.sub(r"\(anonymous namespace\)::|\(Dip.*", "", r[0]).replace("void ", "")
         print(f"{n:44s} grid=({r[1]},{r[2]},{r[3]}) n={r[4]:4d} avg={r[5]:9.1f}us min={r[6]:8.1f} max={r[7]:9.1f}")
+
+print()
+print("# dominant kernel of bench.py's roofline object: conv_igemm_dma_kernel<3, 128, *> (both transform variants)")
+r = cur.execute("select count(*), sum(end-start)/1e3, avg(end-start)/1e3 from kernels where name like '%conv_igemm_dma_kernel<3, 128,%'").fetchone()
+print(f"launches={r[0]} ({r[0]/steps:.1f}/step)  total={r[1]/1e3:.2f} ms ({r[1]/steps/1e3:.3f} ms/step)  avg launch={r[2]:.1f} us")
