@@ -497,14 +497,21 @@ extern "C" int dip_conv_plan(int Hout, int Wout, int Cin, int Cout, int ks, int 
 
 extern "C" int dip_conv_dma_eligible(const DipConvDesc* dp);
 extern "C" int dip_conv_igemm_dma(const DipConvDesc* dp, int ksplit, void* stream);
+extern "C" int dip_conv_igemm_dma_cols(const DipConvDesc* dp, int n_base, void* stream);
+extern "C" int dip_conv_thin4(const DipConvDesc* dp, int ncols, void* stream);
 
 extern "C" int dip_conv_variant(const DipConvDesc* dp) {
     const DipConvDesc& d = *dp;
     static const bool no_dma = getenv("DIP_CONV_NO_DMA") != nullptr;      // A/B switches for profiling
     static const bool no_extra = getenv("DIP_CONV_NO_EXTRA") != nullptr;
     const int CoutP = dip_round_up(d.Cout, 32);
-    // N = 160 (132 real channels): one pass with a fifth 32-column block spread over the four waves
-    // beats a 128-column plus a 32-column launch of the DMA kernel (measured equal end to end)
+    static const bool no_thin4 = getenv("DIP_CONV_NO_THIN4") != nullptr;
+    // 129..132 output channels (the data gradient towards [4 skip | 128 up-sampled] channels): the
+    // 1..4 leading columns on the vector ALU (conv_thin4.hip), the other 128 on the DMA kernel
+    if (!no_thin4 && !no_dma && d.ks == 3 && d.stride == 1 && d.dil == 1 && d.Cout > 128 && d.Cout <= 132 &&
+        d.stats == nullptr && d.tr.a == nullptr && d.ksplit <= 1 && dip_conv_dma_eligible(dp))
+        return 3;
+    // otherwise N = 160 in one pass: a fifth 32-column block spread over the four waves
     if (!no_extra && d.ks == 3 && d.stride == 1 && CoutP == 160 && d.stats == nullptr && (d.Cin % 32) == 0) return 2;
     if (!no_dma && dip_conv_dma_eligible(dp)) return 1;
     return 0;
@@ -523,7 +530,14 @@ extern "C" int dip_conv_igemm(const DipConvDesc* dp, void* stream) {
         if (ksplit > units) DIP_FAIL("conv_igemm: ksplit exceeds the number of K units");
     }
     int rc;
-    if (dip_conv_variant(dp) == 1) rc = dip_conv_igemm_dma(dp, ksplit, stream);
+    const int variant = dip_conv_variant(dp);
+    if (variant == 3) {
+        const int ncols = d.Cout - 128;
+        rc = dip_conv_thin4(dp, ncols, stream);
+        if (rc) return rc;
+        return dip_conv_igemm_dma_cols(dp, ncols, stream);
+    }
+    if (variant == 1) rc = dip_conv_igemm_dma(dp, ksplit, stream);
     else if (d.ks == 1 && d.stride == 1) rc = launch_bn<1, 1, 32>(d, st, ksplit, d.ws);
     else if (d.ks == 3 && d.stride == 1) rc = launch_bn<3, 1, 32>(d, st, ksplit, d.ws);
     else if (d.ks == 3 && d.stride == 2) rc = launch_bn<3, 2, 16>(d, st, ksplit, d.ws);

@@ -619,6 +619,13 @@ extern "C" int dip_debug_prof_read(void* dst, int nwg) {
 }
 #endif
 
+// one 128-column block starting at column n_base (3x3 only): the 132-column data gradients run as
+// conv_thin4 (columns 0..3) + this (columns 4..131)
+extern "C" int dip_conv_igemm_dma_cols(const DipConvDesc* dp, int n_base, void* stream) {
+    if (dp->ks != 3) DIP_FAIL("conv_igemm_dma_cols: 3x3 only");
+    return launch<3, 128>(*dp, reinterpret_cast<hipStream_t>(stream), n_base, 1, 1, nullptr);
+}
+
 extern "C" int dip_conv_igemm_dma(const DipConvDesc* dp, int ksplit, void* stream) {
     const DipConvDesc& d = *dp;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

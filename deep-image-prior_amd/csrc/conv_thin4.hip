@@ -1,0 +1,115 @@
+// 3x3 stride-1 convolution towards <= 4 output channels (vector ALU, LDS-staged halo).
+//
+// Where it is used: the data gradient of the decoder convs flows into a 132-channel concat tensor
+// = 4 skip channels + 128 up-sampled channels (reference models/skip.py:50-53, models/common.py:39).
+// On the matrix core the 4 skip columns cost a whole 32-column block (the N = 160 variant of
+// conv_igemm_kernel, or a 32-column launch with 28 idle columns); here they cost
+// 2*9*Cin*4 FLOP per pixel on the VALU (2.4 GFLOP at 512x512, Cin = 128) and the other 128 columns
+// go through conv_igemm_dma_kernel at its full rate.
+//
+//   y[p][n] = bias[n] + sum_tap sum_c x[src(p, tap)][c] * Wp[(tap*Cin/4 + c/4)*CoutP + n][c%4],  n < 4
+//
+// One thread = one output pixel of a 16x16 tile, 4 accumulators.  The 18x18-pixel halo of a
+// 32-channel chunk is staged in LDS (pixel pitch 36 dwords: the 16 lanes of a ds_read_b128 pass
+// fall on 16 distinct 16-byte slots); the weights of a (tap, 4-channel group) are 16 consecutive
+// floats of the packed B operand and are read through the scalar cache (wave-uniform address).
+#include "dip_common.h"
+
+namespace {
+
+constexpr int T4_TH = 16, T4_TW = 16, T4_HH = T4_TH + 2, T4_HW = T4_TW + 2, T4_NPIX = T4_HH * T4_HW;
+constexpr int T4_PITCH = 36;                                   // dwords per halo pixel (32 channels + 4 pad)
+constexpr int T4_SLOTS = (T4_NPIX * 8 + 255) / 256;            // 16-byte pieces per thread and chunk
+
+__device__ __forceinline__ int t4_map_src(int v, int n_in, int reflect) {
+    if (reflect) v = dip_reflect(v, n_in);
+    return (v < 0 || v >= n_in) ? -1 : v;
+}
+
+__global__ __launch_bounds__(256) void conv_thin4_kernel(const DipConvDesc d, const int ntx, const int CoutP,
+                                                        const int ncols) {
+    __shared__ __attribute__((aligned(16))) float halo[T4_NPIX * T4_PITCH];
+    __shared__ int srcoff[T4_NPIX];
+    const int tid = threadIdx.x;
+    const int ty = blockIdx.x / ntx, tx = blockIdx.x - ty * ntx;
+    for (int hp = tid; hp < T4_NPIX; hp += 256) {
+        const int hr = hp / T4_HW, hc = hp - hr * T4_HW;
+        const int sr = t4_map_src(ty * T4_TH + hr - d.off, d.Hin, d.pad_mode);
+        const int sc = t4_map_src(tx * T4_TW + hc - d.off, d.Win, d.pad_mode);
+        srcoff[hp] = (sr < 0 || sc < 0) ? -1 : (sr * d.Win + sc);
+    }
+    __syncthreads();
+    int soff[T4_SLOTS];                     // this thread's staging pieces: source float offset or -1
+#pragma unroll
+    for (int i = 0; i < T4_SLOTS; ++i) {
+        const int f = tid + i * 256;
+        const int hp = f >> 3;
+        const int so = (hp < T4_NPIX) ? srcoff[hp] : -2;
+        soff[i] = so >= 0 ? so * d.Cx + (f & 7) * 4 : so;
+    }
+    const int py = tid >> 4, px = tid & 15;
+    const float* hbase = halo + (py * T4_HW + px) * T4_PITCH;
+    const int cin4 = d.Cin >> 2;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int cb = 0; cb < d.Cin; cb += 32) {
+        const int c4n = min(8, (d.Cin - cb) >> 2);          // 4-channel groups in this chunk
+        f32x4 st[T4_SLOTS];
+#pragma unroll
+        for (int i = 0; i < T4_SLOTS; ++i) {
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (soff[i] >= 0 && ((tid + i * 256) & 7) < c4n) v = *reinterpret_cast<const f32x4*>(d.x + soff[i] + cb);
+            st[i] = v;
+        }
+        __syncthreads();                    // previous chunk's reads are done
+#pragma unroll
+        for (int i = 0; i < T4_SLOTS; ++i) {
+            const int f = tid + i * 256;
+            if (soff[i] != -2) *reinterpret_cast<f32x4*>(halo + (f >> 3) * T4_PITCH + (f & 7) * 4) = st[i];
+        }
+        __syncthreads();
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const float* hp = hbase + (ky * T4_HW + kx) * T4_PITCH;
+            const float* wt = d.wp + ((size_t)(tap * cin4 + (cb >> 2)) * CoutP) * 4;     // wave-uniform
+            for (int c4 = 0; c4 < c4n; ++c4) {
+                const f32x4 g = *reinterpret_cast<const f32x4*>(hp + c4 * 4);
+                const float* w = wt + (size_t)c4 * CoutP * 4;                             // [n][c%4], n = 0..3
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[n] = fmaf(g[e], w[n * 4 + e], acc[n]);
+            }
+        }
+    }
+    const int oy = ty * T4_TH + py, ox = tx * T4_TW + px;
+    if (oy < d.Hout && ox < d.Wout) {
+        const int pitch = d.y_pitch > 0 ? d.y_pitch : d.Wout;
+        float* p = d.y + ((size_t)oy * pitch + ox) * d.Cy;
+        if (d.bias != nullptr) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                if (n < ncols) acc[n] += d.bias[n];
+        }
+        if (ncols == 4) {
+            if (d.accumulate) acc += *reinterpret_cast<const f32x4*>(p);
+            *reinterpret_cast<f32x4*>(p) = acc;
+        } else {
+            for (int n = 0; n < ncols; ++n) p[n] = d.accumulate ? p[n] + acc[n] : acc[n];
+        }
+    }
+}
+
+}  // namespace
+
+// columns [0, ncols) (ncols <= 4) of a 3x3 stride-1, undilated, transform-free convolution
+extern "C" int dip_conv_thin4(const DipConvDesc* dp, int ncols, void* stream) {
+    const DipConvDesc& d = *dp;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (d.ks != 3 || d.stride != 1 || d.dil != 1 || d.tr.a != nullptr || ncols < 1 || ncols > 4 || (d.Cin & 3))
+        DIP_FAIL("conv_thin4: unsupported configuration");
+    const int ntx = dip_cdiv(d.Wout, T4_TW), nty = dip_cdiv(d.Hout, T4_TH);
+    hipLaunchKernelGGL(conv_thin4_kernel, dim3(ntx * nty), dim3(256), 0, st, d, ntx, dip_round_up(d.Cout, 32), ncols);
+    DIP_CHECK_LAUNCH();
+    return 0;
+}

@@ -113,7 +113,8 @@ int dip_conv_plan(int Hout, int Wout, int Cin, int Cout, int ks, int stride, int
 /* which kernel dip_conv_igemm launches for `d` (diagnostic; bench.py attributes its HIP-event times
  * with it): 0 = conv_igemm_kernel (operands staged through registers: stride 2, 5x5),
  * 1 = conv_igemm_dma_kernel (LDS-DMA staging: stride-1 1x1 / 3x3), 2 = conv_igemm_kernel N=160 variant
- * (3x3 data gradients towards a 132-channel tensor) */
+ * (3x3, 129..160 output channels, split-K), 3 = conv_thin4_kernel (columns 0..Cout-129 on the vector ALU)
+ * + conv_igemm_dma_kernel (the other 128 columns): 3x3 data gradients towards a 132-channel tensor */
 int dip_conv_variant(const DipConvDesc* d);
 
 /* Weight gradient (autograd ConvolutionBackward, weight + bias part):
