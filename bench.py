@@ -120,6 +120,11 @@ def conv_flops(eng):
 def profile_ops(eng, reps=3):
     """HIP-event time of every launch of one iteration, in sequence on the engine's own stream
     (torch's current stream), averaged over `reps` instrumented iterations."""
+    import ctypes as C
+    import dip_native as N
+    lib = N.lib()
+    for f in (lib.dip_conv_thin4, lib.dip_conv_igemm_dma_cols):      # internal entry points of the dispatcher
+        f.restype, f.argtypes = C.c_int, [C.POINTER(N.DipConvDesc), C.c_int, C.c_void_p]
     stream = torch.cuda.current_stream(eng.device)
     sptr = stream.cuda_stream
     acc = {}
@@ -127,12 +132,24 @@ def profile_ops(eng, reps=3):
         for ops in (eng.fwd_ops, eng.bwd_ops):
             evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(ops) + 1)]
             evs[0].record(stream)
+            mids = {}
             for k, (fn, args, name) in enumerate(ops):
-                fn(*args, sptr)
+                if fn is lib.dip_conv_igemm and lib.dip_conv_variant(args[0]) == 3:
+                    # 132-column data gradient = conv_thin4 + a 128-column launch of the dominant kernel
+                    ncols = args[0]._obj.Cout - 128
+                    lib.dip_conv_thin4(args[0], ncols, sptr)
+                    mids[k] = torch.cuda.Event(enable_timing=True)
+                    mids[k].record(stream)
+                    lib.dip_conv_igemm_dma_cols(args[0], ncols, sptr)
+                else:
+                    fn(*args, sptr)
                 evs[k + 1].record(stream)
             torch.cuda.synchronize()
             for k, (_, _, name) in enumerate(ops):
                 acc.setdefault(name, []).append(evs[k].elapsed_time(evs[k + 1]))
+                if k in mids:
+                    acc.setdefault(name + "#thin4", []).append(evs[k].elapsed_time(mids[k]))
+                    acc.setdefault(name + "#dma", []).append(mids[k].elapsed_time(evs[k + 1]))
     return {k: float(np.mean(v)) for k, v in acc.items()}
 
 
@@ -140,24 +157,31 @@ DOMINANT = "conv_igemm_dma_kernel<3,128,*>"
 
 
 def dominant_ops(eng):
-    """Names of the launch-list entries that run the dominant kernel: 3x3 convolutions (forward and
-    data gradient) that dip_conv_igemm dispatches to the LDS-DMA implicit-GEMM kernel, 128-column
-    tile (dip_conv_variant == 1).  The 132-channel data gradients (N = 160 variant of
-    conv_igemm_kernel) and the stride-2 forwards are other kernels and are not counted."""
+    """Launch-list entries that run the dominant kernel, as {timing key: (flops, compulsory bytes)}:
+    3x3 convolutions (forward and data gradient) that dip_conv_igemm dispatches to the LDS-DMA
+    implicit-GEMM kernel with a 128-column tile -- dip_conv_variant == 1, and the 128-column part
+    ("#dma", timed on its own by profile_ops) of the 132-column data gradients (variant 3).  The
+    N = 160 split-K variant of conv_igemm_kernel, the stride-2 forwards and conv_thin4 are other
+    kernels and are not counted."""
     import dip_native as N
     lib = N.lib()
-    names, nbytes = [], 0.0
+    out = {}
     for ops in (eng.fwd_ops, eng.bwd_ops):
         for fn, args, name in ops:
-            kind = name.partition(":")[0]
-            if kind not in ("conv_fwd", "dgrad", "dgrad+"):
+            if name.partition(":")[0] not in ("conv_fwd", "dgrad", "dgrad+"):
                 continue
             d = args[0]._obj
-            if d.ks == 3 and d.Cout >= 128 and lib.dip_conv_variant(args[0]) == 1:
-                names.append(name)
-                # compulsory traffic of the launch: input and packed weights read once, output written once
-                nbytes += 4.0 * (d.Hin * d.Win * d.Cin + 9 * d.Cin * d.Cout + d.Hout * d.Wout * d.Cout)
-    return names, nbytes
+            if d.ks != 3 or d.Cout < 128:
+                continue
+            v = lib.dip_conv_variant(args[0])
+            if v not in (1, 3):
+                continue
+            cols = d.Cout if v == 1 else 128
+            flops = 2.0 * cols * d.Hout * d.Wout * d.Cin * 9
+            # compulsory traffic of the launch: input and packed weights read once, output written once
+            nbytes = 4.0 * (d.Hin * d.Win * d.Cin + 9 * d.Cin * cols + d.Hout * d.Wout * cols)
+            out[name if v == 1 else name + "#dma"] = (flops, nbytes)
+    return out
 
 
 def pmc_traffic():
@@ -176,15 +200,16 @@ def roofline(eng, per_op_ms):
     dominant_ops).  achieved = their algorithmic FLOPs (2*Cout*Ho*Wo*Cin*9 per launch)
     / their HIP-event time on the engine's stream."""
     fl = conv_flops(eng)
-    names, alg_bytes = dominant_ops(eng)
-    tot_f = sum(fl[n] for n in names)
-    tot_ms = sum(per_op_ms[n] for n in names)
-    n = len(names)
+    dom = dominant_ops(eng)
+    tot_f = sum(f for f, _ in dom.values())
+    alg_bytes = sum(b for _, b in dom.values())
+    tot_ms = sum(per_op_ms[k] for k in dom)
+    n = len(dom)
     ach = tot_f / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
     big = per_op_ms.get("conv_fwd:s0.up")
     # every MFMA conv launch (forward, data and weight gradient, all kernels) for the whole-path figure
     all_f = sum(f for k, f in fl.items() if k in per_op_ms)
-    all_ms = sum(ms for k, ms in per_op_ms.items() if k in fl)
+    all_ms = sum(ms for k, ms in per_op_ms.items() if k in fl)          # ("#thin4"/"#dma" parts are not in fl)
     pmc = pmc_traffic()
     return {"bound": "mfma", "kernel": DOMINANT + " (3x3 stride-1 forward + 3x3 data-gradient launches)",
             "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",

@@ -95,6 +95,10 @@ _SIGS = {
     "dip_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double,
                                 C.c_double, C.c_double, C.c_int, C.c_void_p]),
     "dip_noise_axpy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "dip_fit_monitor_nblk": (C.c_int, [C.c_int64]),
+    "dip_fit_monitor": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_int,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]),
+    "dip_arena_backtrack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "dip_lanczos_down_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_int, C.c_int, C.c_void_p]),
     "dip_lanczos_down_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -210,6 +210,28 @@ int dip_adam_step(float* p, const float* g, float* m, float* v, int64_t n, doubl
 int dip_noise_axpy(const float* z, float* out, int64_t n, float sigma, uint64_t seed, uint64_t offset,
                    void* stream);
 
+/* ---------------------------------------------------------------- closure bookkeeping ---- */
+/* The per-iteration bookkeeping of the notebooks' closures without host round trips
+ * (denoising.ipynb:214-248): EMA of the output, PSNR against the noisy / clean image, and the
+ * "fall back to the last checkpoint if psrn_noisy dropped by more than 5 dB" rule.
+ *   out_avg <- first ? out : out_avg*exp_weight + out*(1-exp_weight)
+ *   record  <- {loss, mse_noisy, mse_gt, mse_gt_sm, psnr_noisy, psnr_gt, psnr_gt_sm, fell_back}
+ *              (psnr = -10 log10(mse), data range 1; the gt entries are 0 when gt == NULL;
+ *               `loss` is a device scalar or NULL)
+ *   state   =  {psnr_noisy_last, restore, have_last, snapshot}; zero it before the first call.
+ *              With check_backtrack != 0 (the notebook's `if i % show_every:`): restore = 1 when
+ *              psnr_noisy - psnr_noisy_last < -backtrack_db, otherwise snapshot = 1 and
+ *              psnr_noisy_last <- psnr_noisy.
+ * `partial` is scratch of 4*dip_fit_monitor_nblk(n) floats.  All tensors NCHW / flat, n elements. */
+int dip_fit_monitor_nblk(int64_t n);
+int dip_fit_monitor(const float* out, const float* noisy, const float* gt, float* out_avg, int64_t n,
+                    float exp_weight, int first, const float* loss, float* partial, float* record,
+                    float* state, int check_backtrack, float backtrack_db, void* stream);
+/* applies the decision in `state` to the flat parameter arena: restore -> params = snapshot,
+ * snapshot -> snapshot = params, neither -> nothing (the notebook's net_param.data.copy_(...) /
+ * last_net = [x.detach().cpu() ...], :242-247) */
+int dip_arena_backtrack(float* params, float* snapshot, int64_t n, const float* state, void* stream);
+
 /* ---------------------------------------------------------------- Lanczos down-sampler ---- */
 /* Downsampler.forward (models/downsampler.py:65-71): ReplicationPad2d(pad) + depth-wise
  * k x k stride-`factor` correlation with the fixed taps; NCHW [C][H][W] -> [C][H/f][W/f]. */

@@ -386,3 +386,38 @@ def psnr(a: np.ndarray, b: np.ndarray, data_range: float = 1.0) -> float:
     """skimage<=0.15 compare_psnr for non-negative float images, in float64."""
     mse = np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)
     return float("inf") if mse == 0 else 10.0 * math.log10(data_range ** 2 / mse)
+
+
+class ClosureBookkeeping:
+    """The host-side bookkeeping of the reference's denoising closure, restated line by line
+    (denoising.ipynb:214-248): EMA of the output (:214-217), the three PSNRs (:223-225) and the
+    back-tracking rule (:238-248; note `if i % show_every:` -- the check runs on every iteration
+    that is NOT a multiple of show_every).  `params` plays the role of net.parameters()."""
+
+    def __init__(self, img_noisy_np, img_np, exp_weight=0.99, show_every=100):
+        self.noisy, self.gt = img_noisy_np, img_np
+        self.exp_weight, self.show_every = exp_weight, show_every
+        self.out_avg = None
+        self.last_net = None
+        self.psrn_noisy_last = 0
+        self.i = 0
+
+    def step(self, out: torch.Tensor, params):
+        if self.out_avg is None:
+            self.out_avg = out.detach()
+        else:
+            self.out_avg = self.out_avg * self.exp_weight + out.detach() * (1 - self.exp_weight)
+        psrn_noisy = psnr(self.noisy, out.detach().cpu().numpy()[0])
+        psrn_gt = psnr(self.gt, out.detach().cpu().numpy()[0])
+        psrn_gt_sm = psnr(self.gt, self.out_avg.detach().cpu().numpy()[0])
+        fell_back = False
+        if self.i % self.show_every:
+            if psrn_noisy - self.psrn_noisy_last < -5:
+                for new_param, net_param in zip(self.last_net, params):
+                    net_param.data.copy_(new_param)
+                fell_back = True
+            else:
+                self.last_net = [x.detach().clone() for x in params]
+                self.psrn_noisy_last = psrn_noisy
+        self.i += 1
+        return {"psrn_noisy": psrn_noisy, "psrn_gt": psrn_gt, "psrn_gt_sm": psrn_gt_sm, "fell_back": fell_back}
