@@ -447,14 +447,16 @@ class SkipEngine:
         dz = self._new(a.H * a.W * a.Cs)
         src = self._gradsrc(g, Cg if Cg is not None else a.Cs, choff)
         lib = self.lib
+        # phase 1 only reduces (dz = NULL); phase 3 recomputes the masked gradient from the source:
+        # 5 tensor passes per BatchNorm instead of 6
         ops.append((lib.dip_bn_bwd_stats, (C.byref(src), _ptr(a.buf), a.H, a.W, a.Cs, a.C, _ptr(bn.state), bn.Cs,
-                                           float(a.slope), _ptr(dz), a.Cs, _ptr(self.bwd_scratch), nblk),
+                                           float(a.slope), None, a.Cs, _ptr(self.bwd_scratch), nblk),
                     "bnb_stats:" + bn.name))
         ops.append((lib.dip_bn_bwd_finalize, (_ptr(self.bwd_scratch), nblk, bn.Cs, bn.C, a.H * a.W,
                                               _ptr(self.grads, bn.gamma_off), _ptr(self.grads, bn.beta_off),
                                               _ptr(bn.coef)), "bnb_fin:" + bn.name))
-        ops.append((lib.dip_bn_bwd_apply, (_ptr(dz), a.Cs, _ptr(a.buf), a.Cs, a.H * a.W, a.C, _ptr(bn.state), bn.Cs,
-                                           _ptr(bn.coef)), "bnb_apply:" + bn.name))
+        ops.append((lib.dip_bn_bwd_apply_src, (C.byref(src), _ptr(a.buf), a.H, a.W, a.Cs, a.C, _ptr(bn.state), bn.Cs,
+                                               float(a.slope), _ptr(bn.coef), _ptr(dz), a.Cs), "bnb_apply:" + bn.name))
         return dz
 
     def _emit_up_bwd(self, deep: Act, dcat, Cs_cat, choff, H, W, mode, ops):

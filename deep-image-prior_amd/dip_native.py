@@ -86,6 +86,8 @@ _SIGS = {
                                       C.c_void_p, C.c_void_p]),
     "dip_bn_bwd_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                    C.c_void_p, C.c_void_p]),
+    "dip_bn_bwd_apply_src": (C.c_int, [C.POINTER(DipGradSrc), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "dip_fold_to_nchw": (C.c_int, [C.POINTER(DipGradSrc), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "dip_upcat_fwd": (C.c_int, [C.POINTER(DipUpcatDesc), C.c_void_p]),
     "dip_upcat_nblk": (C.c_int, [C.c_int, C.c_int, C.c_int]),

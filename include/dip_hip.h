@@ -159,9 +159,10 @@ typedef struct DipGradSrc {
     int32_t pad, fold, Cg, choff;
 } DipGradSrc;
 
-/* BatchNorm+LeakyReLU backward, phase 1:  dz = du * (a*y+b > 0 ? 1 : slope); writes dz and the
- * per-block partial sums {sum dz, sum dz*xhat}.  (autograd NativeBatchNormBackward +
- * LeakyReluBackward of models/common.py:82,96.) */
+/* BatchNorm+LeakyReLU backward, phase 1:  dz = du * (a*y+b > 0 ? 1 : slope); writes dz (unless
+ * dz == NULL: then phase 3 is dip_bn_bwd_apply_src, which recomputes it) and the per-block partial
+ * sums {sum dz, sum dz*xhat}.  (autograd NativeBatchNormBackward + LeakyReluBackward of
+ * models/common.py:82,96.) */
 int dip_bn_bwd_stats(const DipGradSrc* src, const float* y, int H, int W, int Cy, int C,
                      const float* state, int Cs, float slope, float* dz, int Cdz,
                      float* partials /*[nblk][2][Cs]*/, int nblk, void* stream);
@@ -172,6 +173,11 @@ int dip_bn_bwd_finalize(const float* partials, int nblk, int Cs, int C, int npix
 /* phase 3 (in place): dy = a * (dz - k1 - xhat*k2) */
 int dip_bn_bwd_apply(float* dz, int Cdz, const float* y, int Cy, int npix, int C, const float* state,
                      int Cs, const float* coef, void* stream);
+/* phase 3 straight from the gradient source (one tensor pass less than stats-with-dz + apply):
+ *   dy = a * (du * lrelu'(a*y+b) - k1 - xhat*k2) */
+int dip_bn_bwd_apply_src(const DipGradSrc* src, const float* y, int H, int W, int Cy, int C,
+                         const float* state, int Cs, float slope, const float* coef, float* dy, int Cdy,
+                         void* stream);
 /* Fold a (reflection-)padded gradient back onto the image and emit it NCHW: gradient wrt
  * `net_input` for get_params('net,input') (utils/common_utils.py:47-49). */
 int dip_fold_to_nchw(const DipGradSrc* src, int H, int W, int C, float* dst, void* stream);

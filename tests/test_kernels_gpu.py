@@ -216,6 +216,16 @@ def test_bn_forward_backward_chain(dev, Cc, Hh, Ww, P, slope):
     torch.cuda.synchronize()
     dy = H.from_nhwc(dz, Cc, Hh, Ww)
     _check("bn_bwd.dy", dy, r64[0], r32[0], floor=5e-6)
+    # the recomputing variant the engine uses: phase 1 without dz, phase 3 from the gradient source
+    part2 = torch.full((nblk * 2 * Cs,), float("nan"), device=dev)
+    N.check(lib.dip_bn_bwd_stats(C.byref(src), yb.data_ptr(), Hh, Ww, Cs, Cc, state.data_ptr(), Cs, slope,
+                                 None, Cs, part2.data_ptr(), nblk, st))
+    dy2 = torch.full((Hh * Ww * Cs,), float("nan"), device=dev)
+    N.check(lib.dip_bn_bwd_apply_src(C.byref(src), yb.data_ptr(), Hh, Ww, Cs, Cc, state.data_ptr(), Cs, slope,
+                                     coef.data_ptr(), dy2.data_ptr(), Cs, st))
+    torch.cuda.synchronize()
+    assert torch.equal(part2, part)
+    assert torch.equal(H.from_nhwc(dy2, Cc, Hh, Ww), dy)
     _check("bn_bwd.dgamma", dgam, r64[1], r32[1], floor=5e-6)
     _check("bn_bwd.dbeta", dbet, r64[2], r32[2], floor=5e-6)
 
