@@ -12,7 +12,9 @@
 // One thread = one output pixel of a 16x16 tile, 4 accumulators.  The 18x18-pixel halo of a
 // 32-channel chunk is staged in LDS (pixel pitch 36 dwords: the 16 lanes of a ds_read_b128 pass
 // fall on 16 distinct 16-byte slots); the weights of a (tap, 4-channel group) are 16 consecutive
-// floats of the packed B operand and are read through the scalar cache (wave-uniform address).
+// floats of the packed B operand; a chunk's 72 groups (4.6 KB) are staged in LDS next to the halo and
+// read as broadcasts (through the scalar cache they missed on every group: 18 KB per workgroup walk
+// thrashes it, 85 us per workgroup instead of ~25).
 #include "dip_common.h"
 
 namespace {
@@ -30,6 +32,7 @@ __global__ __launch_bounds__(256) void conv_thin4_kernel(const DipConvDesc d, co
                                                         const int ncols) {
     __shared__ __attribute__((aligned(16))) float halo[T4_NPIX * T4_PITCH];
     __shared__ int srcoff[T4_NPIX];
+    __shared__ __attribute__((aligned(16))) float wsh[9 * 8 * 16];           // [tap][c4][n][c%4] of the current chunk
     const int tid = threadIdx.x;
     const int ty = blockIdx.x / ntx, tx = blockIdx.x - ty * ntx;
     for (int hp = tid; hp < T4_NPIX; hp += 256) {
@@ -61,24 +64,40 @@ __global__ __launch_bounds__(256) void conv_thin4_kernel(const DipConvDesc d, co
             if (soff[i] >= 0 && ((tid + i * 256) & 7) < c4n) v = *reinterpret_cast<const f32x4*>(d.x + soff[i] + cb);
             st[i] = v;
         }
+        f32x4 wst[2];                       // this thread's pieces of the chunk's 288 weight quads
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = tid + i * 256;    // quad q = (tap*8 + c4)*4 + n
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (q < 288) {
+                const int grp = q >> 2, tap = grp >> 3, c4 = grp & 7;
+                if (c4 < c4n) v = *reinterpret_cast<const f32x4*>(d.wp + ((size_t)(tap * cin4 + (cb >> 2) + c4) * CoutP + (q & 3)) * 4);
+            }
+            wst[i] = v;
+        }
         __syncthreads();                    // previous chunk's reads are done
 #pragma unroll
         for (int i = 0; i < T4_SLOTS; ++i) {
             const int f = tid + i * 256;
             if (soff[i] != -2) *reinterpret_cast<f32x4*>(halo + (f >> 3) * T4_PITCH + (f & 7) * 4) = st[i];
         }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (tid + i * 256 < 288) *reinterpret_cast<f32x4*>(wsh + (tid + i * 256) * 4) = wst[i];
         __syncthreads();
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap - ky * 3;
             const float* hp = hbase + (ky * T4_HW + kx) * T4_PITCH;
-            const float* wt = d.wp + ((size_t)(tap * cin4 + (cb >> 2)) * CoutP) * 4;     // wave-uniform
+            const float* wt = wsh + tap * 128;
+#pragma unroll 4
             for (int c4 = 0; c4 < c4n; ++c4) {
                 const f32x4 g = *reinterpret_cast<const f32x4*>(hp + c4 * 4);
-                const float* w = wt + (size_t)c4 * CoutP * 4;                             // [n][c%4], n = 0..3
 #pragma unroll
-                for (int n = 0; n < 4; ++n)
+                for (int n = 0; n < 4; ++n) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(wt + c4 * 16 + n * 4);   // broadcast read
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[n] = fmaf(g[e], w[n * 4 + e], acc[n]);
+                    for (int e = 0; e < 4; ++e) acc[n] = fmaf(g[e], w[e], acc[n]);
+                }
             }
         }
     }
