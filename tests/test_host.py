@@ -161,3 +161,36 @@ dist.destroy_process_group()
     outs = [p.communicate(timeout=300) for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "OK" in outs[0][0]
+
+
+def test_sr_and_inpainting_helpers(built, tmp_path):
+    """utils/sr_utils.py and utils/inpainting_utils.py: the reference's names with its behaviour
+    (reference utils/sr_utils.py:3-94, utils/inpainting_utils.py:7-22)."""
+    from PIL import Image
+    from utils import sr_utils as S
+    from utils import inpainting_utils as I
+    rng = np.random.RandomState(0)
+    # tv_loss against its definition
+    x = torch.rand(1, 3, 7, 9, dtype=torch.float64)
+    dh, dw = (x[..., 1:] - x[..., :-1]) ** 2, (x[..., 1:, :] - x[..., :-1, :]) ** 2
+    want = sum(float((dh[0, c, i, j] + dw[0, c, i, j]) ** 0.5) for c in range(3) for i in range(6) for j in range(8))
+    assert abs(float(S.tv_loss(x)) - want) < 1e-9
+    # put_in_center
+    img = rng.rand(3, 4, 6)
+    out = S.put_in_center(img, (10, 10))
+    assert out.shape == (3, 10, 10) and np.array_equal(out[:, 3:7, 2:8], img) and out.sum() == pytest.approx(img.sum())
+    # load + crop-to-32 + LR / baselines
+    arr = (rng.rand(70, 100, 3) * 255).astype(np.uint8)
+    f = tmp_path / "img.png"
+    Image.fromarray(arr).save(f)
+    d = S.load_LR_HR_imgs_sr(str(f), -1, 4, 'CROP')
+    assert d['HR_pil'].size == (96, 64) and d['LR_pil'].size == (24, 16) and d['HR_np'].shape == (3, 64, 96)
+    assert np.array_equal(d['HR_np'], d['orig_np'][:, 3:67, 2:98])
+    bic, sharp, near = S.get_baselines(d['LR_pil'], d['HR_pil'])
+    assert bic.shape == sharp.shape == near.shape == (3, 64, 96)
+    # masks
+    np.random.seed(0)
+    m = I.pil_to_np(I.get_bernoulli_mask(d['HR_pil'], zero_fraction=0.9))
+    assert m.shape == (3, 64, 96) and 0.07 < m.mean() < 0.13
+    t = I.get_text_mask(Image.fromarray(np.zeros((200, 300, 3), dtype=np.uint8)))
+    assert t.size == (300, 200) and np.array(t).max() == 255

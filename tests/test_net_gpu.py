@@ -203,6 +203,47 @@ def test_against_oracle_fresh_seed(dev, hw, mode, nskip):
     assert psnr >= 100.0 and rel <= 1e-5 and worst <= 1.0, (psnr, rel, worst, wk)
 
 
+def test_super_resolution_closure_against_oracle(dev):
+    """The SR notebook's loss path (super-resolution.ipynb:169-186): net -> Downsampler(3, 4,
+    'lanczos2', phase=0.5, preserve_size=True) -> MSE against the LR image, + tv_loss; iteration-1
+    parity of loss and every gradient through the Lanczos adjoint."""
+    from models.skip import skip
+    from models.downsampler import Downsampler
+    from utils.sr_utils import tv_loss
+    torch.manual_seed(11)
+    kw = dict(num_channels_down=[32, 32, 32], num_channels_up=[32, 32, 32], num_channels_skip=[4, 4, 4],
+              upsample_mode="bilinear", need_sigmoid=True, need_bias=True, pad="reflection")
+    net = skip(8, 3, **kw)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()
+          if not k.endswith(("running_mean", "running_var", "num_batches_tracked"))}
+    hw = (64, 96)
+    z = torch.rand(1, 8, *hw) * 0.1
+    lr = torch.rand(1, 3, hw[0] // 4, hw[1] // 4)
+    spec = O.SkipSpec(8, 3, [32] * 3, [32] * 3, [4] * 3, pad="reflection", upsample_mode="bilinear")
+    tv_w = 1e-6
+
+    def lf(o_, dt):
+        return torch.nn.functional.mse_loss(O.downsampler_forward(o_, 4, "lanczos2", 0.5, True), lr.to(dt)) \
+            + tv_w * tv_loss(o_, beta=0.5)
+    _, _, g64n = _oracle_grads(spec, sd, z, lf, torch.float64)
+    oo, lo, g32 = _oracle_grads(spec, sd, z, lf, torch.float32)
+    net = net.to(dev)
+    down = Downsampler(n_planes=3, factor=4, kernel_type="lanczos2", phase=0.5, preserve_size=True).to(dev)
+    out = net(z.to(dev))
+    out_lr = down(out)
+    assert out_lr.shape == lr.shape
+    loss = torch.nn.functional.mse_loss(out_lr, lr.to(dev)) + tv_w * tv_loss(out, beta=0.5)
+    loss.backward()
+    torch.cuda.synchronize()
+    import hipops
+    _, _, g64 = _oracle_grads(spec, sd, z, lf, torch.float64, hipops.lrelu_masks(net, spec))
+    psnr = _psnr(out.detach().cpu().numpy(), oo.numpy())
+    rel = abs(loss.item() - lo) / lo
+    worst, wk = _grad_report({k: p.grad for k, p in net.named_parameters()}, g64, g32, g64n)
+    print(f"SR closure: PSNR {psnr:.1f} dB, loss rel {rel:.2e}, grad err/tol {worst:.2f} ({wk})")
+    assert psnr >= 100.0 and rel <= 1e-5 and worst <= 1.0, (psnr, rel, worst, wk)
+
+
 def test_input_gradient_and_opt_over_input(dev):
     """get_params('net,input') (reference utils/common_utils.py:47-49): gradient wrt net_input."""
     from models.skip import skip
