@@ -186,6 +186,75 @@ __global__ __launch_bounds__(256) void upsample_bwd_stats_kernel(const float* __
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// nn.AvgPool2d(2, 2) after a stride-1 conv (conv(..., downsample_mode='avg'), reference
+// models/common.py:101-104) + the {count, mean, M2} partials of the BatchNorm that follows;
+// the adjoint spreads dy/4 over the 2x2 window.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void avgpool2_fwd_kernel(const float* __restrict__ x, int W, int Cx, int C,
+                                                           float* __restrict__ y, int Hl, int Wl, int Cy, float* stats,
+                                                           int ppb) {
+    __shared__ __attribute__((aligned(16))) float sh[256 * 12];
+    const RowLayout L = row_layout(C);
+    f32x4 K = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = K, s2 = K;
+    float n = 0.f;
+    if (L.active) {
+        const int ch = L.cg * 4;
+        const int npix = Hl * Wl;
+        const int p0 = blockIdx.x * ppb, p1 = min(p0 + ppb, npix);
+        for (int p = p0 + L.prow; p < p1; p += L.rpi) {
+            const int r = p / Wl, c = p - r * Wl;
+            const float* q = x + ((size_t)(2 * r) * W + 2 * c) * Cx + ch;
+            const f32x4 v00 = ld4(q), v01 = ld4(q + Cx), v10 = ld4(q + (size_t)W * Cx), v11 = ld4(q + (size_t)W * Cx + Cx);
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ((v00[e] + v01[e]) + (v10[e] + v11[e])) * 0.25f;
+            st4(y + (size_t)p * Cy + ch, v);
+            if (n == 0.f) K = v;
+            n += 1.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float dv = v[e] - K[e];
+                s1[e] += dv;
+                s2[e] += dv * dv;
+            }
+        }
+    }
+    if (stats == nullptr) return;
+    f32x4 mean = f32x4{0.f, 0.f, 0.f, 0.f}, M2 = mean;
+    if (n > 0.f) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            mean[e] = K[e] + s1[e] / n;
+            M2[e] = s2[e] - s1[e] * s1[e] / n;
+        }
+    }
+    dip_tree_chan4(sh, L.nc4, L.rpi, L.prow, L.cg, L.active, n, mean, M2);
+    if (L.active && L.prow == 0) {
+        float* o = stats + (size_t)blockIdx.x * 3 * Cy + L.cg * 4;
+        st4(o, f32x4{n, n, n, n});
+        st4(o + Cy, mean);
+        st4(o + 2 * Cy, M2);
+    }
+}
+
+__global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const float* __restrict__ dy, int Wl, int Cdy, int C,
+                                                           float* __restrict__ dx, int H, int W, int Cdx) {
+    const int nc4 = (C + 3) >> 2;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)H * W * nc4) return;
+    const int cg = (int)(i % nc4);
+    const long long p = i / nc4;
+    const int r = (int)(p / W), c = (int)(p - (long long)r * W);
+    f32x4 g = f32x4{0.f, 0.f, 0.f, 0.f};
+    if ((r >> 1) < (H >> 1) && (c >> 1) < Wl) {
+        g = ld4(dy + ((size_t)(r >> 1) * Wl + (c >> 1)) * Cdy + cg * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] *= 0.25f;
+    }
+    st4(dx + (size_t)p * Cdx + cg * 4, g);
+}
+
 int pixels_per_block(int npix, int C, int* nblk) {
     const int nc4 = (C + 3) / 4;
     int rpi = 256 / nc4;
@@ -213,6 +282,28 @@ extern "C" int dip_upcat_fwd(const DipUpcatDesc* d, void* stream) {
     const int ppb = pixels_per_block(d->H * d->W, C, &nb);
     if (nb != d->nblk) DIP_FAIL("upcat_fwd: nblk mismatch (use dip_upcat_nblk)");
     hipLaunchKernelGGL(upcat_fwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *d, ppb);
+    DIP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dip_avgpool2_fwd(const float* x, int H, int W, int Cx, int C, float* y, int Cy, float* stats, int nblk,
+                                void* stream) {
+    if (C > 1024) DIP_FAIL("avgpool2_fwd: C > 1024 unsupported");
+    if ((Cx & 3) || (Cy & 3)) DIP_FAIL("avgpool2_fwd: channel strides must be multiples of 4");
+    int nb;
+    const int ppb = pixels_per_block((H / 2) * (W / 2), C, &nb);
+    if (stats != nullptr && nb != nblk) DIP_FAIL("avgpool2_fwd: nblk mismatch (use dip_upcat_nblk(H/2, W/2, C))");
+    hipLaunchKernelGGL(avgpool2_fwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, W, Cx, C, y, H / 2, W / 2, Cy,
+                       stats, ppb);
+    DIP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dip_avgpool2_bwd(const float* dy, int H, int W, int Cdy, int C, float* dx, int Cdx, void* stream) {
+    if ((Cdx & 3) || (Cdy & 3)) DIP_FAIL("avgpool2_bwd: channel strides must be multiples of 4");
+    const long long n = (long long)H * W * ((C + 3) / 4);
+    hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, W / 2,
+                       Cdy, C, dx, H, W, Cdx);
     DIP_CHECK_LAUNCH();
     return 0;
 }

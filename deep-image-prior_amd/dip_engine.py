@@ -95,6 +95,7 @@ class ScalePlan:
         self.cat_bn = self.up = self.up_bn = self.up1 = self.up1_bn = None
         self.ns = 0
         self.upsample_mode = "nearest"
+        self.pool = None                    # 'avg': down_a is a stride-1 conv followed by AvgPool2d(2, 2)
 
 
 class SkipEngine:
@@ -119,6 +120,7 @@ class SkipEngine:
         for i, s in enumerate(scales):
             rec = ScalePlan()
             rec.ns, rec.upsample_mode = s.ns, s.upsample_mode
+            rec.pool = getattr(s, 'pool', None)
             for attr in ("skip_conv", "down_a", "down_b", "up", "up1"):
                 m = getattr(s, attr)
                 if m is not None:
@@ -278,7 +280,14 @@ class SkipEngine:
             self._emit_conv_fwd(s.skip_conv, xin, st["s_y"], s.skip_bn)
             st["s_act"] = Act(st["s_y"], H, W, s.ns, s.skip_bn, self.slope)
         st["d1_y"] = self._buf(Hl * Wl * round_up(s.down_a.Cout, 4))
-        self._emit_conv_fwd(s.down_a, xin, st["d1_y"], s.down_a_bn)
+        if s.pool == 'avg':
+            # conv(..., downsample_mode='avg'), models/common.py:101-104: full-resolution conv, then the
+            # pooling pass produces the BatchNorm partials of the pooled tensor
+            st["d1_full"] = self._buf(H * W * round_up(s.down_a.Cout, 4))
+            self._emit_conv_fwd(s.down_a, xin, st["d1_full"], None)
+            self._emit_avgpool(st["d1_full"], H, W, s.down_a.Cout, st["d1_y"], s.down_a_bn)
+        else:
+            self._emit_conv_fwd(s.down_a, xin, st["d1_y"], s.down_a_bn)
         d1 = Act(st["d1_y"], Hl, Wl, s.down_a.Cout, s.down_a_bn, self.slope)
         st["d2_y"] = self._buf(Hl * Wl * round_up(s.down_b.Cout, 4))
         self._emit_conv_fwd(s.down_b, d1, st["d2_y"], s.down_b_bn)
@@ -349,6 +358,23 @@ class SkipEngine:
                     _ptr(self.bnbuf, bn.rm_off) if bn.rm_off >= 0 else None,
                     _ptr(self.bnbuf, bn.rv_off) if bn.rv_off >= 0 else None)
             self.fwd_ops.append((lib.dip_bn_finalize, args, "bn_fin:" + bn.name))
+
+    def _emit_avgpool(self, x, H, W, Cc, y, bn: BNRec):
+        Cs = round_up(Cc, 4)
+        nblk = self.lib.dip_upcat_nblk(H // 2, W // 2, Cc)
+        if self._sizing:
+            self.stat_need = max(self.stat_need, nblk * 3 * Cs)
+            return
+        lib = self.lib
+        self.fwd_ops.append((lib.dip_avgpool2_fwd, (_ptr(x), H, W, Cs, Cc, _ptr(y), Cs, _ptr(self.stats_scratch), nblk),
+                             "pool:" + bn.name))
+        m = bn.module
+        args = (_ptr(self.stats_scratch), nblk, Cs, bn.C, _ptr(self.params, bn.gamma_off),
+                _ptr(self.params, bn.beta_off), float(m.eps), float(m.momentum if m.momentum is not None else 0.1),
+                _ptr(bn.state), bn.Cs,
+                _ptr(self.bnbuf, bn.rm_off) if bn.rm_off >= 0 else None,
+                _ptr(self.bnbuf, bn.rv_off) if bn.rv_off >= 0 else None)
+        self.fwd_ops.append((lib.dip_bn_finalize, args, "bn_fin:" + bn.name))
 
     def _emit_upcat(self, s, s_act: Optional[Act], deep: Act, cat, H, W):
         Ccat = s.ns + deep.C
@@ -511,6 +537,13 @@ class SkipEngine:
         self._emit_wgrad(s.down_b, st["d1"], dy_d2, ops)
         g = self._emit_dgrad(s.down_b, st["d1"], dy_d2, ops)
         dy_d1 = self._emit_bn_act_bwd(st["d1"], g, ops)
+        if s.pool == 'avg':                 # adjoint of AvgPool2d(2, 2): dy of the full-resolution conv output
+            Cs1 = round_up(s.down_a.Cout, 4)
+            dy_full = self._buf(H * W * Cs1)
+            if not self._sizing:
+                ops.append((self.lib.dip_avgpool2_bwd, (_ptr(dy_d1), H, W, Cs1, s.down_a.Cout, _ptr(dy_full), Cs1),
+                            "poolb:" + s.down_a_bn.name))
+            dy_d1 = dy_full
         self._emit_wgrad(s.down_a, xin, dy_d1, ops)
         tgt = ops if i > 0 else self.bwd_input_ops
         g = self._emit_dgrad(s.down_a, xin, dy_d1, tgt)

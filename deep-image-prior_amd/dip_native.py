@@ -91,6 +91,9 @@ _SIGS = {
     "dip_fold_to_nchw": (C.c_int, [C.POINTER(DipGradSrc), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "dip_upcat_fwd": (C.c_int, [C.POINTER(DipUpcatDesc), C.c_void_p]),
     "dip_upcat_nblk": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "dip_avgpool2_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                   C.c_int, C.c_void_p]),
+    "dip_avgpool2_bwd": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "dip_upsample_bwd_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                          C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int,
                                          C.c_void_p, C.c_int, C.c_void_p]),

@@ -59,6 +59,7 @@ def _attach_engine(model, scale_paths, out_path, need_sigmoid, pad, act_fun):
     for sp in scale_paths:
         s = dip_engine.ScalePlan()
         s.ns, s.upsample_mode = sp['ns'], sp['upsample_mode']
+        s.pool = sp.get('pool')
         for k in ('skip_conv', 'skip_bn', 'down_a', 'down_a_bn', 'down_b', 'down_b_bn', 'cat_bn', 'up', 'up_bn',
                   'up1', 'up1_bn'):
             setattr(s, k, at(sp[k]) if sp.get(k) is not None else None)
@@ -138,9 +139,12 @@ def skip(
         deeper.add(act(act_fun))
         sp['down_a'], sp['down_a_bn'] = deep_path + ['1'], deep_path + ['2']
         sp['down_b'], sp['down_b_bn'] = deep_path + ['4'], deep_path + ['5']
-        if downsample_mode[i] != 'stride':
-            sp['unsupported'] = (f"downsample_mode={downsample_mode[i]!r} (pooling after a stride-1 conv) "
-                                 "has no gfx950 kernel yet")
+        sp['pool'] = None
+        if downsample_mode[i] == 'avg':
+            sp['pool'] = 'avg'             # stride-1 conv + AvgPool2d(2, 2): dip_avgpool2_fwd/bwd
+        elif downsample_mode[i] != 'stride':
+            sp['unsupported'] = (f"downsample_mode={downsample_mode[i]!r} (max-pooling / Lanczos after a stride-1 "
+                                 "conv) has no gfx950 kernel yet")
 
         inner = nn.Sequential()
         if i != n - 1:

@@ -197,6 +197,14 @@ typedef struct DipUpcatDesc {
 int dip_upcat_fwd(const DipUpcatDesc* d, void* stream);
 int dip_upcat_nblk(int H, int W, int C);
 
+/* nn.AvgPool2d(2,2) behind a stride-1 conv (conv(..., downsample_mode='avg'), models/common.py:101-104):
+ * x [H][W][Cx] -> y [H/2][W/2][Cy] (H, W even or floored) + the {count, mean, M2} partials
+ * [nblk][3][Cy] of the BatchNorm that follows (nblk = dip_upcat_nblk(H/2, W/2, C); stats may be
+ * NULL); the adjoint writes dx[r][c] = dy[r/2][c/2] / 4 (0 on a floored odd border). */
+int dip_avgpool2_fwd(const float* x, int H, int W, int Cx, int C, float* y, int Cy, float* stats, int nblk,
+                     void* stream);
+int dip_avgpool2_bwd(const float* dy, int H, int W, int Cdy, int C, float* dx, int Cdx, void* stream);
+
 /* Adjoint of the 2x upsample fused with the LeakyReLU/BatchNorm backward phase 1 of the
  * deeper branch: du_d = upsample2x^T(dcat[:, choff:choff+nd]); dz = du_d * lrelu'(a*y+b);
  * partial sums as in dip_bn_bwd_stats.  (autograd UpsampleBilinear2DBackward / Nearest.) */

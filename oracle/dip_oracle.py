@@ -63,6 +63,7 @@ class SkipSpec:
     pad: str = "zero"
     upsample_mode: Sequence[str] | str = "nearest"
     need1x1_up: bool = True
+    downsample_mode: Sequence[str] | str = "stride"      # 'stride' | 'avg' (models/common.py:99-112)
 
     def __post_init__(self):
         n = len(self.num_channels_down)
@@ -73,6 +74,8 @@ class SkipSpec:
             self.filter_size_up = [self.filter_size_up] * n
         if isinstance(self.upsample_mode, str):
             self.upsample_mode = [self.upsample_mode] * n
+        if isinstance(self.downsample_mode, str):
+            self.downsample_mode = [self.downsample_mode] * n
 
     @property
     def n_scales(self) -> int:
@@ -227,7 +230,11 @@ def skip_forward(spec: SkipSpec, sd: Dict[str, torch.Tensor], x: torch.Tensor,
         k = keys[i]
         ns = spec.num_channels_skip[i]
         fd, fu = spec.filter_size_down[i], spec.filter_size_up[i]
-        d = _conv(x, sd, k.down_a, fd, 2, spec.pad)
+        if spec.downsample_mode[i] == "stride":
+            d = _conv(x, sd, k.down_a, fd, 2, spec.pad)
+        else:                               # conv(): stride-1 conv followed by nn.AvgPool2d(2, 2), common.py:101-104
+            assert spec.downsample_mode[i] == "avg", spec.downsample_mode[i]
+            d = F.avg_pool2d(_conv(x, sd, k.down_a, fd, 1, spec.pad), 2, 2)
         d = _bn_act(d, sd, k.down_a_bn, masks=masks)
         d = _conv(d, sd, k.down_b, fd, 1, spec.pad)
         d = _bn_act(d, sd, k.down_b_bn, masks=masks)

@@ -48,6 +48,11 @@ NETS = {
     "tiny_zero": dict(args=(2, 1), hw=(32, 32), seed=5,
                       kw=dict(num_channels_down=[8, 16], num_channels_up=[8, 16],
                               num_channels_skip=[4, 4], need_sigmoid=True, need_bias=True)),
+    # restoration.ipynb:149-160: stride-1 convs + AvgPool2d(2, 2) instead of strided convs
+    "tiny_avg": dict(args=(8, 3), hw=(32, 48), seed=6,
+                     kw=dict(num_channels_down=[16, 32], num_channels_up=[16, 32],
+                             num_channels_skip=[4, 4], upsample_mode="bilinear", downsample_mode="avg",
+                             need_sigmoid=True, need_bias=True, pad="reflection")),
 }
 
 
@@ -172,8 +177,12 @@ if __name__ == "__main__":
     assert _refload.available(), "reference checkout not found"
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)          # fixed reduction order for the committed vectors
+    only = sys.argv[1:]                # optional: regenerate just the named nets
     for n, c in NETS.items():
-        gen_net(n, c)
+        if not only or n in only:
+            gen_net(n, c)
+    if only:
+        sys.exit(0)
     gen_downsampler()
     gen_get_noise()
     gen_default_digest()

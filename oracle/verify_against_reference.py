@@ -33,6 +33,10 @@ CONFIGS = {
                                        num_channels_skip=[0, 0, 0, 4, 4], upsample_mode="bilinear",
                                        need_sigmoid=True, need_bias=True, pad="reflection"), hw=(64, 96)),
     "zero_pad": dict(args=(2, 3), kw=dict(), hw=(64, 64)),   # skip() defaults: pad='zero', nearest
+    # restoration.ipynb:149-160: downsample_mode='avg' (stride-1 conv + AvgPool2d)
+    "avg_down": dict(args=(32, 3), kw=dict(num_channels_down=[64] * 4, num_channels_up=[64] * 4,
+                                           num_channels_skip=[4] * 4, upsample_mode="bilinear", downsample_mode="avg",
+                                           need_sigmoid=True, need_bias=True, pad="reflection"), hw=(64, 96)),
 }
 
 
@@ -44,7 +48,8 @@ def spec_from(cfg) -> O.SkipSpec:
                       kw.get("num_channels_skip", [4, 4, 4, 4, 4]),
                       kw.get("filter_size_down", 3), kw.get("filter_size_up", 3),
                       kw.get("filter_skip_size", 1), kw.get("need_sigmoid", True), kw.get("need_bias", True),
-                      kw.get("pad", "zero"), kw.get("upsample_mode", "nearest"), kw.get("need1x1_up", True))
+                      kw.get("pad", "zero"), kw.get("upsample_mode", "nearest"), kw.get("need1x1_up", True),
+                      kw.get("downsample_mode", "stride"))
 
 
 def check(name, cfg):

@@ -111,9 +111,9 @@ def test_no_silent_fallback():
     bad = skip(4, 3, [8, 8], [8, 8], [4, 4], act_fun="Swish")
     with pytest.raises(NotImplementedError):
         bad(torch.zeros(1, 4, 16, 16))
-    avg = skip(4, 3, [8, 8], [8, 8], [4, 4], downsample_mode="avg")
+    mx = skip(4, 3, [8, 8], [8, 8], [4, 4], downsample_mode="max")     # ('avg' has kernels, 'max' does not)
     with pytest.raises(NotImplementedError):
-        avg(torch.zeros(1, 4, 16, 16))
+        mx(torch.zeros(1, 4, 16, 16))
     with pytest.raises(NotImplementedError):
         get_net(3, "UNet", "zero", "nearest")
     # missing shared library -> loud error

@@ -230,6 +230,44 @@ def test_bn_forward_backward_chain(dev, Cc, Hh, Ww, P, slope):
     _check("bn_bwd.dbeta", dbet, r64[2], r32[2], floor=5e-6)
 
 
+# ----------------------------------------------------------------------------- AvgPool2d(2, 2)
+@pytest.mark.parametrize("Cc,Hh,Ww", [(16, 8, 12), (128, 16, 32), (30, 10, 6)])
+def test_avgpool2_forward_stats_backward(dev, Cc, Hh, Ww):
+    """conv(..., downsample_mode='avg') pooling stage (reference models/common.py:101-104)."""
+    lib = N.lib()
+    torch.manual_seed(Cc)
+    x = torch.randn(1, Cc, Hh, Ww)
+    Cs = round_up(Cc, 4)
+    xb = H.to_nhwc(x.to(dev))
+    nblk = lib.dip_upcat_nblk(Hh // 2, Ww // 2, Cc)
+    y = torch.full(((Hh // 2) * (Ww // 2) * Cs,), float("nan"), device=dev)
+    stats = torch.full((nblk * 3 * Cs,), float("nan"), device=dev)
+    st = H.stream(dev)
+    N.check(lib.dip_avgpool2_fwd(xb.data_ptr(), Hh, Ww, Cs, Cc, y.data_ptr(), Cs, stats.data_ptr(), nblk, st))
+    ref = F.avg_pool2d(x.double(), 2, 2)
+    got = H.from_nhwc(y, Cc, Hh // 2, Ww // 2).cpu().double()
+    assert torch.allclose(got, ref, rtol=1e-6, atol=1e-6)
+    # partials -> batch statistics through the BatchNorm finalisation
+    state = torch.zeros(4 * Cs, device=dev)
+    gam, bet = torch.ones(Cc, device=dev), torch.zeros(Cc, device=dev)
+    N.check(lib.dip_bn_finalize(stats.data_ptr(), nblk, Cs, Cc, gam.data_ptr(), bet.data_ptr(), 1e-5, 0.1,
+                                state.data_ptr(), Cs, None, None, st))
+    torch.cuda.synchronize()
+    s = state.view(4, Cs).cpu().double()
+    r = ref[0].reshape(Cc, -1)
+    assert torch.allclose(s[0, :Cc], r.mean(1), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(s[1, :Cc], 1 / torch.sqrt(r.var(1, unbiased=False) + 1e-5), rtol=1e-5)
+    # adjoint
+    g = torch.randn(1, Cc, Hh // 2, Ww // 2)
+    gb = H.to_nhwc(g.to(dev))
+    dx = torch.full((Hh * Ww * Cs,), float("nan"), device=dev)
+    N.check(lib.dip_avgpool2_bwd(gb.data_ptr(), Hh, Ww, Cs, Cc, dx.data_ptr(), Cs, st))
+    torch.cuda.synchronize()
+    xr = x.double().requires_grad_(True)
+    (F.avg_pool2d(xr, 2, 2) * g.double()).sum().backward()
+    assert torch.allclose(H.from_nhwc(dx, Cc, Hh, Ww).cpu().double(), xr.grad, rtol=1e-6, atol=1e-7)
+
+
 # ----------------------------------------------------------------------------- upsample + concat
 @pytest.mark.parametrize("ns,nd,Hh,Ww,mode", [(4, 128, 16, 32, "bilinear"), (0, 32, 8, 8, "nearest"),
                                                (128, 128, 8, 16, "nearest"), (4, 16, 12, 20, "bilinear"),

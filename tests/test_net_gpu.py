@@ -34,6 +34,9 @@ NETS = {
                                             need_sigmoid=True, need_bias=True, pad="reflection")),
     "tiny_zero": dict(args=(2, 1), kw=dict(num_channels_down=[8, 16], num_channels_up=[8, 16],
                                            num_channels_skip=[4, 4], need_sigmoid=True, need_bias=True)),
+    "tiny_avg": dict(args=(8, 3), kw=dict(num_channels_down=[16, 32], num_channels_up=[16, 32],
+                                          num_channels_skip=[4, 4], upsample_mode="bilinear", downsample_mode="avg",
+                                          need_sigmoid=True, need_bias=True, pad="reflection")),
 }
 
 

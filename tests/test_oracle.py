@@ -20,7 +20,8 @@ def _spec(cfg):
     return O.SkipSpec(cfg["args"][0], cfg["args"][1], kw["num_channels_down"], kw["num_channels_up"],
                       kw["num_channels_skip"], kw.get("filter_size_down", 3), kw.get("filter_size_up", 3),
                       kw.get("filter_skip_size", 1), True, True, kw.get("pad", "zero"),
-                      kw.get("upsample_mode", "nearest"), kw.get("need1x1_up", True))
+                      kw.get("upsample_mode", "nearest"), kw.get("need1x1_up", True),
+                      kw.get("downsample_mode", "stride"))
 
 
 @pytest.mark.parametrize("name", list(NETS))
