@@ -12,10 +12,10 @@ run() { echo "=== $* ===" | tee -a $LOG; timeout "${TMO:-600}" "$@" >> $LOG 2>&1
 nproc >> $LOG; lscpu | grep -E "Model name|^CPU\(s\)" >> $LOG
 run python __graft_entry__.py build
 if [ "${SKIP_TESTS:-0}" != "1" ]; then
-for grp in "conv_forward" "conv_dgrad" "conv_wgrad" "mfma or bn_forward or upcat or layout or adam or noise or lanczos"; do
+for grp in "conv_forward" "conv_dgrad" "conv_wgrad" "mfma or bn_forward or upcat or avgpool or layout or adam or noise or lanczos"; do
   TMO=900 run python -m pytest tests/test_kernels_gpu.py -q -m gpu -k "$grp" --no-header -p no:cacheprovider
 done
-TMO=1200 run python -m pytest tests/test_net_gpu.py -q -m gpu --no-header -p no:cacheprovider -s
+TMO=1200 run python -m pytest tests/test_net_gpu.py tests/test_monitor_gpu.py -q -m gpu --no-header -p no:cacheprovider -s
 TMO=600 run python __graft_entry__.py smoke
 fi
 if [ "${SKIP_BENCH:-0}" != "1" ]; then

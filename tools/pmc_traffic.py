@@ -6,7 +6,7 @@
 Unit / gfx950 correction: rocprofv3 reports both in KiB of 64-byte requests; for 16-byte-per-lane
 coalesced accesses gfx950 tallies 128-byte requests as 64 bytes (guide: "FETCH_SIZE reports exactly
 1/2 of the bytes").  The factor is not assumed but calibrated in the same pass on
-bn_bwd_apply_kernel, which streams exactly two tensors in and one out with the same access width:
+bn_bwd_apply_src_kernel, which streams exactly two tensors in and one out with the same access width:
 its largest launches (scale 0, C = 128: 128 MiB per tensor) give known / reported."""
 import collections, glob, json, re, sqlite3, sys
 
@@ -26,7 +26,7 @@ def load(d):
 def calib(per, known_bytes):
     """factor = known / reported for the scale-0, 128-channel bn_bwd_apply launches (the most common
     value among its big launches)."""
-    vals = [v * 1024 for k, v in per.values() if "bn_bwd_apply_kernel" in k]
+    vals = [v * 1024 for k, v in per.values() if "bn_bwd_apply_src_kernel" in k]
     vals = [v for v in vals if v > 0.9 * max(vals)]          # the scale-0 launches (C = 128 and C = 132)
     ratios = collections.Counter(round(known_bytes / v, 2) for v in vals)
     return ratios.most_common(1)[0][0], dict(ratios)
@@ -45,7 +45,7 @@ def main():
         "fetch_bytes_per_launch": round(sum(fv) / len(fv)), "write_bytes_per_launch": round(sum(wv) / len(wv)),
         "traffic_bytes_per_launch": round(sum(fv) / len(fv) + sum(wv) / len(wv)),
         "correction": {"FETCH_SIZE": ff, "WRITE_SIZE": wf,
-                       "calibrated_on": "bn_bwd_apply_kernel, scale 0, C=128: reads 2 x 128 MiB, writes 128 MiB",
+                       "calibrated_on": "bn_bwd_apply_src_kernel, scale 0, C=128: reads 2 x 128 MiB, writes 128 MiB",
                        "observed_known_over_reported": {"FETCH_SIZE": fr, "WRITE_SIZE": wr}},
         "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python bench.py --steps 3 --warmup 2 "
                   "--no-cpu-baseline --no-roofline (tools/gpu_round.sh, DO_PMC=1); all launches of the kernel in the run",
