@@ -137,10 +137,7 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const DipGradSrc src,
         const int npix = H * W;
         const int p0 = blockIdx.x * ppb;
         const int p1 = min(p0 + ppb, npix);
-        for (int p = p0 + L.prow; p < p1; p += L.rpi) {
-            const int r = p / W, c = p - r * W;
-            const f32x4 du = grad_src4(src, r, c, H, W, ch);
-            const f32x4 yv = ld4(y + (size_t)p * Cy + ch);
+        auto one = [&](int p, const f32x4& du, const f32x4& yv) {
             f32x4 g;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -151,6 +148,22 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const DipGradSrc src,
                 s2[e] += g[e] * xh;
             }
             if (dz != nullptr) st4(dz + (size_t)p * Cdz + ch, g);
+        };
+        int p = p0 + L.prow;
+        // two pixels per iteration: four 16-byte loads in flight per thread (HBM-bound pass)
+        for (; p + L.rpi < p1; p += 2 * L.rpi) {
+            const int q = p + L.rpi;
+            const int r0 = p / W, c0 = p - r0 * W, r1 = q / W, c1 = q - r1 * W;
+            const f32x4 du0 = grad_src4(src, r0, c0, H, W, ch);
+            const f32x4 du1 = grad_src4(src, r1, c1, H, W, ch);
+            const f32x4 y0 = ld4(y + (size_t)p * Cy + ch);
+            const f32x4 y1 = ld4(y + (size_t)q * Cy + ch);
+            one(p, du0, y0);
+            one(q, du1, y1);
+        }
+        if (p < p1) {
+            const int r = p / W, c = p - r * W;
+            one(p, grad_src4(src, r, c, H, W, ch), ld4(y + (size_t)p * Cy + ch));
         }
     }
     block_reduce_2(L, s1, s2, partials, Cs, sh);
@@ -225,10 +238,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_src_kernel(const DipGradSrc 
     const int npix = H * W;
     const int p0 = blockIdx.x * ppb;
     const int p1 = min(p0 + ppb, npix);
-    for (int p = p0 + L.prow; p < p1; p += L.rpi) {
-        const int r = p / W, c = p - r * W;
-        const f32x4 du = grad_src4(src, r, c, H, W, ch);
-        const f32x4 yv = ld4(y + (size_t)p * Cy + ch);
+    auto one = [&](int p, const f32x4& du, const f32x4& yv) {
         f32x4 g;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -238,6 +248,21 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_src_kernel(const DipGradSrc 
             g[e] = a[e] * (gm - k1[e] - xh * k2[e]);
         }
         st4(dy + (size_t)p * Cdy + ch, g);
+    };
+    int p = p0 + L.prow;
+    for (; p + L.rpi < p1; p += 2 * L.rpi) {            // two pixels per iteration (see bn_bwd_stats_kernel)
+        const int q = p + L.rpi;
+        const int r0 = p / W, c0 = p - r0 * W, r1 = q / W, c1 = q - r1 * W;
+        const f32x4 du0 = grad_src4(src, r0, c0, H, W, ch);
+        const f32x4 du1 = grad_src4(src, r1, c1, H, W, ch);
+        const f32x4 y0 = ld4(y + (size_t)p * Cy + ch);
+        const f32x4 y1 = ld4(y + (size_t)q * Cy + ch);
+        one(p, du0, y0);
+        one(q, du1, y1);
+    }
+    if (p < p1) {
+        const int r = p / W, c = p - r * W;
+        one(p, grad_src4(src, r, c, H, W, ch), ld4(y + (size_t)p * Cy + ch));
     }
 }
 
