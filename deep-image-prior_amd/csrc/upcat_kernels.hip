@@ -8,15 +8,6 @@ namespace {
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
-__device__ __forceinline__ f32x4 tr4(f32x4 x, const DipTransform& t, int ch) {
-    if (t.a == nullptr) return x;
-    const f32x4 a = ld4(t.a + ch), b = ld4(t.b + ch);
-    f32x4 o;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = dip_act(fmaf(a[e], x[e], b[e]), t.slope);
-    return o;
-}
-
 // PyTorch upsample_bilinear2d source index, align_corners=False, scale 0.5 (src per dst)
 __device__ __forceinline__ void bil_src(int dst, int n_in, int& i0, int& i1, float& l0, float& l1) {
     float real = 0.5f * ((float)dst + 0.5f) - 0.5f;
@@ -54,24 +45,39 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const DipUpcatDesc d, in
         const int npix = d.H * d.W;
         const int p0 = blockIdx.x * ppb, p1 = min(p0 + ppb, npix);
         const int Hl = d.H >> 1, Wl = d.W >> 1;
+        // this thread's channel group never changes: its BatchNorm+LeakyReLU coefficients are loaded
+        // once (inside the loop every tap re-read them: 8 table loads next to 4 data loads per pixel)
+        const bool skip_side = ch < d.ns;
+        const DipTransform& tt = skip_side ? d.ts : d.td;
+        const int tch = skip_side ? ch : ch - d.ns;
+        const bool has_t = tt.a != nullptr;
+        const f32x4 tA = has_t ? ld4(tt.a + tch) : f32x4{1.f, 1.f, 1.f, 1.f};
+        const f32x4 tB = has_t ? ld4(tt.b + tch) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const float tS = has_t ? tt.slope : 1.f;
+        auto trr = [&](f32x4 x) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = dip_act(fmaf(tA[e], x[e], tB[e]), tS);
+            return o;
+        };
         for (int p = p0 + L.prow; p < p1; p += L.rpi) {
             f32x4 v;
-            if (ch < d.ns) {
-                v = tr4(ld4(d.s + (size_t)p * d.Cs_s + ch), d.ts, ch);
+            if (skip_side) {
+                v = trr(ld4(d.s + (size_t)p * d.Cs_s + ch));
             } else {
                 const int cd = ch - d.ns;
                 const int r = p / d.W, c = p - r * d.W;
                 if (d.mode == DIP_UP_NEAREST) {
-                    v = tr4(ld4(d.d + ((size_t)(r >> 1) * Wl + (c >> 1)) * d.Cs_d + cd), d.td, cd);
+                    v = trr(ld4(d.d + ((size_t)(r >> 1) * Wl + (c >> 1)) * d.Cs_d + cd));
                 } else {
                     int r0, r1, c0, c1;
                     float lr0, lr1, lc0, lc1;
                     bil_src(r, Hl, r0, r1, lr0, lr1);
                     bil_src(c, Wl, c0, c1, lc0, lc1);
-                    const f32x4 v00 = tr4(ld4(d.d + ((size_t)r0 * Wl + c0) * d.Cs_d + cd), d.td, cd);
-                    const f32x4 v01 = tr4(ld4(d.d + ((size_t)r0 * Wl + c1) * d.Cs_d + cd), d.td, cd);
-                    const f32x4 v10 = tr4(ld4(d.d + ((size_t)r1 * Wl + c0) * d.Cs_d + cd), d.td, cd);
-                    const f32x4 v11 = tr4(ld4(d.d + ((size_t)r1 * Wl + c1) * d.Cs_d + cd), d.td, cd);
+                    const f32x4 v00 = trr(ld4(d.d + ((size_t)r0 * Wl + c0) * d.Cs_d + cd));
+                    const f32x4 v01 = trr(ld4(d.d + ((size_t)r0 * Wl + c1) * d.Cs_d + cd));
+                    const f32x4 v10 = trr(ld4(d.d + ((size_t)r1 * Wl + c0) * d.Cs_d + cd));
+                    const f32x4 v11 = trr(ld4(d.d + ((size_t)r1 * Wl + c1) * d.Cs_d + cd));
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         v[e] = lr0 * (lc0 * v00[e] + lc1 * v01[e]) + lr1 * (lc0 * v10[e] + lc1 * v11[e]);
@@ -150,20 +156,26 @@ __global__ __launch_bounds__(256) void upsample_bwd_stats_kernel(const float* __
                         wc[t] = (i0 == j ? l0 : 0.f) + (i1 == j ? l1 : 0.f);
                     }
                 }
+                // all 16 loads of the 4x4 window are issued unconditionally (clamped address, zero
+                // weight outside the image): branching on the weights serialised them
+                f32x4 gw[16];
 #pragma unroll
                 for (int tr = 0; tr < 4; ++tr) {
-                    if (wr[tr] == 0.f) continue;
-                    const int hr = 2 * i - 1 + tr;
+                    const int hr = min(max(2 * i - 1 + tr, 0), H - 1);
 #pragma unroll
                     for (int tc = 0; tc < 4; ++tc) {
-                        if (wc[tc] == 0.f) continue;
-                        const int hc = 2 * j - 1 + tc;
-                        const f32x4 g = ld4(dcat + ((size_t)hr * W + hc) * Cs_cat + choff + ch);
-                        const float w = wr[tr] * wc[tc];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) du[e] = fmaf(w, g[e], du[e]);
+                        const int hc = min(max(2 * j - 1 + tc, 0), W - 1);
+                        gw[tr * 4 + tc] = ld4(dcat + ((size_t)hr * W + hc) * Cs_cat + choff + ch);
                     }
                 }
+#pragma unroll
+                for (int tr = 0; tr < 4; ++tr)
+#pragma unroll
+                    for (int tc = 0; tc < 4; ++tc) {
+                        const float w = wr[tr] * wc[tc];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) du[e] = fmaf(w, gw[tr * 4 + tc][e], du[e]);
+                    }
             }
             const f32x4 yv = ld4(y + (size_t)p * Cy + ch);
             f32x4 g;
