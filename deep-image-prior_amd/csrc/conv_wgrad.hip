@@ -403,9 +403,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         tap = id / (Cout * Cin);
         const size_t slab = (size_t)KK * CinP * CoutP;
         const float* p = partial + ((size_t)tap * CinP + c) * CoutP + o;
-        for (int k = sl; k < nsplit; k += 8) s += p[k * slab];
+#pragma unroll 4
+        for (int k = sl; k < nsplit; k += 8) s += p[k * slab];      // 4 loads in flight, same summation order
     } else if (dbias != nullptr && id < total + Cout) {
         o = id - total;
+#pragma unroll 4
         for (int k = sl; k < nsplit; k += 8) s += bias_partial[(size_t)k * CoutP + o];
     }
     sh[sl][oi] = s;
