@@ -7,8 +7,8 @@ namespace {
 // ------------------------------------------------------------------------------------------
 // forward finalise: combine the per-tile {count, mean, M2} partials -> state + running stats.
 // grid.x = ceil(C/4); a block = 256 tile rows x 4 channels (one 16-byte load per row and moment).
-// One pass in fp64:  N = sum n_i,  S1 = sum n_i m_i,  S2 = sum (M2_i + n_i m_i^2);
-//   mean = S1/N,  M2 = S2 - N mean^2   (fp64: the cancellation costs ~1e-10 relative at N = 2.6e5)
+// One pass in fp64 on means shifted by the first tile's mean K:  N = sum n_i,  S1 = sum n_i (m_i-K),
+//   S2 = sum (M2_i + n_i (m_i-K)^2);   mean = K + S1/N,  M2 = S2 - N (S1/N)^2
 // followed by a fixed-order tree over the 256 rows (deterministic).  The first version walked the
 // partials twice with 4-byte loads, 64 rows per block: 32 dependent trips, 27 us at 512x512.
 // ------------------------------------------------------------------------------------------
@@ -24,6 +24,11 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 #pragma unroll
     for (int k = 0; k < 12; ++k) acc[k] = 0.0;
     const bool vec = (c0 + 3 < Cstride) && ((Cstride & 3) == 0);
+    // means are accumulated relative to the first tile's mean K (same for every thread): the final
+    // M2 = S2 - N d^2 then cancels only d = mean - K, not the mean itself
+    double K[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) K[e] = (c0 + e < Cstride) ? (double)partials[Cstride + c0 + e] : 0.0;
 #pragma unroll 2
     for (int t = row; t < ntiles; t += 256) {
         const float* p = partials + (size_t)t * 3 * Cstride + c0;
@@ -42,7 +47,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const double ni = (double)n[e], mi = (double)m[e];
+            const double ni = (double)n[e], mi = (double)m[e] - K[e];
             acc[e] += ni;
             acc[4 + e] += ni * mi;
             acc[8 + e] += (double)q[e] + ni * mi * mi;
@@ -61,8 +66,9 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     if (row < 4 && c0 + row < C) {
         const int c = c0 + row;
         const double N = sh[0][row], S1 = sh[0][4 + row], S2 = sh[0][8 + row];
-        const double mean = N > 0.0 ? S1 / N : 0.0;
-        double M2 = S2 - N * mean * mean;
+        const double dmean = N > 0.0 ? S1 / N : 0.0;
+        const double mean = (double)partials[Cstride + c] + dmean;
+        double M2 = S2 - N * dmean * dmean;
         if (M2 < 0.0) M2 = 0.0;
         const double var = N > 0.0 ? M2 / N : 0.0;          // biased (normalisation)
         const float rstd = (float)(1.0 / sqrt(var + (double)eps));
