@@ -233,7 +233,7 @@ def cpu_baseline(seed=0, budget_s=25.0):
     import dip_oracle as O
     from models import get_net
     # torch-CPU conv scaling collapses on many-core hosts: on the 256-thread MI355X host a sweep
-    # (tools/cpu_sweep.py, 256x256) gave 3.47 / 2.38 / 1.25 / 0.59 / 0.011 it/s at 16 / 32 / 64 /
+    # (tests/cpu_sweep.py, 256x256) gave 3.47 / 2.38 / 1.25 / 0.59 / 0.011 it/s at 16 / 32 / 64 /
     # 128 / 256 threads, so the baseline uses the best setting, 16 threads, not all of them.
     cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)

@@ -1,4 +1,8 @@
-// Implicit-GEMM convolution on the gfx950 fp32 matrix core (v_mfma_f32_32x32x2_f32).
+// Implicit-GEMM convolution on the gfx950 fp32 matrix core (v_mfma_f32_32x32x2_f32):
+// dispatcher (dip_conv_igemm / dip_conv_variant / dip_conv_plan), split-K finish kernel, and the
+// register-staged kernel that serves what conv_igemm_dma.hip does not: stride-2 forwards, 5x5
+// filters, and the N = 160 one-pass variant for split-K data gradients towards 132 channels.
+// Stride-1 1x1 / 3x3 convolutions -- the bulk of the net -- run conv_igemm_dma_kernel.
 //
 // One workgroup (4 waves) computes an 8x16-pixel x BN-channel output tile:
 //   M = 128 output pixels, N = BN output channels, K = taps x input channels.

@@ -551,7 +551,7 @@ class SkipEngine:
             g = self._emit_dgrad(s.skip_conv, xin, dy_s, tgt, accumulate_into=g)
         s.gin = g
         s.dbg = {"dy_last": dy_last, "dy_u": dy_u, "dcat": dcat, "dy_s": dy_s, "dy_deep": dy_deep, "dy_d2": dy_d2,
-                 "dy_d1": dy_d1}      # gradient buffers by role (tools/debug_grads.py)
+                 "dy_d1": dy_d1}      # gradient buffers by role (tests/debug_grads.py)
         return ops
 
     # ------------------------------------------------------------------ run
