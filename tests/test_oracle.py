@@ -105,3 +105,30 @@ def test_oracle_bitwise_equal_to_reference():
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "oracle pinned against the reference" in r.stdout
+
+
+def test_closure_bookkeeping_restates_the_notebook_rule():
+    """oracle.ClosureBookkeeping (reference denoising.ipynb:214-248): EMA, PSNRs, and back-tracking on
+    the iterations with i % show_every != 0 only."""
+    rng = np.random.RandomState(0)
+    gt = rng.rand(3, 8, 8).astype(np.float32)
+    noisy = np.clip(gt + rng.normal(scale=0.1, size=gt.shape), 0, 1).astype(np.float32)
+    book = O.ClosureBookkeeping(noisy, gt, exp_weight=0.5, show_every=2)
+    params = [torch.zeros(3)]
+    outs, fell = [], []
+    for it, s in enumerate([0.05, 0.05, 0.9, 0.9, 0.05]):
+        out = torch.from_numpy(np.clip(gt + rng.normal(scale=s, size=gt.shape), 0, 1).astype(np.float32))[None]
+        params[0].add_(1.0)                       # the "optimizer step" of this iteration
+        r = book.step(out, params)
+        outs.append(out)
+        fell.append(r["fell_back"])
+        assert r["psrn_gt"] == pytest.approx(O.psnr(gt, out.numpy()[0]))
+    # iteration 0 and 2 are multiples of show_every: never checked; iteration 1 checkpoints (params = 2);
+    # iteration 3 sees a > 5 dB drop against iteration 1 and restores the checkpoint
+    assert fell == [False, False, False, True, False]
+    # (restored to 2 in iteration 3, then stepped once more in iteration 4)
+    assert torch.equal(params[0], torch.full((3,), 3.0))
+    ema = outs[0]
+    for o in outs[1:]:
+        ema = ema * 0.5 + o * 0.5
+    assert torch.allclose(book.out_avg, ema)
