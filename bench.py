@@ -1,102 +1,252 @@
 """Benchmark of the deep-image-prior hot path on MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config default|sr|kate|library|snail]
+                  [--closure fused|notebook] [--no-graph] [--instances B]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one optimisation iteration (reg-noise perturbation, skip-net forward, MSE, backward,
-fused Adam) of ONE 512x512 denoising fit with the default net
+fused Adam) of ONE fit.  The default config is BASELINE.json's headline: the default net
   get_net(32,'skip','reflection',skip_n33d=128,skip_n33u=128,skip_n11=4,num_scales=5,'bilinear')
-(BASELINE.json configs[1]/[4] at the size the metric is quoted on; SURVEY.md section 8d "M1").
+on a 512x512 denoising problem (SURVEY.md section 8d "M1").  The other configs are the reference's
+remaining notebook set-ups at their own sizes (BASELINE.json configs[2..3]): `sr` (M2: the same net,
+loss through the Lanczos x4 down-sampler), `kate` (inpainting net with 128 skip channels, 512x512,
+masked MSE), `library` (depth 6, 5x5 filters, 448x704), `snail` (8..128-channel net, 256x384).
+
 With N GPUs every rank optimises its own independent image (no collective on the data path:
-train-mode BatchNorm forbids batching images, so images shard one-per-GPU) -> "scaling": "weak",
-value = N * K / max-over-ranks time.
+train-mode BatchNorm forbids batching images and the path never shards one image -- "replicas
+only") -> "scaling": "weak", value = N * K / max-over-ranks time.  `--gpus N` without a torchrun
+environment starts the N worker processes itself; the ranks meet over gloo (start barrier and
+max-over-ranks time only -- no RCCL anywhere).
+
+Timed region (default): the iteration captured once as a hipGraph (dip_optim.GraphedIteration)
+with the fused closure (utils.reg_noise.RegNoise + utils.loss_head.MSEHead + in-place EMA), replayed
+K times.  `--closure notebook --no-graph` times the notebook's own torch closure eagerly; the
+default line reports that figure too (`eager_notebook`) from a short second run.
 
 The JSON line also carries
-  roofline     : the dominant kernel (3x3 stride-1 implicit-GEMM conv, 128-wide N block: forward
-                 and data-gradient launches) -- algorithmic FLOPs / HIP-event time, vs the
-                 157.3 TFLOP/s fp32 MFMA peak (MI355X_MICROARCH.md chip table);
-  cpu_baseline : the CPU oracle (oracle/dip_oracle.py, a bitwise-verified restatement of the
-                 reference's PyTorch-CPU path) timed on this box's host cores on the same workload.
+  roofline       : the dominant kernel (3x3 stride-1 implicit-GEMM conv, 128-wide N block: forward
+                   and data-gradient launches) -- ALGORITHMIC FLOPs (2*Cout*Hout*Wout*
+                   Cin*k*k of the layer, no padded ring, no dilation zeros) / the kernel's own
+                   HIP-event time (the split-K finish kernel is timed separately), vs the 157.3
+                   TFLOP/s fp32 MFMA peak (MI355X_MICROARCH.md chip table);
+  roofline_wgrad : the same for conv_wgrad_kernel (3x3), the top line of the rocprof profile;
+  cpu_baseline   : the CPU oracle (oracle/dip_oracle.py, a bitwise-verified restatement of the
+                   reference's PyTorch-CPU path) timed on this box's host cores on the same workload.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-import __graft_entry__ as ge  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP32 (matrix)
-SIZE = 512
+SELFTEST = os.environ.get("DIP_BENCH_SELFTEST") == "1"   # CPU-only plumbing test of the N-rank path (tests/test_host.py)
+
+CONFIGS = {
+    "default": dict(size=(512, 512), desc="default skip-net (2 217 831 params) 512x512 denoising fit"),
+    "sr": dict(size=(512, 512), desc="default skip-net 512x512, super-resolution x4 closure (Lanczos2 down-sampler)"),
+    "kate": dict(size=(512, 512), desc="inpainting 'kate' skip-net (skip=128, nearest) 512x512, masked MSE"),
+    "library": dict(size=(448, 704), desc="inpainting 'library' skip-net (depth 6, 5x5 down filters) 448x704, masked MSE"),
+    "snail": dict(size=(256, 384), desc="denoising 'snail' skip-net (8..128 channels) 256x384"),
+}
 
 
+# ------------------------------------------------------------------------------ rank plumbing
 def shard_images(n_images: int, rank: int, world: int):
     """Static round-robin partition of independent image fits over ranks (no data exchange)."""
     return [i for i in range(n_images) if i % world == rank]
 
 
-def reduce_max_time(t: float, device) -> float:
-    """max over ranks of a wall-time (the only collective in the benchmark; not on the data path)."""
+def reduce_max_time(t: float, device=None) -> float:
+    """max over ranks of a wall-time (gloo, CPU tensor; not on the data path)."""
+    import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return t
-    x = torch.tensor([t], dtype=torch.float64, device=device)
+    x = torch.tensor([t], dtype=torch.float64)
     dist.all_reduce(x, op=dist.ReduceOp.MAX)
     return float(x.item())
 
 
-def make_problem(seed: int, size: int = SIZE):
+def gather_floats(v: float):
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return [v]
+    xs = [torch.zeros(1, dtype=torch.float64) for _ in range(dist.get_world_size())]
+    dist.all_gather(xs, torch.tensor([v], dtype=torch.float64))
+    return [float(x.item()) for x in xs]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_workers(n: int, argv) -> int:
+    """`python bench.py --gpus N` outside torchrun: start one worker process per GPU (rank i drives
+    GPU i), same environment contract as torch.distributed.run."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    return rc
+
+
+# ------------------------------------------------------------------------------ problems
+def make_problem(seed: int, size=(512, 512), depth=32):
     """Synthetic denoising problem of the reference's shape: clean = 5x5 box-blur
-    of U(0,1) noise, target = clip(clean + N(0,(25/255)^2)), z = get_noise(32,'noise') ~ U(0,0.1)."""
+    of U(0,1) noise, target = clip(clean + N(0,(25/255)^2)), z = get_noise(depth,'noise') ~ U(0,0.1)."""
+    import torch
     from utils.common_utils import get_noise
     torch.manual_seed(seed)
     np.random.seed(seed)
-    z = get_noise(32, 'noise', (size, size))
-    clean = torch.nn.functional.avg_pool2d(torch.rand(1, 3, size + 4, size + 4), 5, stride=1)
+    z = get_noise(depth, 'noise', size)
+    clean = torch.nn.functional.avg_pool2d(torch.rand(1, 3, size[0] + 4, size[1] + 4), 5, stride=1)
     noisy = np.clip(clean.numpy() + np.random.normal(scale=25 / 255., size=clean.shape), 0, 1).astype(np.float32)
     return z, torch.from_numpy(noisy)
 
 
-def build_fit(seed: int, dev, size: int = SIZE):
+def build_net(config: str):
     from models import get_net
-    torch.manual_seed(seed)
-    net = get_net(32, 'skip', 'reflection', skip_n33d=128, skip_n33u=128, skip_n11=4, num_scales=5,
-                  upsample_mode='bilinear').to(dev)
-    z, target = make_problem(seed, size)
-    return net, z.to(dev), target.to(dev)
+    from models.skip import skip
+    if config in ("default", "sr"):        # denoising.ipynb:160-165, super-resolution.ipynb:141-148
+        return get_net(32, 'skip', 'reflection', skip_n33d=128, skip_n33u=128, skip_n11=4, num_scales=5,
+                       upsample_mode='bilinear'), 32
+    if config == "kate":                   # inpainting.ipynb:203-209
+        return skip(32, 3, num_channels_down=[128] * 5, num_channels_up=[128] * 5, num_channels_skip=[128] * 5,
+                    filter_size_up=3, filter_size_down=3, upsample_mode='nearest', filter_skip_size=1,
+                    need_sigmoid=True, need_bias=True, pad='reflection', act_fun='LeakyReLU'), 32
+    if config == "library":                # inpainting.ipynb:222-232
+        ch = [16, 32, 64, 128, 128, 128]
+        return skip(1, 3, num_channels_down=ch, num_channels_up=ch, num_channels_skip=[0] * 6, filter_size_up=3,
+                    filter_size_down=5, filter_skip_size=1, upsample_mode='nearest', need1x1_up=False,
+                    need_sigmoid=True, need_bias=True, pad='reflection', act_fun='LeakyReLU'), 1
+    if config == "snail":                  # denoising.ipynb:143-150
+        return skip(3, 3, num_channels_down=[8, 16, 32, 64, 128], num_channels_up=[8, 16, 32, 64, 128],
+                    num_channels_skip=[0, 0, 0, 4, 4], upsample_mode='bilinear', need_sigmoid=True, need_bias=True,
+                    pad='reflection', act_fun='LeakyReLU'), 3
+    raise ValueError(config)
 
 
-def make_closure(net, z, target, reg_noise_std=1. / 30., exp_weight=0.99):
-    """The denoising notebook's closure (reference denoising.ipynb:204-221) minus the per-iteration
-    host syncs (PSNR prints / plots / CPU parameter snapshots), which are not the hot path."""
-    mse = torch.nn.MSELoss()
-    st = {"saved": z.detach().clone(), "noise": z.detach().clone(), "avg": None, "loss": None, "i": 0}
+class Fit:
+    """One independent image fit: net, input, target, closure and optimiser."""
 
-    def closure():
-        net_input = st["saved"] + (st["noise"].normal_() * reg_noise_std)
-        out = net(net_input)
-        st["avg"] = out.detach() if st["avg"] is None else st["avg"] * exp_weight + out.detach() * (1 - exp_weight)
-        total_loss = mse(out, target)
-        total_loss.backward()
-        st["loss"] = total_loss.detach()
-        st["i"] += 1
-        return total_loss
+    def __init__(self, config, seed, dev, closure_kind):
+        import torch
+        from utils.common_utils import get_params
+        from dip_optim import FusedAdam
+        self.config, self.dev = config, dev
+        size = CONFIGS[config]["size"]
+        torch.manual_seed(seed)
+        net, depth = build_net(config)
+        self.net = net.to(dev)
+        z, target = make_problem(seed, size, depth)
+        self.z = z.to(dev)
+        self.target = target.to(dev)
+        self.mask = None
+        self.reg_std = {"default": 1. / 30., "snail": 1. / 30., "sr": 0.03, "kate": 0.03, "library": 0.0}[config]
+        if config in ("kate", "library"):
+            g = torch.Generator().manual_seed(seed + 1000)
+            self.mask = (torch.rand(1, 1, *size, generator=g) > 0.3).float().expand(1, 3, *size).contiguous().to(dev)
+        self.down = None
+        if config == "sr":
+            from models.downsampler import Downsampler
+            self.down = Downsampler(n_planes=3, factor=4, kernel_type='lanczos2', phase=0.5, preserve_size=True).to(dev)
+            self.target = torch.nn.functional.avg_pool2d(self.target, 4)        # a 128x128 LR image
+        self.loss = None
+        self.avg = None
+        self.closure = self._notebook_closure() if closure_kind == "notebook" else self._fused_closure()
+        self.opt = FusedAdam(get_params('net', self.net, self.z), lr=0.01)      # == optimize('adam', ...)
 
-    return closure, st
+    # the notebook's closure (denoising.ipynb:204-221, super-resolution.ipynb:169-186,
+    # inpainting.ipynb:295-313) minus the per-iteration host syncs (prints / plots / PSNR on the CPU)
+    def _notebook_closure(self, exp_weight=0.99):
+        import torch
+        mse = torch.nn.MSELoss()
+        saved, noise = self.z.detach().clone(), self.z.detach().clone()
+
+        def closure():
+            net_input = saved
+            if self.reg_std > 0:
+                net_input = saved + (noise.normal_() * self.reg_std)
+            out = self.net(net_input)
+            if self.config in ("default", "snail"):
+                self.avg = out.detach() if self.avg is None else self.avg * exp_weight + out.detach() * (1 - exp_weight)
+            if self.down is not None:
+                total_loss = mse(self.down(out), self.target)
+            elif self.mask is not None:
+                total_loss = mse(out * self.mask, self.target * self.mask)
+            else:
+                total_loss = mse(out, self.target)
+            total_loss.backward()
+            self.loss = total_loss.detach()
+            return total_loss
+
+        return closure
+
+    # the same arithmetic through the opt-in device helpers; replay-safe (in-place state only)
+    def _fused_closure(self, exp_weight=0.99):
+        import torch
+        from utils.reg_noise import RegNoise
+        from utils.loss_head import MSEHead
+        reg = RegNoise(self.z, self.reg_std, seed=1234)
+        head = None if self.down is not None else MSEHead(self.net, self.target, self.mask)
+        mse = torch.nn.MSELoss()
+        ema = self.config in ("default", "snail")
+        if ema:
+            self.avg = torch.zeros_like(self.target)
+        self.loss = torch.zeros((), device=self.dev)
+
+        def closure():
+            net_input = reg()
+            if head is not None:
+                total_loss, out = head(net_input)
+            else:                                   # SR: the loss goes through the Lanczos down-sampler
+                out = self.net(net_input)
+                total_loss = mse(self.down(out), self.target)
+            if ema:
+                self.avg.mul_(exp_weight).add_(out.detach(), alpha=1 - exp_weight)
+            total_loss.backward()
+            self.loss.copy_(total_loss.detach())
+            return total_loss
+
+        return closure
+
+    def step(self):
+        self.opt.zero_grad()
+        self.closure()
+        self.opt.step()
+
+    @property
+    def engine(self):
+        return self.net.__dict__["_dip_engine"]
 
 
+# ------------------------------------------------------------------------------ roofline
 def conv_flops(eng):
-    """Algorithmic conv FLOPs per iteration, per op name: 2*Cout*Ho*Wo*Cin*k*k for forward,
-    weight-gradient and (where the input needs it) data-gradient."""
+    """Algorithmic conv FLOPs per iteration, per op name: 2*Cout*Ho*Wo*Cin*k*k of the LAYER for its
+    forward, its weight gradient and (where the input needs it) its data gradient."""
     fl = {}
 
-    def dims(r, H, W):
-        Ho, Wo = (H + 2 * r.P - r.ks) // r.stride + 1, (W + 2 * r.P - r.ks) // r.stride + 1
+    def dims(r, H, W, pool):
+        s = 1 if pool else r.stride
+        Ho, Wo = (H + 2 * r.P - r.ks) // s + 1, (W + 2 * r.P - r.ks) // s + 1
         return 2.0 * r.Cout * Ho * Wo * r.Cin * r.ks * r.ks
 
     for i, s in enumerate(eng.sc):
@@ -106,25 +256,27 @@ def conv_flops(eng):
                              ("up1", (H, W))):
             r = getattr(s, attr)
             if r is not None:
-                f = dims(r, h, w)
-                fl["conv_fwd:" + r.name] = f
-                fl["wgrad:" + r.name] = f
-                fl["dgrad:" + r.name] = f
-                fl["dgrad+:" + r.name] = f
+                f = dims(r, h, w, attr == "down_a" and s.pool is not None)
+                for pre in ("conv_fwd:", "wgrad:", "dgrad:", "dgrad+:"):
+                    fl[pre + r.name] = f
     r = eng.out_conv
-    f = dims(r, eng.H, eng.W)
+    f = dims(r, eng.H, eng.W, False)
     fl["conv_fwd:out"] = fl["wgrad:out"] = fl["dgrad:out"] = f
     return fl
 
 
 def profile_ops(eng, reps=3):
     """HIP-event time of every launch of one iteration, in sequence on the engine's own stream
-    (torch's current stream), averaged over `reps` instrumented iterations."""
+    (torch's current stream), averaged over `reps` instrumented iterations.  Composite dispatches of
+    dip_conv_igemm are split into their kernels: "#thin4" / "#dma" (132-column data gradients) and
+    "#main" / "#finish" (split-K launches of the LDS-DMA kernel and their reduction)."""
     import ctypes as C
+    import torch
     import dip_native as N
     lib = N.lib()
     for f in (lib.dip_conv_thin4, lib.dip_conv_igemm_dma_cols):      # internal entry points of the dispatcher
         f.restype, f.argtypes = C.c_int, [C.POINTER(N.DipConvDesc), C.c_int, C.c_void_p]
+    lib.dip_conv_igemm_dma.restype, lib.dip_conv_igemm_dma.argtypes = C.c_int, [C.POINTER(N.DipConvDesc), C.c_int, C.c_void_p]
     stream = torch.cuda.current_stream(eng.device)
     sptr = stream.cuda_stream
     acc = {}
@@ -134,13 +286,19 @@ def profile_ops(eng, reps=3):
             evs[0].record(stream)
             mids = {}
             for k, (fn, args, name) in enumerate(ops):
-                if fn is lib.dip_conv_igemm and lib.dip_conv_variant(args[0]) == 3:
+                variant = lib.dip_conv_variant(args[0]) if fn is lib.dip_conv_igemm else -1
+                if variant == 3:
                     # 132-column data gradient = conv_thin4 + a 128-column launch of the dominant kernel
                     ncols = args[0]._obj.Cout - 128
                     lib.dip_conv_thin4(args[0], ncols, sptr)
-                    mids[k] = torch.cuda.Event(enable_timing=True)
-                    mids[k].record(stream)
+                    mids[k] = ("#thin4", "#dma", torch.cuda.Event(enable_timing=True))
+                    mids[k][2].record(stream)
                     lib.dip_conv_igemm_dma_cols(args[0], ncols, sptr)
+                elif variant == 1 and args[0]._obj.ksplit > 1:
+                    lib.dip_conv_igemm_dma(args[0], args[0]._obj.ksplit, sptr)
+                    mids[k] = ("#main", "#finish", torch.cuda.Event(enable_timing=True))
+                    mids[k][2].record(stream)
+                    lib.dip_conv_splitk_finish(args[0], sptr)
                 else:
                     fn(*args, sptr)
                 evs[k + 1].record(stream)
@@ -148,21 +306,23 @@ def profile_ops(eng, reps=3):
             for k, (_, _, name) in enumerate(ops):
                 acc.setdefault(name, []).append(evs[k].elapsed_time(evs[k + 1]))
                 if k in mids:
-                    acc.setdefault(name + "#thin4", []).append(evs[k].elapsed_time(mids[k]))
-                    acc.setdefault(name + "#dma", []).append(mids[k].elapsed_time(evs[k + 1]))
+                    a, b, ev = mids[k]
+                    acc.setdefault(name + a, []).append(evs[k].elapsed_time(ev))
+                    acc.setdefault(name + b, []).append(ev.elapsed_time(evs[k + 1]))
     return {k: float(np.mean(v)) for k, v in acc.items()}
 
 
 DOMINANT = "conv_igemm_dma_kernel<3,128,*>"
+WGRAD = "conv_wgrad_kernel<3,*,9,1>"
 
 
-def dominant_ops(eng):
-    """Launch-list entries that run the dominant kernel, as {timing key: (flops, compulsory bytes)}:
-    3x3 convolutions (forward and data gradient) that dip_conv_igemm dispatches to the LDS-DMA
-    implicit-GEMM kernel with a 128-column tile -- dip_conv_variant == 1, and the 128-column part
-    ("#dma", timed on its own by profile_ops) of the 132-column data gradients (variant 3).  The
-    N = 160 split-K variant of conv_igemm_kernel, the stride-2 forwards and conv_thin4 are other
-    kernels and are not counted."""
+def dominant_ops(eng, fl):
+    """Launch-list entries that run the dominant kernel, as {timing key: (algorithmic flops,
+    compulsory bytes)}: 3x3 convolutions (forward and data gradient) that dip_conv_igemm dispatches
+    to the LDS-DMA implicit-GEMM kernel with a 128-column tile -- dip_conv_variant == 1 (timing key
+    "#main" when split-K) and the 128-column part ("#dma") of the 132-column data gradients
+    (variant 3).  FLOPs are the LAYER's algorithmic FLOPs (scaled by the share of the columns this
+    kernel computes), not the MACs the launch executes on its padded / dilated domain."""
     import dip_native as N
     lib = N.lib()
     out = {}
@@ -177,88 +337,178 @@ def dominant_ops(eng):
             if v not in (1, 3):
                 continue
             cols = d.Cout if v == 1 else 128
-            flops = 2.0 * cols * d.Hout * d.Wout * d.Cin * 9
+            flops = fl[name] * cols / d.Cout
             # compulsory traffic of the launch: input and packed weights read once, output written once
             nbytes = 4.0 * (d.Hin * d.Win * d.Cin + 9 * d.Cin * cols + d.Hout * d.Wout * cols)
-            out[name if v == 1 else name + "#dma"] = (flops, nbytes)
+            key = name + "#dma" if v == 3 else (name + "#main" if d.ksplit > 1 else name)
+            out[key] = (flops, nbytes)
     return out
 
 
 def pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-    (profiles/r01_pmc_traffic.json, produced by tools/pmc_traffic.py); None when absent."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            t = json.load(f)
-        return t if t.get("kernel") == DOMINANT else None
-    except (OSError, ValueError):
-        return None
+    (profiles/r0N_pmc_traffic.json, produced by tools/pmc_traffic.py); None when absent."""
+    for rnd in ("r02", "r01"):
+        try:
+            with open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")) as f:
+                t = json.load(f)
+            if t.get("kernel") == DOMINANT:
+                return t
+        except (OSError, ValueError):
+            pass
+    return None
 
 
 def roofline(eng, per_op_ms):
-    """Dominant kernel = conv_igemm_dma_kernel<3,128,*> (all its launches of one iteration, see
-    dominant_ops).  achieved = their algorithmic FLOPs (2*Cout*Ho*Wo*Cin*9 per launch)
-    / their HIP-event time on the engine's stream."""
+    """roofline (dominant conv kernel) and roofline_wgrad (3x3 weight-gradient kernel)."""
     fl = conv_flops(eng)
-    dom = dominant_ops(eng)
+    dom = dominant_ops(eng, fl)
     tot_f = sum(f for f, _ in dom.values())
     alg_bytes = sum(b for _, b in dom.values())
     tot_ms = sum(per_op_ms[k] for k in dom)
     n = len(dom)
     ach = tot_f / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+    fin_ms = sum(ms for k, ms in per_op_ms.items() if k.endswith("#finish"))
     big = per_op_ms.get("conv_fwd:s0.up")
     # every MFMA conv launch (forward, data and weight gradient, all kernels) for the whole-path figure
     all_f = sum(f for k, f in fl.items() if k in per_op_ms)
-    all_ms = sum(ms for k, ms in per_op_ms.items() if k in fl)          # ("#thin4"/"#dma" parts are not in fl)
+    all_ms = sum(ms for k, ms in per_op_ms.items() if k in fl)          # (the "#..." parts are not in fl)
     pmc = pmc_traffic()
-    return {"bound": "mfma", "kernel": DOMINANT + " (3x3 stride-1 forward + 3x3 data-gradient launches)",
-            "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
-            "traffic": pmc["traffic_bytes_per_launch"] if pmc else None,
-            "launches_per_step": n, "avg_launch_us": round(1e3 * tot_ms / max(n, 1), 1),
-            "algorithmic_gflop_per_launch": round(tot_f / 1e9 / max(n, 1), 2),
-            "algorithmic_bytes_per_launch": round(alg_bytes / max(n, 1)),
-            "measured_mfma_ceiling_tflops": 151.9,      # tools/ubench/mfma_peak.hip on this chip (2 waves/SIMD)
-            "largest_layer": {"name": "3.1 (132->128 3x3 @512^2) forward", "gflop": round(fl["conv_fwd:s0.up"] / 1e9, 2),
-                              "us": round(1e3 * big, 1) if big else None,
-                              "tflops": round(fl["conv_fwd:s0.up"] / (big * 1e-3) / 1e12, 2) if big else None},
-            "all_conv_launches": {"gflop_per_step": round(all_f / 1e9, 1), "ms_per_step_serial": round(all_ms, 3),
-                                  "tflops": round(all_f / (all_ms * 1e-3) / 1e12, 2) if all_ms > 0 else None}}
+    rl = {"bound": "mfma", "kernel": DOMINANT + " (3x3 stride-1 forward + 3x3 data-gradient launches)",
+          "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+          "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+          "traffic": pmc["traffic_bytes_per_launch"] if pmc else None,
+          "launches_per_step": n, "avg_launch_us": round(1e3 * tot_ms / max(n, 1), 1),
+          "algorithmic_gflop_per_launch": round(tot_f / 1e9 / max(n, 1), 2),
+          "algorithmic_bytes_per_launch": round(alg_bytes / max(n, 1)),
+          "splitk_finish_ms_per_step_not_included": round(fin_ms, 3),
+          "measured_mfma_ceiling_tflops": 151.9,      # tools/ubench/mfma_peak.hip on this chip (2 waves/SIMD)
+          "all_conv_launches": {"gflop_per_step": round(all_f / 1e9, 1), "ms_per_step_serial": round(all_ms, 3),
+                                "tflops": round(all_f / (all_ms * 1e-3) / 1e12, 2) if all_ms > 0 else None}}
+    if big and "conv_fwd:s0.up" in fl:
+        rl["largest_layer"] = {"name": "s0.up forward", "gflop": round(fl["conv_fwd:s0.up"] / 1e9, 2),
+                               "us": round(1e3 * big, 1), "tflops": round(fl["conv_fwd:s0.up"] / (big * 1e-3) / 1e12, 2)}
+    # 3x3 weight gradients (conv_wgrad_kernel<3,S,9,1>; the slab reduction is a separate kernel)
+    wk = {}
+    for fn, args, name in eng.bwd_ops:
+        if name.startswith("wgrad:") and args[0]._obj.ks == 3:
+            wk[name] = fl[name]
+    w_f, w_ms = sum(wk.values()), sum(per_op_ms[k] for k in wk)
+    w_ach = w_f / (w_ms * 1e-3) / 1e12 if w_ms > 0 else 0.0
+    bigw = per_op_ms.get("wgrad:s0.up")
+    rw = {"bound": "mfma", "kernel": WGRAD + " (all 3x3 weight-gradient launches)", "achieved": round(w_ach, 2),
+          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(w_ach / PEAK_FP32_MFMA_TFLOPS, 4),
+          "traffic": None, "launches_per_step": len(wk), "ms_per_step": round(w_ms, 3),
+          "reduce_ms_per_step_not_included": round(sum(ms for k, ms in per_op_ms.items() if k.startswith("wgred:")), 3)}
+    if bigw and "wgrad:s0.up" in fl:
+        rw["largest_layer"] = {"name": "s0.up weight gradient", "gflop": round(fl["wgrad:s0.up"] / 1e9, 2),
+                               "us": round(1e3 * bigw, 1), "tflops": round(fl["wgrad:s0.up"] / (bigw * 1e-3) / 1e12, 2)}
+    return rl, rw
 
 
-def cpu_baseline(seed=0, budget_s=25.0):
+# ------------------------------------------------------------------------------ CPU baseline
+def host_cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(seed=0, timed=5):
     """The CPU oracle on this box's host cores: same net, same 512x512 workload, same closure;
-    1 warm-up + up to 2 timed iterations (bounded: ~10 s each on 8 cores)."""
+    1 warm-up + `timed` timed Adam iterations, median."""
+    import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import dip_oracle as O
-    from models import get_net
     # torch-CPU conv scaling collapses on many-core hosts: on the 256-thread MI355X host a sweep
     # (tests/cpu_sweep.py, 256x256) gave 3.47 / 2.38 / 1.25 / 0.59 / 0.011 it/s at 16 / 32 / 64 /
     # 128 / 256 threads, so the baseline uses the best setting, 16 threads, not all of them.
     cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     torch.manual_seed(seed)
-    net = get_net(32, 'skip', 'reflection', skip_n33d=128, skip_n33u=128, skip_n11=4, num_scales=5,
-                  upsample_mode='bilinear')
+    net, _ = build_net("default")
     sd = {k: v.detach().clone() for k, v in net.state_dict().items() if k in O.param_shapes(O.default_spec())}
     onet = O.OracleNet(O.default_spec(), sd)
     z, target = make_problem(seed)
-    closure, st = make_closure(onet, z, target)
+    mse = torch.nn.MSELoss()
+    saved, noise = z.clone(), z.clone()
+    st = {"avg": None}
+
+    def closure():
+        out = onet(saved + noise.normal_() * (1. / 30.))
+        st["avg"] = out.detach() if st["avg"] is None else st["avg"] * 0.99 + out.detach() * 0.01
+        loss = mse(out, target)
+        loss.backward()
+        return loss
+
     opt = torch.optim.Adam(onet.params, lr=0.01)
     times = []
-    t_start = time.time()
-    for it in range(3):
+    for it in range(1 + timed):
         t0 = time.time()
         opt.zero_grad()
         closure()
         opt.step()
         times.append(time.time() - t0)
-        if it >= 1 and time.time() - t_start > budget_s:
-            break
-    timed = times[1:] if len(times) > 1 else times
-    return {"value": round(1.0 / float(np.median(timed)), 4), "unit": "it/s", "cores": cores, "kind": "port",
-            "sample": f"default skip-net 512x512, 1 warm-up + {len(timed)} timed Adam iterations of the CPU oracle "
-                      f"(torch {torch.__version__} CPU, {cores} threads), median"}
+    tt = times[1:]
+    return {"value": round(1.0 / float(np.median(tt)), 4), "unit": "it/s", "cores": cores, "kind": "port",
+            "host": f"{host_cpu_model()} ({os.cpu_count()} hardware threads)",
+            "sample": f"default skip-net 512x512, 1 warm-up + {len(tt)} timed Adam iterations of the CPU oracle "
+                      f"(torch {torch.__version__} CPU, {cores} threads), median; min/max "
+                      f"{1.0 / max(tt):.3f}/{1.0 / min(tt):.3f} it/s"}
+
+
+# ------------------------------------------------------------------------------ main
+def timed_run(fits, steps, warmup, use_graph, barrier):
+    """W untimed warm-up steps, then exactly K timed steps bracketed by barrier + synchronize.
+    Returns (seconds, graph_used, note)."""
+    import torch
+    from dip_optim import GraphedIteration
+    note = None
+    graph = None
+    if use_graph:
+        try:
+            graph = GraphedIteration.group([(f.opt, f.closure) for f in fits], warmup=min(3, max(warmup, 1)))
+            rest = warmup - graph.iterations
+            if rest > 0:
+                graph.run(rest)
+        except Exception as e:                               # report, then time the eager loop instead
+            note = f"graph capture failed: {type(e).__name__}: {e}"
+            graph = None
+            torch.cuda.synchronize()
+    if graph is None:
+        for _ in range(warmup):
+            for f in fits:
+                f.step()
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    if graph is not None:
+        graph.run(steps)
+    else:
+        for _ in range(steps):
+            for f in fits:
+                f.step()
+    torch.cuda.synchronize()
+    t = time.perf_counter() - t0
+    barrier()
+    return t, graph is not None, note
+
+
+def selftest_rank(args, rank, world, barrier):
+    """DIP_BENCH_SELFTEST=1: the N-rank plumbing (spawn, rendezvous, barrier, max-over-ranks, per-rank
+    gather, JSON) with a dummy CPU step instead of the GPU fit -- driven by tests/test_host.py."""
+    barrier()
+    t0 = time.perf_counter()
+    x = 0.0
+    for k in range(args.steps):
+        x += float(np.sum(np.arange(20000, dtype=np.float64) * (rank + 1)))
+    t = time.perf_counter() - t0 + 1e-4
+    barrier()
+    return t
 
 
 def main():
@@ -266,79 +516,105 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="default", choices=sorted(CONFIGS))
+    ap.add_argument("--closure", default="fused", choices=["fused", "notebook"])
+    ap.add_argument("--no-graph", action="store_true", help="time the eager loop instead of hipGraph replays")
+    ap.add_argument("--instances", type=int, default=1, help="independent fits per GPU, grouped into one hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-eager-line", action="store_true")
     ap.add_argument("--dump-ops", default=None, help="write the per-launch HIP-event table (JSON) here")
     args = ap.parse_args()
 
-    ge.build()
-    from utils.common_utils import get_params
-    from dip_optim import FusedAdam
-
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(launch_workers(args.gpus, sys.argv[1:]))        # this process only supervises the N workers
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(env_world or "1")
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus N` "
+                         "or through torch.distributed.run with --nproc-per-node N")
+
+    import torch
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        dist.init_process_group("gloo")                          # host-side rendezvous only; no RCCL on this path
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    if SELFTEST:
+        t = selftest_rank(args, rank, world, barrier)
+        per_rank = gather_floats(args.steps / t)
+        tmax = reduce_max_time(t)
+        if rank == 0:
+            print(json.dumps({"metric": "selftest", "value": world * args.steps / tmax, "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "per_rank_it_s": per_rank}), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    import __graft_entry__ as ge
+    ge.build()
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    if local >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {local} but only {torch.cuda.device_count()} are visible")
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
 
-    my_images = shard_images(world, rank, world)            # one independent fit per rank
-    fits = []
-    for img in my_images:
-        net, z, target = build_fit(img, dev)
-        closure, st = make_closure(net, z, target)
-        opt = FusedAdam(get_params('net', net, z), lr=0.01)   # == optimize('adam', ...) unrolled for timing
-        fits.append((net, closure, st, opt))
-
-    def step():
-        for net, closure, st, opt in fits:
-            opt.zero_grad()
-            closure()
-            opt.step()
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    t = time.perf_counter() - t0
-    if world > 1:
-        dist.barrier()
-    t = reduce_max_time(t, dev)
-    final_loss = float(fits[0][2]["loss"].item())
+    # one independent image (x --instances) per rank; image index = global fit index = seed
+    n_inst = max(args.instances, 1)
+    my_images = shard_images(world * n_inst, rank, world)
+    fits = [Fit(args.config, img, dev, args.closure) for img in my_images]
+    t, graphed, note = timed_run(fits, args.steps, args.warmup, not args.no_graph, barrier)
+    my_its = len(fits) * args.steps / t
+    per_rank = gather_floats(my_its)
+    tmax = reduce_max_time(t)
+    final_loss = float(fits[0].loss.item())
 
     if rank == 0:
-        eng = fits[0][0].__dict__["_dip_engine"]
-        rl = None
+        eng = fits[0].engine
+        rl = rw = None
         if not args.no_roofline:
             per_op = profile_ops(eng)
-            rl = roofline(eng, per_op)
+            rl, rw = roofline(eng, per_op)
             if args.dump_ops:
                 fl = conv_flops(eng)
                 with open(args.dump_ops, "w") as f:
                     json.dump({k: {"ms": v, "gflop": fl.get(k, 0) / 1e9} for k, v in per_op.items()}, f, indent=1)
-        cb = None if (args.no_cpu_baseline or world > 1) else cpu_baseline()
-        its = world * len(my_images) * args.steps / t
+        eager = None
+        if world == 1 and not args.no_eager_line and not (args.closure == "notebook" and not graphed):
+            # the notebook's own torch closure, eager launches (what an unmodified notebook cell runs)
+            nb = Fit(args.config, 0, dev, "notebook")
+            k = max(10, min(args.steps, 30))
+            te, _, _ = timed_run([nb], k, 3, False, lambda: None)
+            eager = {"it_s": round(k / te, 3), "ms_per_step": round(1e3 * te / k, 3), "steps": k,
+                     "closure": "notebook torch ops (normal_, MSELoss, out-of-place EMA), eager launches"}
+            del nb
+        cb = None if (args.no_cpu_baseline or world > 1 or args.config != "default") else cpu_baseline()
+        its = world * len(fits) * args.steps / tmax
+        n_launch = len(eng.fwd_ops) + len(eng.bwd_ops) + 6
         line = {
-            "metric": "optimisation iters/sec per image (skip-net 512x512 denoising)", "value": round(its, 3),
-            "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * t / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "metric": "optimisation iters/sec per image (skip-net 512x512 denoising)" if args.config == "default"
+            else f"optimisation iters/sec per image ({args.config} config)",
+            "value": round(its, 3), "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * tmax / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "default skip-net (2 217 831 params) 512x512 denoising fit: reg-noise + forward "
-                                   "+ MSE + backward + fused Adam, one independent image per GPU",
-                       "images": world, "final_loss": round(final_loss, 6)},
-            "roofline": rl, "cpu_baseline": cb,
+            "config": {"workload": CONFIGS[args.config]["desc"] + ": reg-noise + forward + MSE + backward + fused Adam, "
+                                   f"{n_inst} independent image(s) per GPU; value = all images' iterations / s",
+                       "images": world * n_inst, "closure": args.closure, "hipgraph": graphed,
+                       "kernel_launches_per_iteration": n_launch, "final_loss": round(final_loss, 6)},
+            "per_rank_it_s": [round(v, 3) for v in per_rank],
+            "roofline": rl, "roofline_wgrad": rw, "cpu_baseline": cb, "eager_notebook": eager,
         }
+        if note:
+            line["config"]["note"] = note
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

@@ -521,6 +521,19 @@ extern "C" int dip_conv_variant(const DipConvDesc* dp) {
     return 0;
 }
 
+// second half of a split-K dispatch: sums the d.ksplit workspace slices in a fixed order, adds the
+// bias, stores and emits the BatchNorm partials (exported so that a profiler can time it on its own)
+extern "C" int dip_conv_splitk_finish(const DipConvDesc* dp, void* stream) {
+    const DipConvDesc& d = *dp;
+    if (d.ksplit <= 1 || d.ws == nullptr) DIP_FAIL("conv_splitk_finish: descriptor is not split-K");
+    int nblk;
+    const int ppb = finish_ppb(d.Hout * d.Wout, d.Cy, &nblk);
+    hipLaunchKernelGGL(splitk_finish_kernel, dim3(nblk), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), d.ws,
+                       d.ksplit, d, dip_round_up(d.Cout, 32), ppb);
+    DIP_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int dip_conv_igemm(const DipConvDesc* dp, void* stream) {
     const DipConvDesc& d = *dp;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -549,10 +562,5 @@ extern "C" int dip_conv_igemm(const DipConvDesc* dp, void* stream) {
     else if (d.ks == 5 && d.stride == 2) rc = launch_bn<5, 2, 8>(d, st, ksplit, d.ws);
     else DIP_FAIL("conv_igemm: unsupported kernel size / stride");
     if (rc || ksplit == 1) return rc;
-    int nblk;
-    const int ppb = finish_ppb(d.Hout * d.Wout, d.Cy, &nblk);
-    hipLaunchKernelGGL(splitk_finish_kernel, dim3(nblk), dim3(256), 0, st, d.ws, ksplit, d,
-                       dip_round_up(d.Cout, 32), ppb);
-    DIP_CHECK_LAUNCH();
-    return 0;
+    return dip_conv_splitk_finish(dp, stream);
 }

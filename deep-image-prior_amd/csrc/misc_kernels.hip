@@ -107,17 +107,30 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
 }
 
 // ---------------------------------------------------------------- Adam (torch 2.x _single_tensor_adam order)
+// The update is evaluated with exactly the roundings of ATen's CPU kernels (the oracle):
+//   exp_avg.lerp_(g, 1-b1)                 -> fma(w, g - m, m)                       (Lerp.h, vec::fmadd)
+//   exp_avg_sq.mul_(b2).addcmul_(g,g,1-b2) -> (v*b2) + ((1-b2)*g)*g   each rounded  (PointwiseOpsKernel.cpp)
+//   denom = sqrt(v)/bc2_sqrt + eps         -> correctly rounded sqrt / div
+//   p.addcdiv_(m, denom, -step_size)       -> p + ((-step_size)*m)/denom
+// __fmul_rn / __fadd_rn / __fdiv_rn keep hipcc from contracting them into other FMAs.
+// DEV: step_size / bc2_sqrt come from the DipIterState in device memory (graph-replayable).
+template <bool DEV>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n, float w1,
                                                    float beta2, float omb2, float step_size, float bc2_sqrt,
-                                                   float eps) {
+                                                   float eps, const DipIterState* __restrict__ st) {
+    if constexpr (DEV) {
+        step_size = st->step_size;
+        bc2_sqrt = st->bc2_sqrt;
+    }
+    const float neg_step = -step_size;
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
         const float gi = g[i];
-        const float mi = fmaf(w1, gi - m[i], m[i]);              // exp_avg.lerp_(grad, 1-beta1)
-        const float vi = fmaf(omb2 * gi, gi, v[i] * beta2);      // mul_(beta2).addcmul_(g, g, 1-beta2)
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        p[i] = p[i] - step_size * (mi / denom);                  // addcdiv_(exp_avg, denom, -step_size)
+        const float mi = fmaf(w1, __fsub_rn(gi, m[i]), m[i]);
+        const float vi = __fadd_rn(__fmul_rn(v[i], beta2), __fmul_rn(__fmul_rn(omb2, gi), gi));
+        const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), bc2_sqrt), eps);
+        p[i] = __fadd_rn(p[i], __fdiv_rn(__fmul_rn(neg_step, mi), denom));
         m[i] = mi;
         v[i] = vi;
     }
@@ -134,7 +147,9 @@ __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2])
 }
 
 __global__ __launch_bounds__(256) void noise_axpy_kernel(const float* __restrict__ z, float* __restrict__ out,
-                                                         int64_t n, float sigma, uint64_t seed, uint64_t offset) {
+                                                         int64_t n, float sigma, uint64_t seed, uint64_t offset,
+                                                         const uint64_t* __restrict__ offset_dev) {
+    if (offset_dev != nullptr) offset = *offset_dev;              // device-side stream position (graph replay)
     const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;   // one Philox block = 4 normals
     const int64_t i0 = q * 4;
     if (i0 >= n) return;
@@ -268,9 +283,22 @@ extern "C" int dip_adam_step(float* p, const float* g, float* m, float* v, int64
     const double bc2_sqrt = sqrt(bc2);
     int64_t blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
+    hipLaunchKernelGGL(adam_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
                        (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)step_size, (float)bc2_sqrt,
-                       (float)eps);
+                       (float)eps, (const DipIterState*)nullptr);
+    DIP_CHECK_LAUNCH();
+    return 0;
+}
+
+// same update with the step-dependent scalars read from a DipIterState (dip_adam_tick advances it)
+extern "C" int dip_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, double beta1, double beta2,
+                                 double eps, const DipIterState* st, void* stream) {
+    if (n <= 0) return 0;
+    if (st == nullptr) DIP_FAIL("adam_step_dev: iteration state is NULL");
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(adam_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
+                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), 0.f, 1.f, (float)eps, st);
     DIP_CHECK_LAUNCH();
     return 0;
 }
@@ -280,9 +308,22 @@ extern "C" int dip_noise_axpy(const float* z, float* out, int64_t n, float sigma
     if (n <= 0) return 0;
     const int64_t quads = (n + 3) / 4;
     hipLaunchKernelGGL(noise_axpy_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, z,
-                       out, n, sigma, seed, offset);
+                       out, n, sigma, seed, offset, (const uint64_t*)nullptr);
     DIP_CHECK_LAUNCH();
     return 0;
+}
+
+// Philox offset read from (and advanced in) device memory: every call continues the stream
+extern "C" int dip_counter_add(uint64_t* counter, uint64_t inc, void* stream);
+extern "C" int dip_noise_axpy_dev(const float* z, float* out, int64_t n, float sigma, uint64_t seed,
+                                  uint64_t* offset_dev, void* stream) {
+    if (n <= 0) return 0;
+    if (offset_dev == nullptr) DIP_FAIL("noise_axpy_dev: offset pointer is NULL");
+    const int64_t quads = (n + 3) / 4;
+    hipLaunchKernelGGL(noise_axpy_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, z,
+                       out, n, sigma, seed, (uint64_t)0, (const uint64_t*)offset_dev);
+    DIP_CHECK_LAUNCH();
+    return dip_counter_add(offset_dev, (uint64_t)quads, stream);
 }
 
 extern "C" int dip_lanczos_down_fwd(const float* x, const float* taps, float* y, int C, int H, int W, int k,

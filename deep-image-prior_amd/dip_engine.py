@@ -148,6 +148,12 @@ class SkipEngine:
             m = r.module
             if m.dilation != (1, 1) or m.groups != 1 or m.kernel_size[0] != m.kernel_size[1]:
                 raise NotImplementedError(f"dip-amd: conv {r.name}: dilation/groups/non-square unsupported")
+        for b in self.bns:
+            if b.module.momentum is None:
+                raise NotImplementedError(f"dip-amd: BatchNorm {b.name}: momentum=None (cumulative moving average of "
+                                          "the running statistics) is not implemented; the reference uses 0.1")
+            if not b.module.affine:
+                raise NotImplementedError(f"dip-amd: BatchNorm {b.name}: affine=False is not implemented")
         for i, s in enumerate(self.sc):
             if s.ns % 4 or s.down_b.Cout % 4 or s.up.Cout % 4 or (s.up.Cin % 4):
                 raise NotImplementedError("dip-amd: internal channel counts must be multiples of 4")
@@ -268,6 +274,7 @@ class SkipEngine:
             du_last = self._emit_dgrad(oc, last, self.dy_out, pre)
             dy_last = self._emit_bn_act_bwd(last, du_last, pre)
             self.dbg_top = {"du_last": du_last, "dy_last": dy_last, "last": last}
+            self.last_act = last                         # input of the output conv (utils/loss_head.MSEHead)
             self.bwd_ops = pre + self._bwd_scale_ops(0, dy_last)
         self.shape_key = (H, W, Cin_img)
 
@@ -353,7 +360,7 @@ class SkipEngine:
         if bn is not None:
             m = bn.module
             args = (_ptr(stats_scratch), ntiles, round_up(r.Cout, 32), bn.C, _ptr(self.params, bn.gamma_off),
-                    _ptr(self.params, bn.beta_off), float(m.eps), float(m.momentum if m.momentum is not None else 0.1),
+                    _ptr(self.params, bn.beta_off), float(m.eps), float(m.momentum),
                     _ptr(bn.state), bn.Cs,
                     _ptr(self.bnbuf, bn.rm_off) if bn.rm_off >= 0 else None,
                     _ptr(self.bnbuf, bn.rv_off) if bn.rv_off >= 0 else None)
@@ -370,7 +377,7 @@ class SkipEngine:
                              "pool:" + bn.name))
         m = bn.module
         args = (_ptr(self.stats_scratch), nblk, Cs, bn.C, _ptr(self.params, bn.gamma_off),
-                _ptr(self.params, bn.beta_off), float(m.eps), float(m.momentum if m.momentum is not None else 0.1),
+                _ptr(self.params, bn.beta_off), float(m.eps), float(m.momentum),
                 _ptr(bn.state), bn.Cs,
                 _ptr(self.bnbuf, bn.rm_off) if bn.rm_off >= 0 else None,
                 _ptr(self.bnbuf, bn.rv_off) if bn.rv_off >= 0 else None)
@@ -393,7 +400,7 @@ class SkipEngine:
         m = bn.module
         self.fwd_ops.append((self.lib.dip_upcat_fwd, (C.byref(d),), "upcat:" + bn.name))
         args = (_ptr(self.stats_scratch), nblk, Cs_cat, bn.C, _ptr(self.params, bn.gamma_off),
-                _ptr(self.params, bn.beta_off), float(m.eps), float(m.momentum if m.momentum is not None else 0.1),
+                _ptr(self.params, bn.beta_off), float(m.eps), float(m.momentum),
                 _ptr(bn.state), bn.Cs,
                 _ptr(self.bnbuf, bn.rm_off) if bn.rm_off >= 0 else None,
                 _ptr(self.bnbuf, bn.rv_off) if bn.rv_off >= 0 else None)
@@ -617,7 +624,10 @@ class SkipEngine:
         self._run_two_streams(ops, main, lambda n: n.endswith((".skip_conv", ".skip_bn")),
                               lambda n: n.startswith("upcat:"), "fwd")
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, head=None):
+        """Runs the forward launch list.  head = None: returns the network output [1,C,H,W].
+        head = a utils.loss_head.MSEHead: the output conv + sigmoid + (mask) + MSE run as ONE launch
+        (dip_loss_head_fwd) and (loss, out) is returned."""
         if x.dim() != 4 or x.shape[0] != 1:
             raise NotImplementedError("dip-amd: input must be [1,C,H,W] (train-mode BatchNorm couples a batch; "
                                       "independent images run as independent nets)")
@@ -633,61 +643,95 @@ class SkipEngine:
                 raise RuntimeError(f"dip-amd: input has {Cimg} channels, net expects {self.sc[0].down_a.Cin}")
             self._build_plan(H, W, Cimg)
         lib = self.lib
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        xs = x.detach()
-        if xs.dtype != torch.float32:
-            xs = xs.float()
-        xs = xs.contiguous()
-        self.fwd_id += 1
-        N.check(lib.dip_pack_weights(_ptr(self.params), _ptr(self.packed), self.pack_recs.data_ptr(), len(self.convs),
-                                     self.pack_max, stream), "pack_weights")
-        N.check(lib.dip_nchw_to_nhwc(xs.data_ptr(), _ptr(self.x_nhwc), Cimg, H * W, round_up(Cimg, 4), stream),
-                "nchw_to_nhwc")
-        if self.two_streams:
-            self._run_forward_two_streams(self.fwd_ops, torch.cuda.current_stream(dev))
-        else:
-            self._run(self.fwd_ops, stream)
-        out = torch.empty((1, self.n_out, H, W), dtype=torch.float32, device=dev)
-        N.check(lib.dip_head_fwd(_ptr(self.y_out), out.data_ptr(), self.n_out, H * W, round_up(self.n_out, 4),
-                                 1 if self.need_sigmoid else 0, stream), "head_fwd")
-        if len(self.bns):
-            self.nbt.add_(1)
+        with torch.cuda.device(dev):          # raw HIP launches go to the CURRENT device's streams
+            main = torch.cuda.current_stream(dev)
+            stream = main.cuda_stream
+            xs = x.detach()
+            if xs.dtype != torch.float32:
+                xs = xs.float()
+            xs = xs.contiguous()
+            self.fwd_id += 1
+            N.check(lib.dip_pack_weights(_ptr(self.params), _ptr(self.packed), self.pack_recs.data_ptr(),
+                                         len(self.convs), self.pack_max, stream), "pack_weights")
+            N.check(lib.dip_nchw_to_nhwc(xs.data_ptr(), _ptr(self.x_nhwc), Cimg, H * W, round_up(Cimg, 4), stream),
+                    "nchw_to_nhwc")
+            ops = self.fwd_ops if head is None else self.fwd_ops[:-1]      # the last op is the output conv
+            if self.two_streams:
+                self._run_forward_two_streams(ops, main)
+            else:
+                self._run(ops, stream)
+            out = torch.empty((1, self.n_out, H, W), dtype=torch.float32, device=dev)
+            loss = None
+            if head is None:
+                N.check(lib.dip_head_fwd(_ptr(self.y_out), out.data_ptr(), self.n_out, H * W, round_up(self.n_out, 4),
+                                         1 if self.need_sigmoid else 0, stream), "head_fwd")
+            else:
+                loss = torch.empty((), dtype=torch.float32, device=dev)
+                self._head_desc = head._descriptor(self, out, loss)
+                N.check(lib.dip_loss_head_fwd(C.byref(self._head_desc), stream), "loss_head_fwd")
+            if len(self.bns):
+                self.nbt.add_(1)
         self.last_out = out
-        return out
+        self.last_head = head
+        return out if head is None else (loss, out)
 
-    def backward(self, gout: torch.Tensor, fwd_id: int, need_input_grad: bool):
+    def _detach_stale_grads(self):
+        """.grad tensors that still alias the gradient arena (no zero_grad() since the previous
+        backward, or zero_grad(set_to_none=False)) would be overwritten by this backward before
+        autograd accumulates into them: move them to a second arena first, so that the usual
+        `p.grad += new` semantics of a second backward() hold."""
+        base = self.grads.data_ptr()
+        stale = [k for k, (p, o) in enumerate(zip(self.param_list, self.slots))
+                 if p.grad is not None and p.grad.data_ptr() == base + 4 * o]
+        if not stale:
+            return
+        if getattr(self, "grads_alt", None) is None or self.grads_alt.numel() != self.grads.numel() \
+                or self.grads_alt.device != self.grads.device:
+            self.grads_alt = torch.empty_like(self.grads)
+        self.grads_alt.copy_(self.grads)
+        for k in stale:
+            p, o = self.param_list[k], self.slots[k]
+            p.grad = self.grads_alt[o:o + p.numel()].view(p.shape)
+
+    def backward(self, gout, fwd_id: int, need_input_grad: bool, gloss=None):
         if fwd_id != self.fwd_id:
             raise RuntimeError("dip-amd: backward() of a stale forward: the engine keeps the activations of the "
                                "most recent net(x) only (one forward, one backward per closure call)")
         dev = self.device
-        stream = torch.cuda.current_stream(dev).cuda_stream
         lib = self.lib
-        g = gout.detach()
-        if g.dtype != torch.float32:
-            g = g.float()
-        g = g.contiguous()
         H, W = self.H, self.W
-        # if the previous backward's gradient views are still installed as .grad (accumulation
-        # across two backward() calls), write this backward into a fresh arena
         grads = self.grads
-        p0 = self.param_list[0]
-        if p0.grad is not None and p0.grad.data_ptr() == grads.data_ptr() + 4 * self.slots[0]:
-            raise RuntimeError("dip-amd: a second backward() while the previous gradients are still installed "
-                               "(.grad not cleared) is not supported; call optimizer.zero_grad() between "
-                               "closure evaluations as utils/common_utils.optimize does")
-        N.check(lib.dip_head_bwd(g.data_ptr(), self.last_out.data_ptr(), _ptr(self.dy_out), self.n_out, H * W,
-                                 round_up(self.n_out, 4), 1 if self.need_sigmoid else 0, stream), "head_bwd")
-        if self.two_streams:
-            self._run_backward_two_streams(self.bwd_ops, torch.cuda.current_stream(dev))
-        else:
-            self._run(self.bwd_ops, stream)
-        gx = None
-        if need_input_grad:
-            self._run(self.bwd_input_ops, stream)
-            gbuf, pad = self.sc[0].gin
-            src = N.DipGradSrc(_ptr(gbuf), pad, 1 if pad > 0 else 0, round_up(self.Cimg, 4), 0)
-            gx = torch.empty((1, self.Cimg, H, W), dtype=torch.float32, device=dev)
-            N.check(lib.dip_fold_to_nchw(C.byref(src), H, W, self.Cimg, gx.data_ptr(), stream), "fold_to_nchw")
+        with torch.cuda.device(dev):
+            main = torch.cuda.current_stream(dev)
+            stream = main.cuda_stream
+            self._detach_stale_grads()
+            if self.last_head is None:
+                g = gout.detach()
+                if g.dtype != torch.float32:
+                    g = g.float()
+                g = g.contiguous()
+                N.check(lib.dip_head_bwd(g.data_ptr(), self.last_out.data_ptr(), _ptr(self.dy_out), self.n_out, H * W,
+                                         round_up(self.n_out, 4), 1 if self.need_sigmoid else 0, stream), "head_bwd")
+            else:
+                gl = gloss.detach().reshape(1)
+                if gl.dtype != torch.float32:
+                    gl = gl.float()
+                self._gloss_keep = gl
+                N.check(lib.dip_loss_head_bwd(C.byref(self._head_desc), gl.data_ptr(), _ptr(self.dy_out),
+                                              round_up(self.n_out, 4), stream), "loss_head_bwd")
+            if self.two_streams:
+                self._run_backward_two_streams(self.bwd_ops, main)
+            else:
+                self._run(self.bwd_ops, stream)
+            gx = None
+            if need_input_grad:
+                self._run(self.bwd_input_ops, stream)
+                gbuf, pad = self.sc[0].gin
+                src = N.DipGradSrc(_ptr(gbuf), pad, 1 if pad > 0 else 0, round_up(self.Cimg, 4), 0)
+                gx = torch.empty((1, self.Cimg, H, W), dtype=torch.float32, device=dev)
+                N.check(lib.dip_fold_to_nchw(C.byref(src), H, W, self.Cimg, gx.data_ptr(), stream), "fold_to_nchw")
+        # NOTE: the returned gradients are VIEWS of the gradient arena; the next backward() overwrites
+        # them in place (keep a .clone() if a gradient has to survive the next closure evaluation)
         views = [grads[o:o + p.numel()].view(p.shape) for p, o in zip(self.param_list, self.slots)]
         return gx, views
 
@@ -701,17 +745,46 @@ class _SkipFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, gout):
         need_x = ctx.needs_input_grad[1]
         gx, views = ctx.engine.backward(gout, ctx.fwd_id, need_x)
         return (None, gx, *views)
 
 
-def run_net(engine: SkipEngine, x: torch.Tensor) -> torch.Tensor:
+class _SkipLossFn(torch.autograd.Function):
+    """net + fused loss head (utils/loss_head.MSEHead): returns (loss, out); `out` is not differentiable."""
+
+    @staticmethod
+    def forward(ctx, engine: SkipEngine, head, x, *params):
+        loss, out = engine.forward(x, head)
+        ctx.engine = engine
+        ctx.fwd_id = engine.fwd_id
+        ctx.mark_non_differentiable(out)
+        return loss, out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gloss, gout_unused):
+        need_x = ctx.needs_input_grad[2]
+        gx, views = ctx.engine.backward(None, ctx.fwd_id, need_x, gloss=gloss)
+        return (None, None, gx, *views)
+
+
+def _check_input(engine: SkipEngine, x: torch.Tensor):
     if not x.is_cuda:
         raise RuntimeError("dip-amd: the skip-net runs on an MI355X only (input tensor is on the CPU); there is "
                            "no CPU fallback in this backend")
     # make sure the parameter arena exists before autograd records the parameter tensors
     if engine.device != x.device or not engine._arena_ok():
         engine._build_arenas(x.device)
+
+
+def run_net(engine: SkipEngine, x: torch.Tensor) -> torch.Tensor:
+    _check_input(engine, x)
     return _SkipFn.apply(engine, x, *engine.param_list)
+
+
+def run_net_loss(engine: SkipEngine, head, x: torch.Tensor):
+    _check_input(engine, x)
+    return _SkipLossFn.apply(engine, head, x, *engine.param_list)

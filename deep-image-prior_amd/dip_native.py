@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdip_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 PAD_ZERO, PAD_REFLECT = 0, 1
 UP_NEAREST, UP_BILINEAR = 0, 1
@@ -58,6 +58,18 @@ class DipUpcatDesc(C.Structure):
                 ("stats", C.c_void_p), ("nblk", C.c_int32)]
 
 
+class DipIterState(C.Structure):
+    _fields_ = [("step", C.c_uint64), ("step_size", C.c_float), ("bc2_sqrt", C.c_float)]
+
+
+class DipLossHeadDesc(C.Structure):
+    _fields_ = [("u", C.c_void_p), ("Cu", C.c_int32), ("Cin", C.c_int32), ("tr", DipTransform),
+                ("w", C.c_void_p), ("bias", C.c_void_p), ("Cout", C.c_int32), ("HW", C.c_int32),
+                ("sigmoid", C.c_int32), ("target", C.c_void_p), ("mask", C.c_void_p), ("mask_c", C.c_int32),
+                ("out", C.c_void_p), ("partials", C.c_void_p), ("nblk", C.c_int32), ("ticket", C.c_void_p),
+                ("loss", C.c_void_p)]
+
+
 _SIGS = {
     "dip_abi_version": (C.c_int, []),
     "dip_last_error": (C.c_char_p, []),
@@ -69,6 +81,7 @@ _SIGS = {
     "dip_conv_igemm": (C.c_int, [C.POINTER(DipConvDesc), C.c_void_p]),
     "dip_conv_ntiles": (C.c_int, [C.c_int, C.c_int]),
     "dip_conv_variant": (C.c_int, [C.POINTER(DipConvDesc)]),
+    "dip_conv_splitk_finish": (C.c_int, [C.POINTER(DipConvDesc), C.c_void_p]),
     "dip_conv_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
                                 C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "dip_conv_wgrad": (C.c_int, [C.POINTER(DipWgradDesc), C.c_void_p]),
@@ -100,6 +113,14 @@ _SIGS = {
     "dip_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double,
                                 C.c_double, C.c_double, C.c_int, C.c_void_p]),
     "dip_noise_axpy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "dip_adam_tick": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p]),
+    "dip_adam_step_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double,
+                                    C.c_double, C.c_void_p, C.c_void_p]),
+    "dip_noise_axpy_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "dip_counter_add": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
+    "dip_loss_head_nblk": (C.c_int, [C.c_int, C.c_int]),
+    "dip_loss_head_fwd": (C.c_int, [C.POINTER(DipLossHeadDesc), C.c_void_p]),
+    "dip_loss_head_bwd": (C.c_int, [C.POINTER(DipLossHeadDesc), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "dip_fit_monitor_nblk": (C.c_int, [C.c_int64]),
     "dip_fit_monitor": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_int,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]),

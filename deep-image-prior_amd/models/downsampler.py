@@ -5,8 +5,14 @@ The reference realises it as ReplicationPad2d + a dense Conv2d(n, n, k, stride=f
 weight is the 2-D tap table on the channel diagonal (2/3 of the MACs multiply zeros for n=3) and
 registers the fixed taps as trainable parameters.  Here the same taps (float64 numpy, then fp32)
 drive `dip_lanczos_down_fwd/bwd`: one depth-wise stencil with clamped (replicated) borders.
-`downsampler_.weight/bias` are kept as parameters so `get_params('down', ...)` and
-`.type(dtype)` behave as in the reference; the native path reads the taps, not the dense weight.
+`downsampler_.weight/bias` are kept as parameters so `state_dict()`, `get_params('down', ...)` and
+`.type(dtype)` have the reference's shape; the native path reads the taps, not the dense weight:
+  * `load_state_dict()` re-derives the taps from the loaded weight and refuses a weight that is not
+    "one 2-D kernel on the channel diagonal, zero bias" (what every reference constructor builds);
+  * OPTIMISING the down-sampler (opt_over containing 'down', utils/common_utils.py:44-46 of the
+    reference -- no notebook does) would train the dense 3x3xkxk weight; there is no kernel for that,
+    so `get_params('down', ...)` marks the module and forward() raises instead of silently
+    optimising nothing.
 """
 import numpy as np
 import torch
@@ -119,7 +125,24 @@ class Downsampler(nn.Module):
             self._pad = int((k - 1) / 2.) if k % 2 == 1 else int((k - factor) / 2.)
             self.padding = nn.ReplicationPad2d(self._pad)
 
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+        w = self.downsampler_.weight.detach()
+        b = self.downsampler_.bias.detach()
+        n = w.shape[0]
+        diag = torch.stack([w[c, c] for c in range(n)])
+        off = w.clone()
+        for c in range(n):
+            off[c, c] = 0
+        if float(off.abs().max()) != 0 or float(b.abs().max()) != 0 or float((diag - diag[0]).abs().max()) != 0:
+            raise NotImplementedError("dip-amd: Downsampler weights other than one 2-D kernel on the channel "
+                                      "diagonal with zero bias have no gfx950 kernel")
+        self._taps = diag[0].to(torch.float32).contiguous().to(self._taps.device)
+
     def forward(self, input):
+        if getattr(self, "_dip_optimised", False):
+            raise NotImplementedError("dip-amd: optimising the down-sampler kernel (opt_over='down') is not "
+                                      "implemented: the HIP path applies the fixed taps and returns no weight gradient")
         if not input.is_cuda:
             raise RuntimeError("dip-amd: Downsampler runs on an MI355X only (no CPU fallback in this backend)")
         if input.dim() != 4 or input.shape[0] != 1:

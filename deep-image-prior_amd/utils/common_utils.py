@@ -9,7 +9,7 @@ steps ALL parameters with one fused gfx950 launch over the flat parameter arena
 import numpy as np
 import torch
 
-from dip_optim import FusedAdam
+from dip_optim import FusedAdam, GraphedIteration, ArenaLBFGS
 
 
 # ------------------------------------------------------------------ image helpers (host side)
@@ -131,6 +131,8 @@ def get_params(opt_over, net, net_input, downsampler=None):
         elif opt == 'down':
             assert downsampler is not None
             params = [x for x in downsampler.parameters()]
+            if hasattr(downsampler, "downsampler_"):      # dip-amd Downsampler: fixed taps, see models/downsampler.py
+                downsampler._dip_optimised = True
         elif opt == 'input':
             net_input.requires_grad = True
             params += [net_input]
@@ -139,12 +141,16 @@ def get_params(opt_over, net, net_input, downsampler=None):
     return params
 
 
-def optimize(optimizer_type, parameters, closure, LR, num_iter):
+def optimize(optimizer_type, parameters, closure, LR, num_iter, graph=False):
     """Runs the optimisation loop: `num_iter` x { zero_grad(); closure(); step() }.
 
     'adam': fused multi-tensor Adam on the GPU arena (torch.optim.Adam defaults).
-    'LBFGS': 100 Adam warm-up steps (lr 1e-3) then torch.optim.LBFGS driving the same closure.
-    """
+    'LBFGS': 100 Adam warm-up steps (lr 1e-3), then L-BFGS with max_iter=num_iter, lr=LR and both
+             tolerances at -1, exactly as the reference sets torch.optim.LBFGS up -- executed on the
+             flat parameter/gradient arenas (dip_optim.ArenaLBFGS).
+    graph=True (extension, 'adam' only): the iteration is captured once into a hipGraph after three
+    eager iterations and replayed; the closure must then be replay-safe (see
+    dip_optim.GraphedIteration)."""
     if optimizer_type == 'LBFGS':
         optimizer = FusedAdam(parameters, lr=0.001)
         for j in range(100):
@@ -156,11 +162,14 @@ def optimize(optimizer_type, parameters, closure, LR, num_iter):
         def closure2():
             optimizer.zero_grad()
             return closure()
-        optimizer = torch.optim.LBFGS(parameters, max_iter=num_iter, lr=LR, tolerance_grad=-1, tolerance_change=-1)
+        optimizer = ArenaLBFGS(parameters, max_iter=num_iter, lr=LR, tolerance_grad=-1, tolerance_change=-1)
         optimizer.step(closure2)
     elif optimizer_type == 'adam':
         print('Starting optimization with ADAM')
         optimizer = FusedAdam(parameters, lr=LR)
+        if graph and num_iter > 3:
+            GraphedIteration(optimizer, closure, warmup=3).run(num_iter - 3)
+            return
         for j in range(num_iter):
             optimizer.zero_grad()
             closure()

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DIP_ABI_VERSION 1
+#define DIP_ABI_VERSION 2
 
 #define DIP_PAD_ZERO 0
 #define DIP_PAD_REFLECT 1
@@ -116,6 +116,9 @@ int dip_conv_plan(int Hout, int Wout, int Cin, int Cout, int ks, int stride, int
  * (3x3, 129..160 output channels, split-K), 3 = conv_thin4_kernel (columns 0..Cout-129 on the vector ALU)
  * + conv_igemm_dma_kernel (the other 128 columns): 3x3 data gradients towards a 132-channel tensor */
 int dip_conv_variant(const DipConvDesc* d);
+/* second half of a split-K dispatch (d->ksplit > 1): fixed-order sum of the workspace slices, bias,
+ * store, BatchNorm partials.  dip_conv_igemm calls it itself; exported for per-kernel timing. */
+int dip_conv_splitk_finish(const DipConvDesc* d, void* stream);
 
 /* Weight gradient (autograd ConvolutionBackward, weight + bias part):
  *   dW[o][c][tap] = sum_q dy[q][o] * u[src(q,tap)][c],  db[o] = sum_q dy[q][o]
@@ -223,6 +226,59 @@ int dip_adam_step(float* p, const float* g, float* m, float* v, int64_t n, doubl
  * counter-based Philox4x32-10 + Box-Muller, NCHW in / NCHW out (elementwise). */
 int dip_noise_axpy(const float* z, float* out, int64_t n, float sigma, uint64_t seed, uint64_t offset,
                    void* stream);
+
+/* ---------------------------------------------------------------- device-side iteration state */
+/* Everything that changes from one optimisation iteration to the next on the HOST side of the
+ * reference loop (utils/common_utils.py:226-230: the step count inside torch.optim.Adam; the
+ * device RNG position behind `noise.normal_()`, denoising.ipynb:209) kept in DEVICE memory, so the
+ * launch list of one iteration is static and can be captured once and replayed as a hipGraph. */
+typedef struct DipIterState {
+    uint64_t step;        /* Adam step count t (0 before the first step) */
+    float step_size;      /* lr / (1 - beta1^t), written by dip_adam_tick */
+    float bc2_sqrt;       /* sqrt(1 - beta2^t) */
+} DipIterState;
+/* t <- t + 1 and the two bias-correction scalars of torch.optim.Adam, computed in double. */
+int dip_adam_tick(DipIterState* st, double lr, double beta1, double beta2, void* stream);
+/* dip_adam_step with step_size / bc2_sqrt read from `st` (call dip_adam_tick first). */
+int dip_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, double beta1, double beta2,
+                      double eps, const DipIterState* st, void* stream);
+/* dip_noise_axpy whose Philox offset lives at *offset_dev and is advanced by ceil(n/4) afterwards. */
+int dip_noise_axpy_dev(const float* z, float* out, int64_t n, float sigma, uint64_t seed, uint64_t* offset_dev,
+                       void* stream);
+/* *counter += inc (one thread; ordering by the stream). */
+int dip_counter_add(uint64_t* counter, uint64_t inc, void* stream);
+
+/* ---------------------------------------------------------------- fused loss head ------------ */
+/* The tail of the closure in two launches: output conv (1x1, Cout <= 4, weights straight from the
+ * OIHW parameter arena) + nn.Sigmoid (models/skip.py:96-98) + optional mask + torch.nn.MSELoss
+ * (denoising.ipynb:177,219: mse(out, img_noisy); inpainting.ipynb:310: mse(out * mask, img * mask),
+ * the mean runs over ALL Cout*HW elements in both cases).
+ *   forward : out[o][p] = sigmoid(sum_c w[o][c] * tr(u[p][c]) + bias[o])            (NCHW)
+ *             *loss = 1/(Cout*HW) * sum (out*m - target*m)^2
+ *             wavefront reduction over the channels of a pixel, LDS tree per block, one partial per
+ *             block, fixed-order sum of the partials in the last-arriving block (ticket):
+ *             deterministic, no float atomics.  `ticket` must be zero before the first launch.
+ *   backward: dy[p][o] = *gscale * 2/(Cout*HW) * (out*m - target*m) * m * out*(1-out)  (NHWC, stride Cy)
+ *             = grad wrt the output conv's result, consumed by dip_conv_wgrad / dip_conv_igemm. */
+typedef struct DipLossHeadDesc {
+    const float* u;       /* [HW][Cu] input activation of the output conv (raw conv output of the producer) */
+    int Cu, Cin;
+    DipTransform tr;      /* the producer's BatchNorm + LeakyReLU */
+    const float* w;       /* [Cout][Cin] 1x1 weights (OIHW) */
+    const float* bias;    /* [Cout] or NULL */
+    int Cout, HW, sigmoid;
+    const float* target;  /* [Cout][HW] NCHW */
+    const float* mask;    /* [mask_c][HW] NCHW or NULL; mask_c in {1, Cout} */
+    int mask_c;
+    float* out;           /* [Cout][HW] NCHW: the network output */
+    float* partials;      /* nblk floats */
+    int nblk;             /* dip_loss_head_nblk(HW, Cin) */
+    unsigned* ticket;
+    float* loss;          /* 1 float */
+} DipLossHeadDesc;
+int dip_loss_head_nblk(int HW, int Cin);
+int dip_loss_head_fwd(const DipLossHeadDesc* d, void* stream);
+int dip_loss_head_bwd(const DipLossHeadDesc* d, const float* gscale, float* dy, int Cy, void* stream);
 
 /* ---------------------------------------------------------------- closure bookkeeping ---- */
 /* The per-iteration bookkeeping of the notebooks' closures without host round trips

@@ -1,0 +1,93 @@
+"""CPU arm of tests/test_net_gpu.py::test_end_quality_default_net_128: the denoising notebook's
+closure (denoising.ipynb:204-221 of the reference) on the CPU oracle with a given thread count.
+
+    python tests/end_quality_cpu.py <threads> <iters> <out.json>
+
+Prints/writes {"psnr_gt": tail-averaged PSNR vs the clean image, "psnr_gt_sm": PSNR of the EMA
+output, "loss": final loss, "sec": wall time}.  Test infrastructure only."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import __graft_entry__ as ge  # noqa: E402
+
+ge.add_to_path()
+import dip_oracle as O  # noqa: E402
+
+SIZE = 128
+SIGMA = 25 / 255.
+REG = 1. / 30.
+TAIL = 20
+
+
+def problem():
+    """Clean image: smooth colour gradients + one step edge; noisy = clip(clean + N(0, sigma^2))."""
+    rng = np.random.RandomState(0)
+    yy, xx = np.mgrid[0:SIZE, 0:SIZE] / float(SIZE)
+    clean = np.stack([0.5 + 0.4 * np.sin(6 * xx) * np.cos(4 * yy), 0.5 + 0.4 * np.cos(5 * xx + 2 * yy),
+                      0.3 + 0.5 * (xx > 0.5)]).astype(np.float32)
+    noisy = np.clip(clean + rng.normal(scale=SIGMA, size=clean.shape), 0, 1).astype(np.float32)
+    return clean, noisy
+
+
+def build():
+    """Default net + z exactly as the notebook builds them (torch.manual_seed(0))."""
+    from models import get_net
+    from utils.common_utils import get_noise
+    torch.manual_seed(0)
+    net = get_net(32, 'skip', 'reflection', skip_n33d=128, skip_n33u=128, skip_n11=4, num_scales=5,
+                  upsample_mode='bilinear')
+    z = get_noise(32, 'noise', (SIZE, SIZE))
+    return net, z
+
+
+def run_fit(net_call, params_step, z, noisy, clean, iters, device, exp_weight=0.99):
+    """The notebook closure with the reg-noise drawn from a host generator (same perturbations in
+    every arm).  net_call(x) -> out; params_step(closure) runs the optimisation loop."""
+    gen = torch.Generator().manual_seed(77)
+    zt = z.to(device)
+    tgt = torch.from_numpy(noisy)[None].to(device)
+    mse = torch.nn.MSELoss()
+    st = {"i": 0, "avg": None, "loss": None, "tail": []}
+
+    def closure():
+        noise = torch.randn(z.shape, generator=gen) * REG
+        out = net_call(zt + noise.to(device))
+        st["avg"] = out.detach() if st["avg"] is None else st["avg"] * exp_weight + out.detach() * (1 - exp_weight)
+        loss = mse(out, tgt)
+        loss.backward()
+        st["i"] += 1
+        st["loss"] = loss.detach()
+        if st["i"] > iters - TAIL:              # single-iteration PSNR jitters by ~1 dB: average the tail
+            st["tail"].append(O.psnr(clean, out.detach().cpu().numpy()[0]))
+        return loss
+
+    t0 = time.time()
+    params_step(closure)
+    return {"psnr_gt": float(np.mean(st["tail"])), "psnr_gt_sm": O.psnr(clean, st["avg"].cpu().numpy()[0]),
+            "loss": float(st["loss"].item()), "sec": time.time() - t0}
+
+
+def main():
+    threads, iters, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+    torch.set_num_threads(threads)
+    clean, noisy = problem()
+    net, z = build()
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items() if k in O.param_shapes(O.default_spec())}
+    onet = O.OracleNet(O.default_spec(), sd)
+    res = run_fit(onet, lambda c: O.optimize_adam(onet.params, c, 0.01, iters), z, noisy, clean, iters, "cpu")
+    res["threads"] = threads
+    with open(out, "w") as f:
+        json.dump(res, f)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

@@ -22,7 +22,7 @@ def test_cabi_exports_every_declared_symbol(built):
     L = ctypes.CDLL(dip_native.LIB_PATH)
     for name in declared:
         assert hasattr(L, name), name
-    assert built.dip_abi_version() == 1
+    assert built.dip_abi_version() == 2
     # struct layouts agree with the header's field order (sizes on LP64)
     assert ctypes.sizeof(dip_native.DipTransform) == 24
     assert ctypes.sizeof(dip_native.DipGradSrc) == 24
@@ -161,6 +161,84 @@ dist.destroy_process_group()
     outs = [p.communicate(timeout=300) for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "OK" in outs[0][0]
+
+
+def _bench_selftest(cmd, extra_env=None):
+    env = dict(os.environ, DIP_BENCH_SELFTEST="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(extra_env or {})
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+
+
+def test_bench_gpus_2_starts_two_ranks():
+    """`python bench.py --gpus 2` itself starts 2 worker processes (one per GPU), which meet over gloo
+    (barrier, per-rank gather, max-over-ranks time) and print ONE JSON line with n_gpus == 2.
+    DIP_BENCH_SELFTEST=1 swaps the GPU fit for a dummy CPU step; launcher, rendezvous and reduction
+    are the code the real run uses."""
+    import json
+    r = _bench_selftest([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and len(d["per_rank_it_s"]) == 2 and d["value"] > 0
+    # the torch.distributed.run spelling the driver uses
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    r = _bench_selftest([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                         "--gpus", "2", "--steps", "2", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and len(d["per_rank_it_s"]) == 2
+    # a world size that disagrees with --gpus is an error, not a silent single-rank run
+    r = _bench_selftest([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"],
+                        {"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_arena_lbfgs_matches_torch_lbfgs():
+    """dip_optim.ArenaLBFGS restates torch.optim.LBFGS (no line search, the reference's settings:
+    tolerance -1, utils/common_utils.py:218): same iterates on a small smooth problem, for parameters
+    that are views of one arena (flat path) and for scattered parameters (gather path)."""
+    import dip_optim
+
+    def run(kind, flat):
+        torch.manual_seed(0)
+        A, b = torch.randn(30, 20), torch.randn(30)
+        torch.manual_seed(1)
+        arena = torch.randn(32) * 0.1
+        if flat:
+            w, c = torch.nn.Parameter(arena[:20].view(4, 5)), torch.nn.Parameter(arena[20:32])
+        else:
+            w, c = torch.nn.Parameter(arena[:20].clone().view(4, 5)), torch.nn.Parameter(arena[20:32].clone())
+        params = [w, c]
+        if kind == "torch":
+            opt = torch.optim.LBFGS(params, max_iter=25, lr=0.5, tolerance_grad=-1, tolerance_change=-1)
+        else:
+            opt = dip_optim.ArenaLBFGS(params, max_iter=25, lr=0.5, tolerance_grad=-1, tolerance_change=-1,
+                                       _allow_cpu=True)
+        hist = []
+
+        def closure():
+            opt.zero_grad()
+            x = w.reshape(-1)
+            l = ((A @ x - b) ** 2).mean() + 0.1 * (torch.tanh(c) ** 2).sum() + (x[:12] * c).sum() ** 2
+            l.backward()
+            hist.append(l.item())
+            return l
+
+        opt.step(closure)
+        return hist, torch.cat([w.detach().reshape(-1), c.detach()])
+
+    h0, x0 = run("torch", False)
+    for flat in (True, False):
+        h, x = run("arena", flat)
+        assert len(h) == len(h0) == 25
+        assert max(abs(a - b) for a, b in zip(h, h0)) < 1e-5 and (x - x0).abs().max() < 1e-5
+    with pytest.raises(RuntimeError, match="CUDA"):
+        dip_optim.ArenaLBFGS([torch.nn.Parameter(torch.zeros(3))])
 
 
 def test_sr_and_inpainting_helpers(built, tmp_path):

@@ -371,7 +371,11 @@ def test_layout_head_roundtrip(dev):
 
 
 def test_adam_matches_torch(dev):
-    """dip_adam_step vs torch.optim.Adam on identical gradients: <= 2 ulp-class agreement."""
+    """dip_adam_step vs torch.optim.Adam (CPU, the oracle's optimiser) on identical gradients.
+    The kernel evaluates the update with ATen's own rounding sequence (fma lerp, fma addcmul,
+    (-step*m)/denom), so exp_avg / exp_avg_sq agree BITWISE; the parameters agree to <= 2 ulp of
+    max(|p_old|, |p_new|, |update|): the residual is the oracle's, whose `exp_avg_sq.sqrt()` runs MKL
+    vsSqrt (<= 1 ulp, not correctly rounded) while v_sqrt + fix-up on the GPU is correctly rounded."""
     lib = N.lib()
     g = torch.Generator().manual_seed(11)
     n = 100003
@@ -380,17 +384,32 @@ def test_adam_matches_torch(dev):
     opt = torch.optim.Adam([pt], lr=0.01)
     p = p0.to(dev)
     m, v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
-    for step in range(1, 6):
+    eps32 = torch.finfo(torch.float32).eps
+    worst = 0.0
+    bitwise = True
+    for step in range(1, 9):
         gr = torch.randn(n, generator=g) * (10.0 ** torch.randint(-6, 1, (n,), generator=g).float())
+        p_old = pt.detach().clone()
         pt.grad = gr.clone()
         opt.step()
+        # both arms start every step from the oracle's parameters: the check is per step, not cumulative
+        p.copy_(p_old.to(dev))
         gd = gr.to(dev)
         N.check(lib.dip_adam_step(p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, 0.01, 0.9, 0.999, 1e-8,
                                   step, H.stream(dev)))
         torch.cuda.synchronize()
-        d = (p.cpu() - pt.detach()).abs()
-        ulp = torch.finfo(torch.float32).eps * pt.detach().abs().clamp_min(1e-3)
-        assert (d <= 4 * ulp + 1e-8).all(), (step, (d / ulp).max().item())
+        st = opt.state[pt]
+        # (bitwise on an AVX-512 host; <= 1 ulp allowed in case another ISA path of ATen contracts differently)
+        for got, ref in ((m.cpu(), st["exp_avg"]), (v.cpu(), st["exp_avg_sq"])):
+            assert ((got - ref).abs() <= eps32 * ref.abs()).all(), step
+        bitwise = bitwise and torch.equal(m.cpu(), st["exp_avg"]) and torch.equal(v.cpu(), st["exp_avg_sq"])
+        p_new = pt.detach()
+        d = (p.cpu() - p_new).abs()
+        scale = torch.maximum(torch.maximum(p_old.abs(), p_new.abs()), (p_new - p_old).abs())
+        r = (d / (eps32 * scale)).max().item()
+        worst = max(worst, r)
+        assert r <= 2.0, (step, r)
+    print(f"adam: worst parameter deviation {worst:.2f} ulp-units; moments bitwise equal: {bitwise}")
 
 
 def test_noise_axpy_statistics(dev):

@@ -17,6 +17,8 @@ pytestmark = pytest.mark.gpu
 
 from conftest import GOLDEN  # noqa: E402
 import dip_oracle as O  # noqa: E402
+import parity as PT  # noqa: E402
+from parity import oracle_grads as _oracle_grads  # noqa: E402
 
 NETS = {
     "tiny_default": dict(args=(8, 3), kw=dict(num_channels_down=[16, 32, 32], num_channels_up=[16, 32, 32],
@@ -44,38 +46,11 @@ def _psnr(a, b):
     return O.psnr(np.asarray(a), np.asarray(b))
 
 
-def _oracle_grads(spec, sd, z, loss_fn, dtype, masks=None):
-    """Oracle forward/backward in `dtype` (fp64 = the truth, fp32 = the reference's own noise).
-    `masks`: LeakyReLU branch pattern of the HIP forward (hipops.lrelu_masks) -- the truth for the
-    HIP gradient is the fp64 gradient of the branch pattern it actually realised."""
-    onet = O.OracleNet(spec, {k: v.to(dtype) for k, v in sd.items()})
-    out = onet(z.to(dtype), None, masks)
-    loss = loss_fn(out, dtype)
-    loss.backward()
-    return out.detach(), loss.item(), {k: p.grad.detach() for k, p in zip(onet.names, onet.params)}
-
-
-def _grad_report(named_grads, g64, g32, g64n=None, ratio=4.0, floor=2e-5):
-    """Every gradient tensor must be as close to the fp64 truth as the reference's own fp32 CPU
-    path is, up to `ratio` (different summation orders) plus an fp32 roundoff floor:
-        ||g_hip - g64|| <= ratio * ||g_ref32 - g64|| + floor * ||g64|| + 1e-7 * max_k ||g64_k||.
-    This is scale-free for the many gradients that are ANALYTICALLY ZERO on this net (conv biases
-    in front of a train-mode BatchNorm; BatchNorm gammas at beta = 0): their fp32 values are
-    roundoff in both implementations and a relative comparison between them is meaningless."""
-    worst, worst_k = 0.0, None
-    # analytically-zero gradients are sums of O(gscale) terms that cancel: both implementations leave
-    # roundoff of order eps * gscale there, so the floor also scales with the largest gradient
-    gscale = max(torch.as_tensor(v).double().norm().item() for v in g64.values())
-    for k, g in named_grads.items():
-        t = torch.as_tensor(g64[k]).double()                      # fp64 truth for the HIP branch pattern
-        tn = torch.as_tensor((g64n or g64)[k]).double()           # fp64 truth for the reference's pattern
-        r = torch.as_tensor(g32[k]).double()
-        g = g.detach().cpu().double()
-        e_hip, e_ref = (g - t).norm().item(), (r - tn).norm().item()
-        tol = ratio * e_ref + floor * t.norm().item() + 1e-7 * gscale + 1e-12
-        if e_hip / tol > worst:
-            worst, worst_k = e_hip / tol, f"{k} (err {e_hip:.2e}, ref-fp32 err {e_ref:.2e}, |g| {t.norm().item():.2e})"
-    return worst, worst_k
+def _grad_report(named_grads, g64, g32, g64n, spec):
+    """parity.grad_report: purely relative bound per tensor, absolute roundoff floor only for the
+    analytically-zero conv biases (enumerated from the spec)."""
+    rep = PT.grad_report(named_grads, g64, g32, g64n, PT.zero_grad_keys(spec))
+    return rep["worst"], PT.fmt(rep)
 
 
 @pytest.mark.parametrize("name", list(NETS))
@@ -109,7 +84,7 @@ def test_golden_reference_vectors(dev, name):
     import hipops
     _, _, g64 = _oracle_grads(_spec(cfg), learn, zc, lf, torch.float64, hipops.lrelu_masks(net, _spec(cfg)))
     _, _, g64n = _oracle_grads(_spec(cfg), learn, zc, lf, torch.float64)
-    worst, wk = _grad_report(grads, g64, {k: gold["grad/" + k] for k in grads}, g64n)
+    worst, wk = _grad_report(grads, g64, {k: gold["grad/" + k] for k in grads}, g64n, _spec(cfg))
     print(f"{name}: out PSNR {psnr:.1f} dB, loss rel {rel:.2e}, worst grad err/tol {worst:.2f} ({wk})")
     assert psnr >= 100.0, psnr
     assert rel <= 1e-5, rel
@@ -175,7 +150,7 @@ def test_default_net_64_against_oracle_and_digest(dev):
     _, _, g64n = _oracle_grads(O.default_spec(), sd, z, lf, torch.float64)
     _, l32, g32 = _oracle_grads(O.default_spec(), sd, z, lf, torch.float32)
     assert abs(l32 - dg["loss"]) <= 1e-6 * dg["loss"]           # the oracle reproduces the reference digest
-    worst, wk = _grad_report({k: p.grad for k, p in net.named_parameters()}, g64, g32, g64n)
+    worst, wk = _grad_report({k: p.grad for k, p in net.named_parameters()}, g64, g32, g64n, O.default_spec())
     print(f"default net 64x64: worst grad err/tol {worst:.2f} ({wk})")
     assert worst <= 1.0, (worst, wk)
 
@@ -204,7 +179,7 @@ def test_against_oracle_fresh_seed(dev, hw, mode, nskip):
     _, _, g64 = _oracle_grads(spec, sd, z, lf, torch.float64, hipops.lrelu_masks(net, spec))
     psnr = _psnr(out.detach().cpu().numpy(), oo.numpy())
     rel = abs(loss.item() - lo) / lo
-    worst, wk = _grad_report({k: p.grad for k, p in net.named_parameters()}, g64, g32, g64n)
+    worst, wk = _grad_report({k: p.grad for k, p in net.named_parameters()}, g64, g32, g64n, spec)
     print(f"oracle {hw} {mode} skip{nskip}: PSNR {psnr:.1f} dB, loss rel {rel:.2e}, grad err/tol {worst:.2f} ({wk})")
     assert psnr >= 100.0 and rel <= 1e-5 and worst <= 1.0, (psnr, rel, worst, wk)
 
@@ -245,7 +220,7 @@ def test_super_resolution_closure_against_oracle(dev):
     _, _, g64 = _oracle_grads(spec, sd, z, lf, torch.float64, hipops.lrelu_masks(net, spec))
     psnr = _psnr(out.detach().cpu().numpy(), oo.numpy())
     rel = abs(loss.item() - lo) / lo
-    worst, wk = _grad_report({k: p.grad for k, p in net.named_parameters()}, g64, g32, g64n)
+    worst, wk = _grad_report({k: p.grad for k, p in net.named_parameters()}, g64, g32, g64n, spec)
     print(f"SR closure: PSNR {psnr:.1f} dB, loss rel {rel:.2e}, grad err/tol {worst:.2f} ({wk})")
     assert psnr >= 100.0 and rel <= 1e-5 and worst <= 1.0, (psnr, rel, worst, wk)
 
@@ -277,8 +252,9 @@ def test_input_gradient_and_opt_over_input(dev):
 
 def test_end_quality_matches_cpu_oracle(dev):
     """Short denoising fit (notebook closure, reg-noise pre-generated on the host so both arms
-    see the same perturbations): end quality must agree within the CPU-vs-CPU spread measured in
-    the survey (|dPSNR_gt| <= 0.5 dB, final loss within 3 %... here 5 % at 150 iterations)."""
+    see the same perturbations) on a small 3-scale net: a quick version of
+    test_end_quality_default_net_128 with the same thresholds (|dPSNR_gt| <= 0.5 dB,
+    |dPSNR_gt_sm| <= 0.3 dB, final loss within 3 %)."""
     from models.skip import skip
     from utils.common_utils import get_params, optimize
     torch.manual_seed(0)
@@ -322,8 +298,51 @@ def test_end_quality_matches_cpu_oracle(dev):
     net = net.to(dev)
     got = run(net, dev, lambda c: optimize("adam", get_params("net", net, None), c, 0.01, iters))
     print(f"end quality  oracle(psnr_gt, psnr_sm, loss)={ref}  hip={got}")
-    assert abs(got[0] - ref[0]) <= 0.7 and abs(got[1] - ref[1]) <= 0.4, (got, ref)
-    assert abs(got[2] - ref[2]) / ref[2] <= 0.05, (got, ref)
+    assert abs(got[0] - ref[0]) <= 0.5 and abs(got[1] - ref[1]) <= 0.3, (got, ref)
+    assert abs(got[2] - ref[2]) / ref[2] <= 0.03, (got, ref)
+
+
+def test_end_quality_default_net_128(dev, tmp_path):
+    """the DEFAULT net, 128x128, sigma = 25, 600 iterations of the notebook
+    closure (denoising.ipynb:204-221): end quality of the HIP fit against the CPU oracle, with the
+    CPU-vs-CPU spread (4 threads vs 16 threads: another summation order, nothing else; a 1-thread arm
+    would take ~8 minutes) measured in the same test as the yard-stick.  Trajectories are chaotic (8c), so the comparison is on end quality:
+    |dPSNR_gt| <= 0.5 dB, |dPSNR_gt_sm| <= 0.3 dB, final loss within 3 %, each measured from the
+    interval the two CPU arms span."""
+    import subprocess
+    import sys
+    import end_quality_cpu as E
+    from utils.common_utils import get_params, optimize
+    iters = 600
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "end_quality_cpu.py")
+    arms = []
+    for th in (min(4, os.cpu_count() or 1), min(16, os.cpu_count() or 1)):
+        out = str(tmp_path / f"cpu_{th}.json")
+        arms.append((out, subprocess.Popen([sys.executable, script, str(th), str(iters), out],
+                                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+    clean, noisy = E.problem()
+    net, z = E.build()
+    net = net.to(dev)
+    got = E.run_fit(net, lambda c: optimize("adam", get_params("net", net, None), c, 0.01, iters), z, noisy, clean,
+                    iters, dev)
+    cpu = []
+    for out, proc in arms:
+        so, se = proc.communicate(timeout=3000)
+        assert proc.returncode == 0, se[-2000:]
+        cpu.append(json.load(open(out)))
+    print(f"end quality default net 128x128, {iters} it: hip={got}  cpu={cpu}")
+
+    def dist(v, key):
+        lo, hi = min(c[key] for c in cpu), max(c[key] for c in cpu)
+        return max(lo - v, v - hi, 0.0), hi - lo
+
+    d_gt, s_gt = dist(got["psnr_gt"], "psnr_gt")
+    d_sm, s_sm = dist(got["psnr_gt_sm"], "psnr_gt_sm")
+    d_l, s_l = dist(got["loss"], "loss")
+    lmean = float(np.mean([c["loss"] for c in cpu]))
+    print(f"  distance from the CPU interval: PSNR_gt {d_gt:.3f} dB (cpu spread {s_gt:.3f}), PSNR_gt_sm {d_sm:.3f} dB "
+          f"(spread {s_sm:.3f}), loss {100 * d_l / lmean:.2f} % (spread {100 * s_l / lmean:.2f} %)")
+    assert d_gt <= 0.5 and d_sm <= 0.3 and d_l <= 0.03 * lmean, (got, cpu)
 
 
 def test_full_size_properties_512(dev):

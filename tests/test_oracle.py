@@ -54,7 +54,7 @@ def test_oracle_reproduces_reference_vectors(name):
         O.optimize_adam(o2.params, closure, 0.01, nsteps)
         for k, p in zip(o2.names, o2.params):
             assert torch.equal(p.detach(), torch.from_numpy(gold[f"adam{nsteps}/" + k])), (nsteps, k)
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
 
 
 def test_oracle_downsampler_and_noise_vectors():
