@@ -1,7 +1,7 @@
 // Implicit-GEMM convolution on the gfx950 fp32 matrix core (v_mfma_f32_32x32x2_f32):
 // dispatcher (dip_conv_igemm / dip_conv_variant / dip_conv_plan), split-K finish kernel, and the
-// register-staged kernel that serves what conv_igemm_dma.hip does not: stride-2 forwards, 5x5
-// filters, and the N = 160 one-pass variant for split-K data gradients towards 132 channels.
+// register-staged kernel that serves what conv_igemm_dma.hip does not: stride-2 forwards, 5x5 and
+// 7x7 filters, and the N = 160 one-pass variant for split-K data gradients towards 132 channels.
 // Stride-1 1x1 / 3x3 convolutions -- the bulk of the net -- run conv_igemm_dma_kernel.
 //
 // One workgroup (4 waves) computes an 8x16-pixel x BN-channel output tile:
@@ -454,6 +454,8 @@ int cch_of(int ks, int stride) {
     if (ks == 3 && stride == 2) return 16;
     if (ks == 5 && stride == 1) return 16;
     if (ks == 5 && stride == 2) return 8;
+    if (ks == 7 && stride == 1) return 16;     // feature_inversion.ipynb: filter_size_down/up = [7, 7, 5, 5, 3, 3]
+    if (ks == 7 && stride == 2) return 8;
     return 0;
 }
 
@@ -560,6 +562,8 @@ extern "C" int dip_conv_igemm(const DipConvDesc* dp, void* stream) {
     else if (d.ks == 3 && d.stride == 2) rc = launch_bn<3, 2, 16>(d, st, ksplit, d.ws);
     else if (d.ks == 5 && d.stride == 1) rc = launch_bn<5, 1, 16>(d, st, ksplit, d.ws);
     else if (d.ks == 5 && d.stride == 2) rc = launch_bn<5, 2, 8>(d, st, ksplit, d.ws);
+    else if (d.ks == 7 && d.stride == 1) rc = launch_bn<7, 1, 16>(d, st, ksplit, d.ws);
+    else if (d.ks == 7 && d.stride == 2) rc = launch_bn<7, 2, 8>(d, st, ksplit, d.ws);
     else DIP_FAIL("conv_igemm: unsupported kernel size / stride");
     if (rc || ksplit == 1) return rc;
     return dip_conv_splitk_finish(dp, stream);

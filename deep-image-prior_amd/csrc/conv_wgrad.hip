@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d
 }
 
 template <int KS, int S, int NT, int CB>
-int launch(const DipWgradDesc& d, hipStream_t st) {
+int launch(const DipWgradDesc& d, hipStream_t st, int CinP_slab = 0) {
     using C = WCfg<KS, S, NT, CB>;
     static bool attr_set = false;
     auto kern = conv_wgrad_kernel<KS, S, NT, CB>;
@@ -291,7 +291,8 @@ int launch(const DipWgradDesc& d, hipStream_t st) {
     const int CinP = dip_round_up(d.Cin, 32), CoutP = dip_round_up(d.Cout, 32);
     if (d.nsplit < 1 || d.nsplit > ntiles) DIP_FAIL("conv_wgrad: nsplit out of range");
     dim3 grid(d.nsplit, dip_cdiv(CinP, C::CW), C::NGROUPS * dip_cdiv(CoutP, 128));
-    hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, st, d, ntx, ntiles, CinP, CoutP);
+    // CinP_slab: row count of the slabs when this launch covers only the leading channels of the layer
+    hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, st, d, ntx, ntiles, CinP_slab > 0 ? CinP_slab : CinP, CoutP);
     DIP_CHECK_LAUNCH();
     return 0;
 }
@@ -438,7 +439,7 @@ extern "C" int dip_wgrad_plan(int Hout, int Wout, int Cin, int Cout, int ks, int
     const int CinP = dip_round_up(Cin, 32), CoutP = dip_round_up(Cout, 32);
     const int nt = dip_conv_wgrad_ntiles(Hout, Wout);
     const int cw = (ks == 1) ? 128 : 32;
-    const int groups = (ks == 5) ? 5 : 1;
+    const int groups = (ks == 5) ? 5 : (ks == 7 ? 7 : 1);
     int chunks = dip_cdiv(CinP, cw);
     // a ragged <= 4-channel tail of a 3x3 conv runs the packed variant (2 of 9 MFMAs): its
     // workgroups are light, so fill the chip with the full chunks' workgroups
@@ -450,6 +451,63 @@ extern "C" int dip_wgrad_plan(int Hout, int Wout, int Cin, int Cout, int ks, int
     const long long slab = (long long)ks * ks * CinP * CoutP;
     while (n > 1 && (long long)n * slab > (64ll << 20)) n /= 2;
     *nsplit = n;
+    return 0;
+}
+
+// Cost model of one MFMA weight-gradient launch (microseconds): `n` pixel splits x `chunks` channel
+// chunks x `groups` tap groups x `oblk` 128-column blocks of workgroups, two resident per CU; every
+// workgroup walks ceil(nt / n) 64-pixel tiles, each costing its MFMAs (taps-per-workgroup x 32 K steps
+// x 64 cycles) plus the staging of the tile; then the n slabs are written once and read once by the
+// reduction.  Only used for layers with <= 256 tiles, where launch shape, not MFMA rate, sets the time.
+static double wgrad_cost(int nt, int n, int chunks, int groups, int oblk, int taps_per_wg, double slab_bytes) {
+    const int wgs = n * chunks * groups * oblk;
+    const int rounds = dip_cdiv(wgs, 512);
+    const int tiles = dip_cdiv(nt, n);
+    const double t_tile = (taps_per_wg * 32.0 * 64.0 + 3000.0) / 2400.0;
+    const double t_main = rounds * tiles * t_tile + 4.0;
+    const double t_slab = 2.0 * n * slab_bytes / 3.0e6 + 3.0;
+    return t_main + t_slab;
+}
+
+extern "C" int dip_wgrad_plan2(int Hout, int Wout, int Cin, int Cout, int ks, int stride, int* nsplit, int* tap_groups,
+                               int* chan_block) {
+    *tap_groups = 1;
+    *chan_block = (ks == 1) ? 4 : 1;
+    int rc = dip_wgrad_plan(Hout, Wout, Cin, Cout, ks, stride, nsplit);
+    if (rc) return rc;
+    if (is_thin(ks, Cin, Cout) || (ks != 3 && ks != 1)) return 0;
+    const int nt = dip_conv_wgrad_ntiles(Hout, Wout);
+    static const bool off = getenv("DIP_WGRAD_NO_SMALL_PLAN") != nullptr;
+    if (nt > 256 || off) return 0;
+    if (ks == 3 && nt > 128) return 0;
+    const int CinP = dip_round_up(Cin, 32), CoutP = dip_round_up(Cout, 32);
+    const int oblk = dip_cdiv(CoutP, 128);
+    const double slab = 4.0 * ks * ks * CinP * CoutP;
+    double best = 1e30;
+    int bn = *nsplit, bg = 1, bcb = *chan_block;
+    if (ks == 3) {
+        // Measured on MI355X (tools/wgrad_sweep.py small, kernel + slab reduction, 128 -> 128 channels):
+        //   64x64 out (nt 64): (g3, n32) 32 us | (g1, n64) 34 | old plan (g1, n16) 80
+        //   32x32 out (nt 16): (g3, n16) 18 us | (g9, n16) 18 | old plan (g1, n4) 79
+        //   16x16 out (nt  4): (g9, n4) 13 us | (g3, n4) 16  | old plan (g1, n1) 118
+        //   128x128 out (nt 256): (g3, n64) 70 ~ (g1, n64) 73: the large-layer plan stays.
+        if (nt <= 8) { bn = nt; bg = 9; }
+        else if (nt <= 32) { bn = nt; bg = 3; }
+        else if (nt <= 128) { bn = nt / 2; bg = 3; }
+        (void)best;
+    } else {
+        const int cbs[2] = {4, 1};
+        for (int ci = 0; ci < 2; ++ci) {
+            const int chunks = dip_cdiv(CinP, 32 * cbs[ci]);
+            for (int n = 1; n <= nt; n *= 2) {
+                const double c = wgrad_cost(nt, n, chunks, 1, oblk, cbs[ci], slab);
+                if (c < best) { best = c; bn = n; bcb = cbs[ci]; }
+            }
+        }
+    }
+    *nsplit = bn;
+    *tap_groups = bg;
+    *chan_block = bcb;
     return 0;
 }
 
@@ -470,11 +528,18 @@ extern "C" int dip_conv_wgrad(const DipWgradDesc* dp, void* stream) {
         DIP_CHECK_LAUNCH();
         return 0;
     }
-    if (d.ks == 1 && d.stride == 1) return launch<1, 1, 1, 4>(d, st);
-    if (d.ks == 3 && d.stride == 1) return launch<3, 1, 9, 1>(d, st);
-    if (d.ks == 3 && d.stride == 2) return launch<3, 2, 9, 1>(d, st);
+    const int g = d.tap_groups > 1 ? d.tap_groups : 1;
+    if (d.ks == 1 && d.stride == 1) return d.chan_block == 1 ? launch<1, 1, 1, 1>(d, st) : launch<1, 1, 1, 4>(d, st);
+    if (d.ks == 3 && (g != 1 && g != 3 && g != 9)) DIP_FAIL("conv_wgrad: tap_groups must be 1, 3 or 9");
+    if (d.ks == 3 && d.stride == 1) {
+        return g == 1 ? launch<3, 1, 9, 1>(d, st) : (g == 3 ? launch<3, 1, 3, 1>(d, st) : launch<3, 1, 1, 1>(d, st));
+    }
+    if (d.ks == 3 && d.stride == 2)
+        return g == 1 ? launch<3, 2, 9, 1>(d, st) : (g == 3 ? launch<3, 2, 3, 1>(d, st) : launch<3, 2, 1, 1>(d, st));
     if (d.ks == 5 && d.stride == 1) return launch<5, 1, 5, 1>(d, st);
     if (d.ks == 5 && d.stride == 2) return launch<5, 2, 5, 1>(d, st);
+    if (d.ks == 7 && d.stride == 1) return launch<7, 1, 7, 1>(d, st);
+    if (d.ks == 7 && d.stride == 2) return launch<7, 2, 7, 1>(d, st);
     DIP_FAIL("conv_wgrad: unsupported kernel size / stride");
 }
 

@@ -4,8 +4,9 @@
 //    output conv (1x1, <= 4 channels) + nn.Sigmoid (models/skip.py:96-98 of the reference) +
 //    optional mask multiply + torch.nn.MSELoss (denoising.ipynb:177,219; inpainting.ipynb:310:
 //    mse(out * mask, img * mask), mean over ALL elements).  HBM-bound: the 128-channel activation
-//    is read once; the scalar loss is reduced wavefront -> LDS tree -> one partial per block, and
-//    the last-arriving block sums the partials in a fixed order (deterministic, no float atomics).
+//    is read once (conv on the 4x4x1 MFMA, one lane per pixel); the scalar loss is reduced per lane
+//    -> LDS tree -> one partial per block, and the last-arriving block sums the partials in a fixed
+//    order (deterministic, no float atomics).
 //  * DipIterState + dip_adam_tick / dip_adam_step_dev / dip_noise_axpy_dev: Adam's step count and
 //    the Philox offset live in device memory, so one optimisation iteration is a STATIC launch list
 //    and can be replayed as a hipGraph (nothing changes on the host between iterations).
@@ -15,60 +16,52 @@ namespace {
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
 
-// block = 256 threads; LPP lanes (power of two, <= 64) share a pixel, lane cg owns channels 4cg..4cg+3
-__global__ __launch_bounds__(256) void loss_head_fwd_kernel(const DipLossHeadDesc d, const int LPP, const int ppb) {
+// One lane = one pixel.  The 1x1 conv towards <= 4 channels runs on v_mfma_f32_4x4x1_16b_f32 (16
+// independent 4x4 outer products per instruction, A of block 0 broadcast with CBSZ = 4):
+//   A[i][k] = w[o = i][c = k]  (lanes 0..3),   B[k][j] = act(u[pixel(lane)][c = k]),   D[i][lane] = y[o = i][pixel]
+// so after Cin K steps every lane holds the 4 outputs of its own pixel: no cross-lane reduction for the
+// conv, NCHW stores / target / mask loads are coalesced across the lanes, and the only reduction left
+// is the scalar loss: per-lane sums -> LDS tree -> one partial per block -> loss_reduce_kernel.
+__global__ __launch_bounds__(256) void loss_head_fwd_kernel(const DipLossHeadDesc d, const int ppb) {
     __shared__ float red[256];
-    __shared__ int is_last;
     const int tid = threadIdx.x;
-    const int cg = tid & (LPP - 1), prow = tid / LPP, rpi = 256 / LPP;
-    const int nc4 = (d.Cin + 3) >> 2;
-    const bool cvalid = cg < nc4;
-    float w[4][4];
-#pragma unroll
-    for (int o = 0; o < 4; ++o)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int c = cg * 4 + e;
-            w[o][e] = (o < d.Cout && c < d.Cin) ? d.w[(size_t)o * d.Cin + c] : 0.f;
-        }
-    f32x4 ta = f32x4{1.f, 1.f, 1.f, 1.f}, tb = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int oi = tid & 3;                                    // A row of this lane (only lanes 0..3 of a wave are read)
+    const int cin4 = (d.Cin + 3) >> 2;
     const bool has_tr = d.tr.a != nullptr;
-    if (has_tr && cvalid) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (cg * 4 + e < d.Cin) { ta[e] = d.tr.a[cg * 4 + e]; tb[e] = d.tr.b[cg * 4 + e]; }
-    }
+    const float slope = d.tr.slope;
     float bias[4];
 #pragma unroll
     for (int o = 0; o < 4; ++o) bias[o] = (d.bias != nullptr && o < d.Cout) ? d.bias[o] : 0.f;
+    const float* wrow = d.w + (size_t)(oi < d.Cout ? oi : 0) * d.Cin;
+    const bool wvalid = oi < d.Cout;
 
     const int p0 = blockIdx.x * ppb, p1 = min(p0 + ppb, d.HW);
     float lsum = 0.f;
-    for (int pb = p0; pb < p1; pb += rpi) {
-        const int p = pb + prow;
+    for (int pb = p0; pb < p1; pb += 256) {
+        const int p = pb + tid;
         const bool pv = p < p1;
-        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (pv && cvalid) {
-            v = *reinterpret_cast<const f32x4*>(d.u + (size_t)p * d.Cu + cg * 4);
-            if (has_tr) {
+        const float* up = d.u + (size_t)(pv ? p : p0) * d.Cu;
+        f32x4 ac4[4];                                          // independent accumulator chains
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = dip_act(fmaf(ta[e], v[e], tb[e]), d.tr.slope);
+        for (int e = 0; e < 4; ++e) ac4[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+        for (int k4 = 0; k4 < cin4; ++k4) {
+            f32x4 b = *reinterpret_cast<const f32x4*>(up + k4 * 4);
+            f32x4 a;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = k4 * 4 + e;
+                a[e] = (wvalid && c < d.Cin) ? wrow[c] : 0.f;
+                if (has_tr) {
+                    const float ta = c < d.Cin ? d.tr.a[c] : 0.f, tb = c < d.Cin ? d.tr.b[c] : 0.f;   // wave-uniform
+                    b[e] = dip_act(fmaf(ta, b[e], tb), slope);
+                }
             }
-        }
-        float acc[4];
 #pragma unroll
-        for (int o = 0; o < 4; ++o) {
-            float s = v[0] * w[o][0];
-            s = fmaf(v[1], w[o][1], s);
-            s = fmaf(v[2], w[o][2], s);
-            s = fmaf(v[3], w[o][3], s);
-            acc[o] = s;
+            for (int e = 0; e < 4; ++e) ac4[e] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[e], b[e], ac4[e], 4, 0, 0);
         }
-        for (int off = LPP >> 1; off >= 1; off >>= 1) {           // wavefront reduction over the pixel's lanes
-#pragma unroll
-            for (int o = 0; o < 4; ++o) acc[o] += __shfl_xor(acc[o], off);
-        }
-        if (pv && cg == 0) {
+        const f32x4 acc = (ac4[0] + ac4[1]) + (ac4[2] + ac4[3]);
+        if (pv) {
 #pragma unroll
             for (int o = 0; o < 4; ++o) {
                 if (o < d.Cout) {
@@ -88,36 +81,33 @@ __global__ __launch_bounds__(256) void loss_head_fwd_kernel(const DipLossHeadDes
             }
         }
     }
-    // block tree (fixed order) -> one partial per block
+    // block tree (fixed order) -> one partial per block; loss_reduce_kernel sums the partials
     red[tid] = lsum;
     __syncthreads();
     for (int s = 128; s >= 1; s >>= 1) {
         if (tid < s) red[tid] += red[tid + s];
         __syncthreads();
     }
-    if (tid == 0) {
-        d.partials[blockIdx.x] = red[0];
-        __threadfence();
-        const unsigned t = atomicAdd(d.ticket, 1u);
-        is_last = (t == gridDim.x - 1);
-    }
-    __syncthreads();
-    if (!is_last) return;
-    __threadfence();
-    // last-arriving block: fixed-order sum of all partials (independent of which block is last)
-    double s = 0.0;
-    for (int i = tid; i < (int)gridDim.x; i += 256) s += (double)__hip_atomic_load(d.partials + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) d.partials[blockIdx.x] = red[0];
+}
+
+// Fixed-order fp64 sum of the per-block partials -> the scalar loss.  A launch of its own on purpose: a
+// "last-arriving block" ticket needs an agent-scope release fence in EVERY block, which on the multi-XCD
+// MI355X writes back / invalidates L2 each time (the ticketed version of this head took 110 us instead
+// of ~35: DESIGN.md, dead ends).
+__global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restrict__ partials, int n, double scale,
+                                                          float* __restrict__ loss) {
     __shared__ double dred[256];
+    const int tid = threadIdx.x;
+    double s = 0.0;
+    for (int i = tid; i < n; i += 256) s += (double)partials[i];
     dred[tid] = s;
     __syncthreads();
     for (int st = 128; st >= 1; st >>= 1) {
         if (tid < st) dred[tid] += dred[tid + st];
         __syncthreads();
     }
-    if (tid == 0) {
-        *d.loss = (float)(dred[0] / ((double)d.Cout * (double)d.HW));
-        *d.ticket = 0u;                                             // re-armed for the next launch / graph replay
-    }
+    if (tid == 0) *loss = (float)(dred[0] * scale);
 }
 
 // dy[p][o] = gscale * 2/N * (out*m - t*m) * m * out*(1-out)       (NHWC, channel stride Cy; pad channels zero)
@@ -169,31 +159,28 @@ __global__ void counter_add_kernel(unsigned long long* c, unsigned long long inc
 
 }  // namespace
 
-static int lpp_of(int Cin) {
-    const int nc4 = (Cin + 3) / 4;
-    int l = 1;
-    while (l < nc4) l <<= 1;
-    return l;
+static int head_ppb(int HW) {
+    int ppb = dip_round_up(dip_cdiv(HW, 1024), 256);      // ~1024 blocks, whole 256-pixel strips
+    return ppb < 256 ? 256 : ppb;
 }
 
 extern "C" int dip_loss_head_nblk(int HW, int Cin) {
-    const int rpi = 256 / lpp_of(Cin);
-    int ppb = dip_cdiv(HW, 1024);
-    ppb = dip_round_up(ppb < rpi * 4 ? rpi * 4 : ppb, rpi);
-    return dip_cdiv(HW, ppb);
+    (void)Cin;
+    return dip_cdiv(HW, head_ppb(HW));
 }
 
 extern "C" int dip_loss_head_fwd(const DipLossHeadDesc* dp, void* stream) {
     const DipLossHeadDesc& d = *dp;
     if (d.Cout < 1 || d.Cout > 4) DIP_FAIL("loss_head: 1..4 output channels");
-    if (d.Cin < 1 || d.Cin > 256 || (d.Cu & 3)) DIP_FAIL("loss_head: Cin must be <= 256 and the channel stride a multiple of 4");
+    if (d.Cin < 1 || (d.Cu & 3) || dip_round_up(d.Cin, 4) > d.Cu) DIP_FAIL("loss_head: channel stride must be a multiple of 4 covering Cin");
     if (d.mask != nullptr && d.mask_c != 1 && d.mask_c != d.Cout) DIP_FAIL("loss_head: mask must have 1 or Cout channels");
-    const int LPP = lpp_of(d.Cin), rpi = 256 / LPP;
-    int ppb = dip_cdiv(d.HW, 1024);
-    ppb = dip_round_up(ppb < rpi * 4 ? rpi * 4 : ppb, rpi);
+    const int ppb = head_ppb(d.HW);
     const int nblk = dip_cdiv(d.HW, ppb);
     if (nblk != d.nblk) DIP_FAIL("loss_head: nblk must come from dip_loss_head_nblk");
-    hipLaunchKernelGGL(loss_head_fwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, d, LPP, ppb);
+    hipLaunchKernelGGL(loss_head_fwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, d, ppb);
+    DIP_CHECK_LAUNCH();
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, d.partials, nblk,
+                       1.0 / ((double)d.Cout * (double)d.HW), d.loss);
     DIP_CHECK_LAUNCH();
     return 0;
 }

@@ -143,7 +143,7 @@ class SkipEngine:
     # ------------------------------------------------------------------ support matrix
     def _check_supported(self):
         for r in self.convs:
-            if r.ks not in (1, 3, 5) or r.stride not in (1, 2) or (r.ks == 1 and r.stride != 1):
+            if r.ks not in (1, 3, 5, 7) or r.stride not in (1, 2) or (r.ks == 1 and r.stride != 1):
                 raise NotImplementedError(f"dip-amd: conv {r.name} k={r.ks} s={r.stride} has no gfx950 kernel")
             m = r.module
             if m.dilation != (1, 1) or m.groups != 1 or m.kernel_size[0] != m.kernel_size[1]:
@@ -236,6 +236,12 @@ class SkipEngine:
         self._alloc.append(t)          # the launch descriptors hold raw pointers: keep every buffer alive
         return t
 
+    def _reset_sizing(self):
+        """Sizes of the shared scratch buffers, accumulated by the sizing pass of the planner."""
+        self.stat_need = self.wg_need = self.wgb_need = self.bwdp_need = self.ws_need = 4
+        self.stat2_need = self.ws2_need = 4            # scratch of the skip-branch convs (side stream)
+        self.bwdp2_need = 4                            # ... and of the skip-branch BatchNorm backward
+
     def _build_plan(self, H, W, Cin_img):
         div = 2 ** self.nscales
         if H % div or W % div:
@@ -243,8 +249,7 @@ class SkipEngine:
                 f"dip-amd: input {H}x{W} must be divisible by 2^{self.nscales} (ragged Concat crop, "
                 "models/common.py:29-37 of the reference, is not implemented)")
         self.H, self.W, self.Cimg = H, W, Cin_img
-        self.stat_need = self.wg_need = self.wgb_need = self.bwdp_need = self.ws_need = 4
-        self.stat2_need = self.ws2_need = 4            # scratch of the skip-branch convs (side stream)
+        self._reset_sizing()
         self._alloc = []
         oc = self.out_conv
         self.n_out = oc.Cout
@@ -261,6 +266,7 @@ class SkipEngine:
                 self.ws_scratch = self._new(self.ws_need)
                 self.stats_scratch2 = self._new(self.stat2_need)
                 self.ws_scratch2 = self._new(self.ws2_need)
+                self.bwd_scratch2 = self._new(self.bwdp2_need)
             self.x_nhwc = self._buf(H * W * round_up(Cin_img, 4))
             xin = Act(self.x_nhwc, H, W, Cin_img)
             last = self._plan_scale(0, xin, H, W)
@@ -328,6 +334,18 @@ class SkipEngine:
         return None if self._sizing else self._new(n)
 
     # ------------------------------------------------------------------ op emitters
+    def _emit_bn_finalize(self, bn: BNRec, scratch, rows, cstride):
+        """Partial rows -> state block + running statistics (dip_bn_finalize).  A separate launch on
+        purpose: finishing inside the producer ("last-arriving workgroup", arrival tickets) was built and
+        measured -- every workgroup then needs an agent-scope release fence, which on the multi-XCD MI355X
+        writes back / invalidates L2 per workgroup: +200 us on a 2048-tile conv launch."""
+        m = bn.module
+        args = (_ptr(scratch), rows, cstride, bn.C, _ptr(self.params, bn.gamma_off), _ptr(self.params, bn.beta_off),
+                float(m.eps), float(m.momentum), _ptr(bn.state), bn.Cs,
+                _ptr(self.bnbuf, bn.rm_off) if bn.rm_off >= 0 else None,
+                _ptr(self.bnbuf, bn.rv_off) if bn.rv_off >= 0 else None)
+        self.fwd_ops.append((self.lib.dip_bn_finalize, args, "bn_fin:" + bn.name))
+
     def _emit_conv_fwd(self, r: ConvRec, x: Act, y, bn: Optional[BNRec]):
         assert x.C == r.Cin, (r.name, x.C, r.Cin)
         Ho = (x.H + 2 * r.P - r.ks) // r.stride + 1
@@ -358,13 +376,7 @@ class SkipEngine:
         lib = self.lib
         self.fwd_ops.append((lib.dip_conv_igemm, (C.byref(d),), "conv_fwd:" + r.name))
         if bn is not None:
-            m = bn.module
-            args = (_ptr(stats_scratch), ntiles, round_up(r.Cout, 32), bn.C, _ptr(self.params, bn.gamma_off),
-                    _ptr(self.params, bn.beta_off), float(m.eps), float(m.momentum),
-                    _ptr(bn.state), bn.Cs,
-                    _ptr(self.bnbuf, bn.rm_off) if bn.rm_off >= 0 else None,
-                    _ptr(self.bnbuf, bn.rv_off) if bn.rv_off >= 0 else None)
-            self.fwd_ops.append((lib.dip_bn_finalize, args, "bn_fin:" + bn.name))
+            self._emit_bn_finalize(bn, stats_scratch, ntiles, round_up(r.Cout, 32))
 
     def _emit_avgpool(self, x, H, W, Cc, y, bn: BNRec):
         Cs = round_up(Cc, 4)
@@ -372,16 +384,9 @@ class SkipEngine:
         if self._sizing:
             self.stat_need = max(self.stat_need, nblk * 3 * Cs)
             return
-        lib = self.lib
-        self.fwd_ops.append((lib.dip_avgpool2_fwd, (_ptr(x), H, W, Cs, Cc, _ptr(y), Cs, _ptr(self.stats_scratch), nblk),
-                             "pool:" + bn.name))
-        m = bn.module
-        args = (_ptr(self.stats_scratch), nblk, Cs, bn.C, _ptr(self.params, bn.gamma_off),
-                _ptr(self.params, bn.beta_off), float(m.eps), float(m.momentum),
-                _ptr(bn.state), bn.Cs,
-                _ptr(self.bnbuf, bn.rm_off) if bn.rm_off >= 0 else None,
-                _ptr(self.bnbuf, bn.rv_off) if bn.rv_off >= 0 else None)
-        self.fwd_ops.append((lib.dip_bn_finalize, args, "bn_fin:" + bn.name))
+        self.fwd_ops.append((self.lib.dip_avgpool2_fwd, (_ptr(x), H, W, Cs, Cc, _ptr(y), Cs, _ptr(self.stats_scratch),
+                                                         nblk), "pool:" + bn.name))
+        self._emit_bn_finalize(bn, self.stats_scratch, nblk, Cs)
 
     def _emit_upcat(self, s, s_act: Optional[Act], deep: Act, cat, H, W):
         Ccat = s.ns + deep.C
@@ -396,21 +401,14 @@ class SkipEngine:
                            _ptr(deep.buf), deep.Cs, deep.C, deep.transform(), H, W, mode, _ptr(cat), Cs_cat,
                            _ptr(self.stats_scratch), nblk)
         self.keep.append(d)
-        bn = s.cat_bn
-        m = bn.module
-        self.fwd_ops.append((self.lib.dip_upcat_fwd, (C.byref(d),), "upcat:" + bn.name))
-        args = (_ptr(self.stats_scratch), nblk, Cs_cat, bn.C, _ptr(self.params, bn.gamma_off),
-                _ptr(self.params, bn.beta_off), float(m.eps), float(m.momentum),
-                _ptr(bn.state), bn.Cs,
-                _ptr(self.bnbuf, bn.rm_off) if bn.rm_off >= 0 else None,
-                _ptr(self.bnbuf, bn.rv_off) if bn.rv_off >= 0 else None)
-        self.fwd_ops.append((self.lib.dip_bn_finalize, args, "bn_fin:" + bn.name))
+        self.fwd_ops.append((self.lib.dip_upcat_fwd, (C.byref(d),), "upcat:" + s.cat_bn.name))
+        self._emit_bn_finalize(s.cat_bn, self.stats_scratch, nblk, Cs_cat)
 
     def _emit_wgrad(self, r: ConvRec, x: Act, dy, ops):
         Ho = (x.H + 2 * r.P - r.ks) // r.stride + 1
         Wo = (x.W + 2 * r.P - r.ks) // r.stride + 1
         CinP, CoutP = round_up(r.Cin, 32), round_up(r.Cout, 32)
-        nsplit = N.wgrad_plan(Ho, Wo, r.Cin, r.Cout, r.ks, r.stride)
+        nsplit, tap_groups, chan_block = N.wgrad_plan2(Ho, Wo, r.Cin, r.Cout, r.ks, r.stride)
         slab = r.ks * r.ks * CinP * CoutP
         if self._sizing:
             self.wg_need = max(self.wg_need, nsplit * slab)
@@ -419,7 +417,8 @@ class SkipEngine:
         has_b = r.b_off >= 0
         d = N.DipWgradDesc(_ptr(x.buf), x.H, x.W, x.Cs, x.C, x.transform(), _ptr(dy), Ho, Wo,
                            round_up(r.Cout, 4), r.Cout, r.ks, r.stride, r.pad_mode, r.P,
-                           _ptr(self.wg_scratch), _ptr(self.wgb_scratch) if has_b else None, nsplit)
+                           _ptr(self.wg_scratch), _ptr(self.wgb_scratch) if has_b else None, nsplit, tap_groups,
+                           chan_block)
         self.keep.append(d)
         ops.append((self.lib.dip_conv_wgrad, (C.byref(d),), "wgrad:" + r.name))
         ops.append((self.lib.dip_wgrad_reduce,
@@ -469,23 +468,28 @@ class SkipEngine:
         self.keep.append(d)
         return d
 
-    def _emit_bn_act_bwd(self, a: Act, g, ops, choff=0, Cg=None):
+    def _emit_bn_act_bwd(self, a: Act, g, ops, choff=0, Cg=None, side=False):
         """BatchNorm(+LeakyReLU) backward of activation `a` given the gradient source g=(buf,pad)
-        wrt the activated value.  Returns the dy buffer (grad wrt a.buf, the conv's raw output)."""
+        wrt the activated value.  Returns the dy buffer (grad wrt a.buf, the conv's raw output).
+        side=True: the op runs on the side stream (skip branch) and gets partial-sum scratch of its own."""
         bn = a.bn
         nblk = self.lib.dip_bn_bwd_nblk(a.H, a.W, a.C)
         if self._sizing:
-            self.bwdp_need = max(self.bwdp_need, nblk * 2 * a.Cs)
+            if side:
+                self.bwdp2_need = max(self.bwdp2_need, nblk * 2 * a.Cs)
+            else:
+                self.bwdp_need = max(self.bwdp_need, nblk * 2 * a.Cs)
             return None
+        scratch = self.bwd_scratch2 if side else self.bwd_scratch
         dz = self._new(a.H * a.W * a.Cs)
         src = self._gradsrc(g, Cg if Cg is not None else a.Cs, choff)
         lib = self.lib
         # phase 1 only reduces (dz = NULL); phase 3 recomputes the masked gradient from the source:
         # 5 tensor passes per BatchNorm instead of 6
         ops.append((lib.dip_bn_bwd_stats, (C.byref(src), _ptr(a.buf), a.H, a.W, a.Cs, a.C, _ptr(bn.state), bn.Cs,
-                                           float(a.slope), None, a.Cs, _ptr(self.bwd_scratch), nblk),
+                                           float(a.slope), None, a.Cs, _ptr(scratch), nblk),
                     "bnb_stats:" + bn.name))
-        ops.append((lib.dip_bn_bwd_finalize, (_ptr(self.bwd_scratch), nblk, bn.Cs, bn.C, a.H * a.W,
+        ops.append((lib.dip_bn_bwd_finalize, (_ptr(scratch), nblk, bn.Cs, bn.C, a.H * a.W,
                                               _ptr(self.grads, bn.gamma_off), _ptr(self.grads, bn.beta_off),
                                               _ptr(bn.coef)), "bnb_fin:" + bn.name))
         ops.append((lib.dip_bn_bwd_apply_src, (C.byref(src), _ptr(a.buf), a.H, a.W, a.Cs, a.C, _ptr(bn.state), bn.Cs,
@@ -531,7 +535,7 @@ class SkipEngine:
         dcat = self._emit_bn_act_bwd(cat, g, ops)            # grad wrt the concat tensor [H,W,Cs_cat]
         dy_s = None
         if s.ns:
-            dy_s = self._emit_bn_act_bwd(st["s_act"], (dcat, 0), ops, choff=0, Cg=cat.Cs)
+            dy_s = self._emit_bn_act_bwd(st["s_act"], (dcat, 0), ops, choff=0, Cg=cat.Cs, side=True)
             self._emit_wgrad(s.skip_conv, xin, dy_s, ops)
         deep = st["deep"]
         dy_deep = self._emit_up_bwd(deep, dcat, cat.Cs, s.ns, H, W, s.upsample_mode, ops)
@@ -569,17 +573,20 @@ class SkipEngine:
             if rc:
                 check(rc, name)
 
-    def _run_two_streams(self, ops, main, on_side_fn, join_before_fn, key):
+    def _run_two_streams(self, ops, main, on_side_fn, join_before_fn, key, deps=None):
         """Launch list on two HIP streams.
         Backward: the weight-gradient kernels (+ their slab reductions) of a layer depend only on that
         layer's dy and the stored activations, not on the data-gradient / BatchNorm-backward chain
-        that continues to the next layer.  Forward: the 1x1 skip-branch conv (+ its BatchNorm
+        that continues to the next layer; the BatchNorm backward of the 4-channel skip branch depends
+        only on the concat gradient.  Forward: the 1x1 skip-branch conv (+ its BatchNorm
         finalisation) of a scale depends only on the scale's input and is needed again at the
         scale's concat, so it runs next to the encoder convs (scratch of its own).
         Fork: an event on the main stream in front of a run of side ops; join: main waits for the
-        side stream in front of every op `join_before_fn` selects and at the end.  The side work
-        fills the partially occupied last round of workgroups / the latency-bound low-resolution
-        kernels of the main stream instead of idling CUs."""
+        side stream in front of every op `join_before_fn` selects and at the end.  `deps` =
+        {consumer op name: producer op name}: the consumer's stream waits for an event recorded right
+        after the producer (finer than a join: the main stream does not wait for the weight-gradient
+        kernels queued behind the producer).  The side work fills the partially occupied last round of
+        workgroups / the latency-bound low-resolution kernels of the main stream instead of idling CUs."""
         if self._side is None or self._side.device != self.device:
             self._side = torch.cuda.Stream(self.device)
             self._events = {}
@@ -587,6 +594,8 @@ class SkipEngine:
         mptr, sptr = main.cuda_stream, side.cuda_stream
         check = N.check
         events = self._events
+        deps = deps or {}
+        producers = set(deps.values())
 
         def event(tag):
             ev = events.get(tag)
@@ -607,9 +616,13 @@ class SkipEngine:
                 ev.record(side)
                 main.wait_event(ev)
                 pending = False
+            if name in deps:
+                (side if on_side else main).wait_event(event((key, "dep", deps[name])))
             rc = fn(*args, sptr if on_side else mptr)
             if rc:
                 check(rc, name)
+            if name in producers:
+                event((key, "dep", name)).record(side if on_side else main)
             pending = pending or on_side
             prev_side = on_side
         if pending:
@@ -618,7 +631,13 @@ class SkipEngine:
             main.wait_event(ev)
 
     def _run_backward_two_streams(self, ops, main):
-        self._run_two_streams(ops, main, lambda n: n.startswith(("wgrad:", "wgred:")), lambda n: False, "bwd")
+        deps = getattr(self, "_bwd_deps", None)
+        if deps is None:         # dgrad+ of a skip conv (main stream) consumes dy of the skip BatchNorm backward (side)
+            deps = self._bwd_deps = {f"dgrad+:s{i}.skip_conv": f"bnb_apply:s{i}.skip_bn"
+                                     for i, sc in enumerate(self.sc) if sc.ns}
+        self._run_two_streams(ops, main,
+                              lambda n: n.startswith(("wgrad:", "wgred:")) or n.endswith(".skip_bn"),
+                              lambda n: False, "bwd", deps)
 
     def _run_forward_two_streams(self, ops, main):
         self._run_two_streams(ops, main, lambda n: n.endswith((".skip_conv", ".skip_bn")),
@@ -671,7 +690,10 @@ class SkipEngine:
                 N.check(lib.dip_loss_head_fwd(C.byref(self._head_desc), stream), "loss_head_fwd")
             if len(self.bns):
                 self.nbt.add_(1)
-        self.last_out = out
+        # (aliases without autograd history: holding the Function's own output tensors would keep the
+        # autograd graph -- and its AccumulateGrad nodes with their recorded stream -- alive until the
+        # next forward, which breaks hipGraph capture on another stream)
+        self.last_out = out.detach()
         self.last_head = head
         return out if head is None else (loss, out)
 

@@ -43,7 +43,8 @@ class DipWgradDesc(C.Structure):
                 ("tr", DipTransform), ("dy", C.c_void_p),
                 ("Hout", C.c_int32), ("Wout", C.c_int32), ("Cdy", C.c_int32), ("Cout", C.c_int32),
                 ("ks", C.c_int32), ("stride", C.c_int32), ("pad_mode", C.c_int32), ("off", C.c_int32),
-                ("partial", C.c_void_p), ("bias_partial", C.c_void_p), ("nsplit", C.c_int32)]
+                ("partial", C.c_void_p), ("bias_partial", C.c_void_p), ("nsplit", C.c_int32),
+                ("tap_groups", C.c_int32), ("chan_block", C.c_int32)]
 
 
 class DipGradSrc(C.Structure):
@@ -66,8 +67,7 @@ class DipLossHeadDesc(C.Structure):
     _fields_ = [("u", C.c_void_p), ("Cu", C.c_int32), ("Cin", C.c_int32), ("tr", DipTransform),
                 ("w", C.c_void_p), ("bias", C.c_void_p), ("Cout", C.c_int32), ("HW", C.c_int32),
                 ("sigmoid", C.c_int32), ("target", C.c_void_p), ("mask", C.c_void_p), ("mask_c", C.c_int32),
-                ("out", C.c_void_p), ("partials", C.c_void_p), ("nblk", C.c_int32), ("ticket", C.c_void_p),
-                ("loss", C.c_void_p)]
+                ("out", C.c_void_p), ("partials", C.c_void_p), ("nblk", C.c_int32), ("loss", C.c_void_p)]
 
 
 _SIGS = {
@@ -87,6 +87,8 @@ _SIGS = {
     "dip_conv_wgrad": (C.c_int, [C.POINTER(DipWgradDesc), C.c_void_p]),
     "dip_conv_wgrad_ntiles": (C.c_int, [C.c_int, C.c_int]),
     "dip_wgrad_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "dip_wgrad_plan2": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
+                                  C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dip_wgrad_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                    C.c_void_p, C.c_void_p]),
     "dip_bn_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
@@ -175,3 +177,10 @@ def wgrad_plan(Hout, Wout, Cin, Cout, ks, stride):
     n = C.c_int()
     check(lib().dip_wgrad_plan(Hout, Wout, Cin, Cout, ks, stride, C.byref(n)), "wgrad_plan")
     return n.value
+
+
+def wgrad_plan2(Hout, Wout, Cin, Cout, ks, stride):
+    """(nsplit, tap_groups, chan_block) of dip_wgrad_plan2."""
+    n, g, cb = C.c_int(), C.c_int(), C.c_int()
+    check(lib().dip_wgrad_plan2(Hout, Wout, Cin, Cout, ks, stride, C.byref(n), C.byref(g), C.byref(cb)), "wgrad_plan2")
+    return n.value, g.value, cb.value

@@ -65,8 +65,11 @@ class FusedAdam:
             if p.grad is not None:
                 if set_to_none:
                     p.grad = None
-                else:
-                    p.grad.detach_()
+                else:                  # torch.optim.Optimizer.zero_grad: views cannot be detached in place
+                    if p.grad.grad_fn is not None:
+                        p.grad = p.grad.detach()
+                    else:
+                        p.grad.requires_grad_(False)
                     p.grad.zero_()
 
     def _signature(self):
@@ -167,15 +170,33 @@ class GraphedIteration:
         self._capture(warmup, device)
 
     @classmethod
-    def group(cls, fits, warmup=3, device=None):
+    def group(cls, fits, warmup=3, device=None, single_graph=False):
         """Grouped multi-instance execution: `fits` = [(optimizer, closure), ...] of INDEPENDENT nets
-        (own weights, own BatchNorm statistics, own Adam state).  Every fit is captured on its own
-        HIP stream inside one graph, so the kernels of different instances overlap on the chip --
-        what fills an MI355X when one image (e.g. the 384x256 snail net: 25 us of math per
-        iteration) cannot."""
+        (own weights, own BatchNorm statistics, own Adam state).  Every fit is captured into its own
+        hipGraph on its own HIP stream and one run() step replays all of them, so the kernels of
+        different instances overlap on the chip -- what fills an MI355X when one image (e.g. the
+        384x256 snail net: 25 us of math per iteration) cannot.
+        single_graph=True captures all fits as concurrent branches of ONE graph instead (one graph
+        launch per iteration; cross-stream capture of this size is fragile in the HIP runtime, so it is
+        opt-in)."""
         self = cls.__new__(cls)
         self.fits = list(fits)
-        self._capture(warmup, device)
+        if single_graph or len(self.fits) == 1:
+            self._capture(warmup, device)
+            return self
+        if device is None:
+            device = self.fits[0][0].params[0].device
+        self.device = device
+        self.iterations = 0
+        self.graph = None
+        self.members = []
+        with torch.cuda.device(device):
+            for opt, clo in self.fits:
+                m = cls.__new__(cls)
+                m.fits = [(opt, clo)]
+                m._capture(warmup, device)
+                self.members.append(m)
+        self.iterations = self.members[0].iterations
         return self
 
     def _one(self, optimizer, closure):
@@ -190,18 +211,24 @@ class GraphedIteration:
         self.iterations = 0
         with torch.cuda.device(device):
             cur = torch.cuda.current_stream(device)
-            warm = torch.cuda.Stream(device)
-            warm.wait_stream(cur)
-            with torch.cuda.stream(warm):
-                for _ in range(max(int(warmup), 1)):
-                    for opt, clo in self.fits:
+            # The eager warm-up runs on the SAME streams the capture uses: autograd caches the stream of
+            # every AccumulateGrad node, and a node created on another stream would pull a dependency on a
+            # non-capturing stream into the capture.
+            self.capture_stream = torch.cuda.Stream(device)
+            self.branch_streams = [torch.cuda.Stream(device) for _ in self.fits[1:]]
+            streams = [self.capture_stream] + self.branch_streams
+            for s in streams:
+                s.wait_stream(cur)
+            for _ in range(max(int(warmup), 1)):
+                for (opt, clo), s in zip(self.fits, streams):
+                    with torch.cuda.stream(s):
                         self._one(opt, clo)
-            cur.wait_stream(warm)
+            for s in streams:
+                cur.wait_stream(s)
             torch.cuda.synchronize(device)
             self.iterations += max(int(warmup), 1)
-            self.branch_streams = [torch.cuda.Stream(device) for _ in self.fits[1:]]
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, stream=self.capture_stream):
                 main = torch.cuda.current_stream(device)
                 start = torch.cuda.Event()
                 start.record(main)
@@ -214,8 +241,19 @@ class GraphedIteration:
                     main.wait_stream(s)                       # join
 
     def run(self, n=1):
-        for _ in range(int(n)):
-            self.graph.replay()
+        if self.graph is not None:
+            for _ in range(int(n)):
+                self.graph.replay()
+        else:                                   # one graph per instance, each on its own stream
+            cur = torch.cuda.current_stream(self.device)
+            for m in self.members:
+                m.capture_stream.wait_stream(cur)
+            for _ in range(int(n)):
+                for m in self.members:
+                    with torch.cuda.stream(m.capture_stream):
+                        m.graph.replay()
+            for m in self.members:
+                cur.wait_stream(m.capture_stream)
         self.iterations += int(n)
 
 

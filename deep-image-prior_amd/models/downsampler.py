@@ -119,14 +119,16 @@ class Downsampler(nn.Module):
             holder.weight.data[c, c] = kt
         self.downsampler_ = holder
         self.register_buffer('_taps', kt.to(torch.float32).contiguous(), persistent=False)
+        self.register_load_state_dict_post_hook(Downsampler._taps_from_weight)
         self.preserve_size = preserve_size
         self._pad = 0
         if preserve_size:
             self._pad = int((k - 1) / 2.) if k % 2 == 1 else int((k - factor) / 2.)
             self.padding = nn.ReplicationPad2d(self._pad)
 
-    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
-        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+    def _taps_from_weight(self, *_):
+        """load_state_dict post-hook: the native path applies `_taps`, so re-derive them from the loaded
+        dense weight and refuse anything that is not one 2-D kernel on the channel diagonal."""
         w = self.downsampler_.weight.detach()
         b = self.downsampler_.bias.detach()
         n = w.shape[0]

@@ -11,9 +11,9 @@ the same arithmetic out as separate PyTorch ops in every closure):
         return total_loss
 
 `head(net_input)` runs the skip-net up to the input of its last conv and then ONE launch
-(dip_loss_head_fwd) for the 1x1 output conv + Sigmoid + mask + MSE, with the scalar reduced by
-wavefront shuffles, an LDS tree and a fixed-order sum of per-block partials; `backward()` starts
-from dip_loss_head_bwd.  The plain `out = net(x); mse(out, t)` spelling keeps working (the head,
+(dip_loss_head_fwd) for the 1x1 output conv + Sigmoid + mask + MSE, with the scalar reduced by an
+LDS tree per block and a fixed-order fp64 sum of the per-block partials; `backward()` starts from
+dip_loss_head_bwd.  The plain `out = net(x); mse(out, t)` spelling keeps working (the head,
 the mask product and the MSE then run as separate kernels); this class is the opt-in fused path.
 """
 import ctypes as C
@@ -58,17 +58,16 @@ class MSEHead:
         oc = eng.out_conv
         nblk = eng.lib.dip_loss_head_nblk(H * W, oc.Cin)
         dev = out.device
-        if self._scratch is None or self._scratch[0].numel() != nblk or self._scratch[0].device != dev:
-            self._scratch = (torch.empty(nblk, dtype=torch.float32, device=dev),
-                             torch.zeros(1, dtype=torch.int32, device=dev))
-        partials, ticket = self._scratch
+        if self._scratch is None or self._scratch.numel() != nblk or self._scratch.device != dev:
+            self._scratch = torch.empty(nblk, dtype=torch.float32, device=dev)
+        partials = self._scratch
         tr = a.transform()
-        self._keep = (out, loss, tr)
+        self._keep = (out.detach(), tr)     # (not `loss`: it becomes the autograd output and would pin the graph)
         ptr = lambda t, off=0: None if t is None else t.data_ptr() + 4 * off
         return N.DipLossHeadDesc(ptr(a.buf), a.Cs, oc.Cin, tr, ptr(eng.params, oc.w_off),
                                  ptr(eng.params, oc.b_off) if oc.b_off >= 0 else None, oc.Cout, H * W,
                                  1 if eng.need_sigmoid else 0, ptr(self.target), ptr(self.mask), self.mask_c,
-                                 ptr(out), ptr(partials), nblk, ptr(ticket), ptr(loss))
+                                 ptr(out), ptr(partials), nblk, ptr(loss))
 
     def __call__(self, net_input):
         import dip_engine

@@ -135,6 +135,9 @@ typedef struct DipWgradDesc {
     float* partial;
     float* bias_partial;          /* or NULL */
     int32_t nsplit;
+    int32_t tap_groups;           /* 3x3 MFMA kernel: the 9 taps are spread over 1, 3 or 9 workgroups (more, lighter
+                                     workgroups for low-resolution layers); 0 = 1.  From dip_wgrad_plan2. */
+    int32_t chan_block;           /* 1x1 MFMA kernel: input channels per workgroup / 32: 4 (default, 0) or 1 */
 } DipWgradDesc;
 int dip_conv_wgrad(const DipWgradDesc* d, void* stream);
 /* number of 4x16 output tiles walked by the wgrad workgroups (upper bound for nsplit) */
@@ -142,6 +145,12 @@ int dip_conv_wgrad_ntiles(int Hout, int Wout);
 /* nsplit (number of partial slabs) to run dip_conv_wgrad with; mandatory for 1x1 convs with
  * Cout <= 8, which take a thin vector-ALU streaming kernel with one slab per block */
 int dip_wgrad_plan(int Hout, int Wout, int Cin, int Cout, int ks, int stride, int* nsplit);
+/* the full launch plan: nsplit plus the tap_groups / chan_block fields of DipWgradDesc.  Large layers
+ * get (nsplit as dip_wgrad_plan, 1, 4); layers with <= 256 pixel tiles (<= 128x128 outputs) trade
+ * taps-per-workgroup and slabs against workgroup count with a small cost model so that a 16x16 layer
+ * runs ~150 light workgroups instead of 4 heavy ones. */
+int dip_wgrad_plan2(int Hout, int Wout, int Cin, int Cout, int ks, int stride, int* nsplit, int* tap_groups,
+                    int* chan_block);
 int dip_wgrad_reduce(const float* partial, const float* bias_partial, int nsplit, int ks, int Cin,
                      int Cout, float* dw /*OIHW*/, float* dbias /*or NULL*/, void* stream);
 
@@ -255,9 +264,9 @@ int dip_counter_add(uint64_t* counter, uint64_t inc, void* stream);
  * the mean runs over ALL Cout*HW elements in both cases).
  *   forward : out[o][p] = sigmoid(sum_c w[o][c] * tr(u[p][c]) + bias[o])            (NCHW)
  *             *loss = 1/(Cout*HW) * sum (out*m - target*m)^2
- *             wavefront reduction over the channels of a pixel, LDS tree per block, one partial per
- *             block, fixed-order sum of the partials in the last-arriving block (ticket):
- *             deterministic, no float atomics.  `ticket` must be zero before the first launch.
+ *             one lane per pixel (conv on the 4x4x1 MFMA), LDS tree per block, one partial per block,
+ *             then a one-block fp64 sum of the partials in a fixed order (second launch inside the
+ *             call): deterministic, no float atomics.
  *   backward: dy[p][o] = *gscale * 2/(Cout*HW) * (out*m - target*m) * m * out*(1-out)  (NHWC, stride Cy)
  *             = grad wrt the output conv's result, consumed by dip_conv_wgrad / dip_conv_igemm. */
 typedef struct DipLossHeadDesc {
@@ -273,7 +282,6 @@ typedef struct DipLossHeadDesc {
     float* out;           /* [Cout][HW] NCHW: the network output */
     float* partials;      /* nblk floats */
     int nblk;             /* dip_loss_head_nblk(HW, Cin) */
-    unsigned* ticket;
     float* loss;          /* 1 float */
 } DipLossHeadDesc;
 int dip_loss_head_nblk(int HW, int Cin);

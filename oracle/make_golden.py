@@ -53,6 +53,13 @@ NETS = {
                      kw=dict(num_channels_down=[16, 32], num_channels_up=[16, 32],
                              num_channels_skip=[4, 4], upsample_mode="bilinear", downsample_mode="avg",
                              need_sigmoid=True, need_bias=True, pad="reflection")),
+    # feature_inversion.ipynb:169-174: per-scale filter sizes 7 / 5 / 3, zero padding, avg-pool
+    # down-sampling, nearest up-sampling, meshgrid input
+    "tiny_feat7": dict(args=(2, 3), hw=(32, 48), seed=7,
+                       kw=dict(num_channels_down=[8, 16, 16], num_channels_up=[8, 16, 16],
+                               num_channels_skip=[4, 4, 4], filter_size_down=[7, 5, 3], filter_size_up=[7, 5, 3],
+                               upsample_mode="nearest", downsample_mode="avg",
+                               need_sigmoid=True, need_bias=True, pad="zero")),
 }
 
 

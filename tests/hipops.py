@@ -114,7 +114,8 @@ def conv_dgrad(dy, w, stride, pad_mode, Hin, Win, split=False):
     return gx
 
 
-def conv_wgrad(x, dy, ks, stride, pad_mode, tr=(None, None, 1.0), nsplit=None, bias=True):
+def conv_wgrad(x, dy, ks, stride, pad_mode, tr=(None, None, 1.0), nsplit=None, bias=True, tap_groups=0,
+               chan_block=0):
     lib = N.lib()
     dev = x.device
     _, Cin, H, W = x.shape
@@ -123,15 +124,18 @@ def conv_wgrad(x, dy, ks, stride, pad_mode, tr=(None, None, 1.0), nsplit=None, b
     xb, dyb = to_nhwc(x), to_nhwc(dy)
     CinP, CoutP = round_up(Cin, 32), round_up(Cout, 32)
     nt = lib.dip_conv_wgrad_ntiles(Ho, Wo)
-    planned = N.wgrad_plan(Ho, Wo, Cin, Cout, ks, stride)
+    planned, pg, pcb = N.wgrad_plan2(Ho, Wo, Cin, Cout, ks, stride)
     thin = ks == 1 and Cout <= 8
-    nsplit = planned if (thin or nsplit == "plan") else (nsplit or max(1, min(nt, 7)))
+    if thin or nsplit == "plan":
+        nsplit, tap_groups, chan_block = planned, pg, pcb
+    else:
+        nsplit = nsplit or max(1, min(nt, 7))
     partial = torch.full((nsplit * ks * ks * CinP * CoutP,), float("nan"), dtype=torch.float32, device=dev)
     bpart = torch.full((nsplit * CoutP,), float("nan"), dtype=torch.float32, device=dev)
     trd, keep = transform(*tr)
     d = N.DipWgradDesc(xb.data_ptr(), H, W, round_up(Cin, 4), Cin, trd, dyb.data_ptr(), Ho, Wo, round_up(Cout, 4),
                        Cout, ks, stride, pad_mode if P > 0 else N.PAD_ZERO, P, partial.data_ptr(),
-                       bpart.data_ptr() if bias else None, nsplit)
+                       bpart.data_ptr() if bias else None, nsplit, tap_groups, chan_block)
     N.check(lib.dip_conv_wgrad(C.byref(d), stream(dev)), "conv_wgrad")
     dw = torch.full((Cout, Cin, ks, ks), float("nan"), dtype=torch.float32, device=dev)
     db = torch.full((Cout,), float("nan"), dtype=torch.float32, device=dev)

@@ -12,7 +12,8 @@ Iteration-1 criterion:
     order of the matrix core, plus an fp32 roundoff floor relative to THAT tensor's norm);
   * the analytically-zero tensors (bias of every conv that feeds a train-mode BatchNorm: the
     BatchNorm subtracts the batch mean, so d loss / d bias == 0 exactly; SURVEY 8c "redundant
-    biases") hold roundoff in both implementations; they are sums of O(max_k ||g_k||) terms that
+    biases"; likewise beta of the concat BatchNorm in front of a reflection-padded conv + BatchNorm)
+    hold roundoff in both implementations; they are sums of O(max_k ||g_k||) terms that
     cancel, so their bound is absolute:  ||g_hip_k|| <= RATIO * ||g_ref32_k|| + ZFLOOR * max_k ||g64_k||.
 The unmasked comparison (against g64n, the oracle's own branch pattern) is reported next to the
 masked one so the effect of imposing the HIP branch pattern stays visible.
@@ -27,19 +28,40 @@ FLOOR = 2e-5       # fp32 roundoff floor, relative to the tensor's own norm
 ZFLOOR = 1e-7      # roundoff floor of the analytically-zero tensors, relative to the largest gradient norm
 
 
-def zero_grad_keys(spec):
-    """Names of the parameters whose gradient is analytically zero: the bias of every conv that is
-    followed by a train-mode BatchNorm (all convs of skip() except the output conv,
-    models/skip.py:57-98 of the reference; with downsample_mode='avg' the pooling in between is
-    linear and shift-preserving, so the statement still holds)."""
+def zero_grad_keys(spec, sd=None):
+    """Names of the parameters whose gradient is analytically zero:
+      * the bias of every conv that is followed by a train-mode BatchNorm (all convs of skip() except
+        the output conv, models/skip.py:57-98 of the reference; with downsample_mode='avg' the pooling
+        in between is linear and shift-preserving, so the statement still holds);
+      * beta of the BatchNorm over the concat (see below);
+      * with the state_dict `sd` given: gamma of a BatchNorm whose beta is all zero (the default
+        initialisation) and whose output reaches, through LeakyReLU (positively homogeneous) and
+        up-sampling / concatenation only, a PER-CHANNEL BatchNorm -- the skip-branch BatchNorm, the last
+        BatchNorm of every scale below the top, and the deepest down_b BatchNorm: scaling one of their
+        channels is undone by the concat BatchNorm, so d loss / d gamma_c == 0 for every channel."""
     keys, _ = O.scale_keys(spec)
     out = set()
-    if not spec.need_bias:
-        return out
-    for k in keys:
-        for c in (k.skip_conv, k.down_a, k.down_b, k.up, k.up1):
-            if c is not None:
-                out.add(c + ".bias")
+    n = spec.n_scales
+    for i, k in enumerate(keys):
+        if spec.need_bias:
+            for c in (k.skip_conv, k.down_a, k.down_b, k.up, k.up1):
+                if c is not None:
+                    out.add(c + ".bias")
+        # beta of the BatchNorm over the concat: it feeds (without an activation) the reflection-padded
+        # decoder conv, whose output BatchNorm removes the per-channel constant a constant input shift
+        # produces (with zero padding the border breaks this, so only for pad == 'reflection')
+        if spec.pad == "reflection":
+            out.add(k.cat_bn + ".bias")
+        if sd is not None:
+            cands = [k.skip_bn] if k.skip_bn else []
+            if i >= 1:
+                cands.append(k.up1_bn if k.up1_bn else k.up_bn)
+            if i == n - 1:
+                cands.append(k.down_b_bn)
+            for b in cands:
+                beta = sd.get(b + ".bias")
+                if beta is not None and float(torch.as_tensor(beta).abs().max()) == 0.0:
+                    out.add(b + ".weight")
     return out
 
 

@@ -54,7 +54,7 @@ def _iter1(dev, net, spec, z, loss_cpu, loss_gpu, tag):
     _, _, g64 = PT.oracle_grads(spec, sd, z, loss_cpu, torch.float64, H.lrelu_masks(net, spec))
     psnr = PT.psnr(out.detach().cpu().numpy(), out32.numpy())
     rel = abs(loss.item() - l32) / abs(l32)
-    rep = PT.grad_report({k: p.grad for k, p in net.named_parameters()}, g64, g32, g64n, PT.zero_grad_keys(spec))
+    rep = PT.grad_report({k: p.grad for k, p in net.named_parameters()}, g64, g32, g64n, PT.zero_grad_keys(spec, sd))
     print(f"{tag}: out PSNR {psnr:.1f} dB, loss rel {rel:.2e}, {PT.fmt(rep)}; oracle fp32 fwd+bwd {t32:.1f} s "
           f"({torch.get_num_threads()} threads)")
     assert psnr >= 100.0, psnr

@@ -55,8 +55,7 @@ def test_planner_launch_lists(built):
     eng._sizing = True
     eng._alloc = []
     eng.H = eng.W = 512
-    eng.stat_need = eng.wg_need = eng.wgb_need = eng.bwdp_need = eng.ws_need = 4
-    eng.stat2_need = eng.ws2_need = 4
+    eng._reset_sizing()
     eng.fwd_ops, eng.bwd_ops, eng.bwd_input_ops, eng.keep = [], [], [], []
     from dip_engine import Act
     last = eng._plan_scale(0, Act(None, 512, 512, 32), 512, 512)

@@ -39,6 +39,10 @@ NETS = {
     "tiny_avg": dict(args=(8, 3), kw=dict(num_channels_down=[16, 32], num_channels_up=[16, 32],
                                           num_channels_skip=[4, 4], upsample_mode="bilinear", downsample_mode="avg",
                                           need_sigmoid=True, need_bias=True, pad="reflection")),
+    "tiny_feat7": dict(args=(2, 3), kw=dict(num_channels_down=[8, 16, 16], num_channels_up=[8, 16, 16],
+                                            num_channels_skip=[4, 4, 4], filter_size_down=[7, 5, 3],
+                                            filter_size_up=[7, 5, 3], upsample_mode="nearest", downsample_mode="avg",
+                                            need_sigmoid=True, need_bias=True, pad="zero")),
 }
 
 
@@ -46,10 +50,10 @@ def _psnr(a, b):
     return O.psnr(np.asarray(a), np.asarray(b))
 
 
-def _grad_report(named_grads, g64, g32, g64n, spec):
+def _grad_report(named_grads, g64, g32, g64n, spec, sd=None):
     """parity.grad_report: purely relative bound per tensor, absolute roundoff floor only for the
-    analytically-zero conv biases (enumerated from the spec)."""
-    rep = PT.grad_report(named_grads, g64, g32, g64n, PT.zero_grad_keys(spec))
+    analytically-zero tensors (enumerated from the spec and, for BatchNorm gammas, the state_dict)."""
+    rep = PT.grad_report(named_grads, g64, g32, g64n, PT.zero_grad_keys(spec, sd))
     return rep["worst"], PT.fmt(rep)
 
 
@@ -84,7 +88,7 @@ def test_golden_reference_vectors(dev, name):
     import hipops
     _, _, g64 = _oracle_grads(_spec(cfg), learn, zc, lf, torch.float64, hipops.lrelu_masks(net, _spec(cfg)))
     _, _, g64n = _oracle_grads(_spec(cfg), learn, zc, lf, torch.float64)
-    worst, wk = _grad_report(grads, g64, {k: gold["grad/" + k] for k in grads}, g64n, _spec(cfg))
+    worst, wk = _grad_report(grads, g64, {k: gold["grad/" + k] for k in grads}, g64n, _spec(cfg), learn)
     print(f"{name}: out PSNR {psnr:.1f} dB, loss rel {rel:.2e}, worst grad err/tol {worst:.2f} ({wk})")
     assert psnr >= 100.0, psnr
     assert rel <= 1e-5, rel
@@ -150,7 +154,7 @@ def test_default_net_64_against_oracle_and_digest(dev):
     _, _, g64n = _oracle_grads(O.default_spec(), sd, z, lf, torch.float64)
     _, l32, g32 = _oracle_grads(O.default_spec(), sd, z, lf, torch.float32)
     assert abs(l32 - dg["loss"]) <= 1e-6 * dg["loss"]           # the oracle reproduces the reference digest
-    worst, wk = _grad_report({k: p.grad for k, p in net.named_parameters()}, g64, g32, g64n, O.default_spec())
+    worst, wk = _grad_report({k: p.grad for k, p in net.named_parameters()}, g64, g32, g64n, O.default_spec(), sd)
     print(f"default net 64x64: worst grad err/tol {worst:.2f} ({wk})")
     assert worst <= 1.0, (worst, wk)
 
@@ -179,7 +183,7 @@ def test_against_oracle_fresh_seed(dev, hw, mode, nskip):
     _, _, g64 = _oracle_grads(spec, sd, z, lf, torch.float64, hipops.lrelu_masks(net, spec))
     psnr = _psnr(out.detach().cpu().numpy(), oo.numpy())
     rel = abs(loss.item() - lo) / lo
-    worst, wk = _grad_report({k: p.grad for k, p in net.named_parameters()}, g64, g32, g64n, spec)
+    worst, wk = _grad_report({k: p.grad for k, p in net.named_parameters()}, g64, g32, g64n, spec, sd)
     print(f"oracle {hw} {mode} skip{nskip}: PSNR {psnr:.1f} dB, loss rel {rel:.2e}, grad err/tol {worst:.2f} ({wk})")
     assert psnr >= 100.0 and rel <= 1e-5 and worst <= 1.0, (psnr, rel, worst, wk)
 
@@ -220,7 +224,7 @@ def test_super_resolution_closure_against_oracle(dev):
     _, _, g64 = _oracle_grads(spec, sd, z, lf, torch.float64, hipops.lrelu_masks(net, spec))
     psnr = _psnr(out.detach().cpu().numpy(), oo.numpy())
     rel = abs(loss.item() - lo) / lo
-    worst, wk = _grad_report({k: p.grad for k, p in net.named_parameters()}, g64, g32, g64n, spec)
+    worst, wk = _grad_report({k: p.grad for k, p in net.named_parameters()}, g64, g32, g64n, spec, sd)
     print(f"SR closure: PSNR {psnr:.1f} dB, loss rel {rel:.2e}, grad err/tol {worst:.2f} ({wk})")
     assert psnr >= 100.0 and rel <= 1e-5 and worst <= 1.0, (psnr, rel, worst, wk)
 

@@ -34,16 +34,16 @@ if [ "${SKIP_BENCH:-0}" != "1" ]; then
   done
   if [ -n "${BENCH_INSTANCES:-}" ]; then
     for cfg in snail library; do
-      TMO=600 run python bench.py --config $cfg --instances $BENCH_INSTANCES --steps 60 --warmup 10 --no-cpu-baseline --no-roofline --no-eager-line
+      TMO=600 run env DIP_TWO_STREAMS=0 python bench.py --config $cfg --instances $BENCH_INSTANCES --steps 60 --warmup 10 --no-cpu-baseline --no-roofline --no-eager-line
       grep '^{"metric"' $LOG | tail -1 > gpurun_out/bench_${cfg}_x$BENCH_INSTANCES.json
     done
   fi
 fi
 if [ "${DO_PROF:-0}" = "1" ]; then
-  ( cd /tmp && TMO=900 run rocprofv3 --kernel-trace --stats -d $ROOTD/gpurun_out/prof1 -o trace -- env DIP_TWO_STREAMS=0 python $ROOTD/bench.py --steps 10 --warmup 3 --no-graph --no-cpu-baseline --no-roofline --no-eager-line )
+  ( cd /tmp && TMO=900 run rocprofv3 --kernel-trace --stats -d $ROOTD/gpurun_out/prof1 -o trace -- env DIP_TWO_STREAMS=0 python $ROOTD/bench.py --steps 10 --warmup 3 --mode eager --no-cpu-baseline --no-roofline --no-eager-line )
   python tools/prof_summary.py gpurun_out/prof1 13 > gpurun_out/prof1_summary.txt 2>> $LOG
   if [ "${DO_PROF2:-0}" = "1" ]; then
-  ( cd /tmp && TMO=900 run rocprofv3 --kernel-trace --stats -d $ROOTD/gpurun_out/prof2 -o trace -- python $ROOTD/bench.py --steps 10 --warmup 3 --no-graph --no-cpu-baseline --no-roofline --no-eager-line )
+  ( cd /tmp && TMO=900 run rocprofv3 --kernel-trace --stats -d $ROOTD/gpurun_out/prof2 -o trace -- python $ROOTD/bench.py --steps 10 --warmup 3 --mode eager --no-cpu-baseline --no-roofline --no-eager-line )
   python tools/prof_summary.py gpurun_out/prof2 13 > gpurun_out/prof2_summary.txt 2>> $LOG
   fi
 fi
@@ -51,7 +51,7 @@ if [ "${DO_PMC:-0}" = "1" ]; then
   # counters in their own passes (no trace domains besides --kernel-trace); the library is preloaded
   # because rocprofv3's counter service crashes on code objects that are dlopen()ed after start-up
   for ctr in FETCH_SIZE WRITE_SIZE; do
-    ( cd /tmp && TMO=600 run rocprofv3 --kernel-trace --pmc $ctr -d $ROOTD/gpurun_out/pmc_$ctr -o pmc -- env LD_PRELOAD=$ROOTD/deep-image-prior_amd/lib/libdip_hip.so python $ROOTD/bench.py --steps 3 --warmup 2 --no-graph --no-cpu-baseline --no-roofline --no-eager-line )
+    ( cd /tmp && TMO=600 run rocprofv3 --kernel-trace --pmc $ctr -d $ROOTD/gpurun_out/pmc_$ctr -o pmc -- env LD_PRELOAD=$ROOTD/deep-image-prior_amd/lib/libdip_hip.so python $ROOTD/bench.py --steps 3 --warmup 2 --mode eager --no-cpu-baseline --no-roofline --no-eager-line )
   done
   python tools/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE > gpurun_out/pmc_traffic.json 2>> $LOG
 fi

@@ -1,5 +1,7 @@
-"""Micro-benchmark of dip_conv_wgrad (+ dip_wgrad_reduce) on the net's big layers; variants of the
-kernel are selected through DIP_WGRAD_* environment switches read at every launch (debug builds)."""
+"""Micro-benchmark of dip_conv_wgrad + dip_wgrad_reduce on the net's layer shapes.
+  python tools/wgrad_sweep.py            planned launch shape of every layer shape
+  python tools/wgrad_sweep.py small      (tap_groups, nsplit) sweep of the <= 128x128 shapes (calibrates dip_wgrad_plan2)
+"""
 import ctypes as C, os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -13,40 +15,70 @@ lib = N.lib()
 st = H.stream(dev)
 
 
-def bench(Cin, Cout, ks, stride, Hh, Ww, use_tr=True, reps=10):
+def bench(Cin, Cout, ks, stride, Hh, Ww, plan=None, use_tr=True, reps=10):
     P = (ks - 1) // 2
     Ho, Wo = Hh // stride, Ww // stride
     x = torch.randn(Hh, Ww, round_up(Cin, 4), device=dev)
     dy = torch.randn(Ho, Wo, round_up(Cout, 4), device=dev)
     CinP, CoutP = round_up(Cin, 32), round_up(Cout, 32)
-    nsplit = N.wgrad_plan(Ho, Wo, Cin, Cout, ks, stride)
+    nsplit, tg, cb = plan or N.wgrad_plan2(Ho, Wo, Cin, Cout, ks, stride)
     partial = torch.empty(nsplit * ks * ks * CinP * CoutP, device=dev)
     bpart = torch.empty(nsplit * CoutP, device=dev)
+    dw = torch.empty(Cout * Cin * ks * ks, device=dev)
+    db = torch.empty(Cout, device=dev)
     a = torch.rand(round_up(Cin, 4), device=dev) + 0.5
     b = torch.randn(round_up(Cin, 4), device=dev) * 0.3
     tr = N.DipTransform(a.data_ptr(), b.data_ptr(), 0.2) if use_tr else N.DipTransform(None, None, 1.0)
     d = N.DipWgradDesc(x.data_ptr(), Hh, Ww, round_up(Cin, 4), Cin, tr, dy.data_ptr(), Ho, Wo, round_up(Cout, 4),
-                       Cout, ks, stride, N.PAD_REFLECT if P else N.PAD_ZERO, P, partial.data_ptr(), bpart.data_ptr(), nsplit)
-    for _ in range(2):
-        N.check(lib.dip_conv_wgrad(C.byref(d), st))
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        lib.dip_conv_wgrad(C.byref(d), st)
-    e1.record(); torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / reps
-    gf = 2.0 * Cout * Ho * Wo * Cin * ks * ks / 1e9
-    return nsplit, us, gf / us * 1e-3
+                       Cout, ks, stride, N.PAD_REFLECT if P else N.PAD_ZERO, P, partial.data_ptr(), bpart.data_ptr(), nsplit,
+                       tg, cb)
 
+    def go():
+        lib.dip_conv_wgrad(C.byref(d), st)
+
+    def red():
+        lib.dip_wgrad_reduce(partial.data_ptr(), bpart.data_ptr(), nsplit, ks, Cin, Cout, dw.data_ptr(), db.data_ptr(), st)
+
+    for _ in range(2):
+        N.check(lib.dip_conv_wgrad(C.byref(d), st)); red()
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    e[0].record()
+    for _ in range(reps):
+        go()
+    e[1].record()
+    for _ in range(reps):
+        red()
+    e[2].record(); torch.cuda.synchronize()
+    us, rus = e[0].elapsed_time(e[1]) * 1e3 / reps, e[1].elapsed_time(e[2]) * 1e3 / reps
+    gf = 2.0 * Cout * Ho * Wo * Cin * ks * ks / 1e9
+    return (nsplit, tg, cb), us, rus, gf / us * 1e-3
+
+
+SHAPES = ((132, 128, 3, 1, 512), (128, 128, 3, 1, 512), (132, 128, 3, 1, 256), (128, 128, 3, 1, 256), (128, 128, 1, 1, 512),
+          (128, 128, 3, 2, 256), (32, 128, 3, 2, 512), (132, 128, 3, 1, 128), (128, 128, 3, 1, 128), (128, 128, 3, 2, 128),
+          (132, 128, 3, 1, 64), (128, 128, 3, 1, 64), (128, 128, 3, 2, 64), (132, 128, 3, 1, 32), (128, 128, 3, 1, 32),
+          (128, 128, 3, 2, 32), (128, 128, 3, 1, 16), (128, 128, 1, 1, 256), (128, 128, 1, 1, 128), (128, 128, 1, 1, 64),
+          (128, 128, 1, 1, 32), (256, 128, 3, 1, 512))
 
 if __name__ == "__main__":
-    variants = ["0"]
-    for rep in range(2):
-        for v in variants:
-            os.environ["DIP_WGRAD_VARIANT"] = v
-            out = []
-            for (Cin, Cout, ks, s, Hh, Ww) in ((132, 128, 3, 1, 512, 512), (128, 128, 3, 1, 512, 512), (132, 128, 3, 1, 256, 256),
-                                               (128, 128, 3, 1, 256, 256), (128, 128, 1, 1, 512, 512), (128, 128, 3, 2, 256, 256)):
-                ns, us, tf = bench(Cin, Cout, ks, s, Hh, Ww)
-                out.append(f"{Cin}>{Cout} k{ks}s{s} {Hh}: {us:7.1f}us {tf:5.1f}TF n={ns}")
-            print(f"variant {v}: " + " | ".join(out), flush=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "small":
+        for (Cin, Cout, ks, s, Hh) in SHAPES:
+            Ho = Hh // s
+            nt = lib.dip_conv_wgrad_ntiles(Ho, Ho)
+            if nt > 256 or ks != 3:
+                continue
+            planned = N.wgrad_plan2(Ho, Ho, Cin, Cout, ks, s)
+            rows = []
+            for g in (1, 3, 9):
+                n = 1
+                while n <= nt:
+                    _, us, rus, tf = bench(Cin, Cout, ks, s, Hh, Hh, plan=(n, g, 1), reps=5)
+                    rows.append((us + rus, g, n, us, rus))
+                    n *= 2
+            rows.sort()
+            best = " ".join(f"g{g}n{n}:{us:.0f}+{rus:.0f}" for _, g, n, us, rus in rows[:6])
+            print(f"{Cin}>{Cout} k{ks}s{s} out{Ho} nt={nt} planned={planned} | {best}", flush=True)
+        sys.exit(0)
+    for (Cin, Cout, ks, s, Hh) in SHAPES:
+        plan, us, rus, tf = bench(Cin, Cout, ks, s, Hh, Hh)
+        print(f"{Cin}>{Cout} k{ks}s{s} {Hh}: {us:7.1f}us +reduce {rus:5.1f}us {tf:5.1f}TF plan={plan}", flush=True)
