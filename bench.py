@@ -261,6 +261,7 @@ def conv_flops(eng):
                 f = dims(r, h, w, attr == "down_a" and s.pool is not None)
                 for pre in ("conv_fwd:", "wgrad:", "dgrad:", "dgrad+:"):
                     fl[pre + r.name] = f
+                fl["dgthin:" + r.name] = 0.0       # thin columns of a 132-column data gradient: time counted, FLOPs are in "dgrad:"
     r = eng.out_conv
     f = dims(r, eng.H, eng.W, False)
     fl["conv_fwd:out"] = fl["wgrad:out"] = fl["dgrad:out"] = f
@@ -276,8 +277,6 @@ def profile_ops(eng, reps=3):
     import torch
     import dip_native as N
     lib = N.lib()
-    for f in (lib.dip_conv_thin4, lib.dip_conv_igemm_dma_cols):      # internal entry points of the dispatcher
-        f.restype, f.argtypes = C.c_int, [C.POINTER(N.DipConvDesc), C.c_int, C.c_void_p]
     lib.dip_conv_igemm_dma.restype, lib.dip_conv_igemm_dma.argtypes = C.c_int, [C.POINTER(N.DipConvDesc), C.c_int, C.c_void_p]
     stream = torch.cuda.current_stream(eng.device)
     sptr = stream.cuda_stream
@@ -342,7 +341,10 @@ def dominant_ops(eng, fl):
             flops = fl[name] * cols / d.Cout
             # compulsory traffic of the launch: input and packed weights read once, output written once
             nbytes = 4.0 * (d.Hin * d.Win * d.Cin + 9 * d.Cin * cols + d.Hout * d.Wout * cols)
-            key = name + "#dma" if v == 3 else (name + "#main" if d.ksplit > 1 else name)
+            if fn is lib.dip_conv_igemm_dma_cols:            # the engine launches the 128-column part itself
+                key = name
+            else:
+                key = name + "#dma" if v == 3 else (name + "#main" if d.ksplit > 1 else name)
             out[key] = (flops, nbytes)
     return out
 

@@ -53,7 +53,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d
     const int half = lane >> 5;
 
     const int split = blockIdx.x;
-    const int cchunk = blockIdx.y;                 // 32*CB input channels
+    // 32*CB input channels.  Workgroups are dispatched in blockIdx order; the ragged tail chunk of a
+    // 132-channel layer is light (2 of 9 MFMAs per K step), so it goes FIRST: its workgroups retire early
+    // and the slots go to the full chunks, instead of forming a lonely last round behind them.
+    const int cchunk = (blockIdx.y + gridDim.y - 1) % gridDim.y;
     const int group = blockIdx.z % C::NGROUPS;     // tap group
     const int nblk = blockIdx.z / C::NGROUPS;      // 128 output channels
     const int tap0 = group * NT;

@@ -203,6 +203,7 @@ __global__ __launch_bounds__(256) void upsample_bwd_stats_kernel(const float* __
 // models/common.py:101-104) + the {count, mean, M2} partials of the BatchNorm that follows;
 // the adjoint spreads dy/4 over the 2x2 window.
 // ------------------------------------------------------------------------------------------
+template <bool MAXP>       // false: nn.AvgPool2d(2, 2), true: nn.MaxPool2d(2, 2)
 __global__ __launch_bounds__(256) void avgpool2_fwd_kernel(const float* __restrict__ x, int W, int Cx, int C,
                                                            float* __restrict__ y, int Hl, int Wl, int Cy, float* stats,
                                                            int ppb) {
@@ -220,7 +221,9 @@ __global__ __launch_bounds__(256) void avgpool2_fwd_kernel(const float* __restri
             const f32x4 v00 = ld4(q), v01 = ld4(q + Cx), v10 = ld4(q + (size_t)W * Cx), v11 = ld4(q + (size_t)W * Cx + Cx);
             f32x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = ((v00[e] + v01[e]) + (v10[e] + v11[e])) * 0.25f;
+            for (int e = 0; e < 4; ++e)
+                v[e] = MAXP ? fmaxf(fmaxf(v00[e], v01[e]), fmaxf(v10[e], v11[e]))
+                            : ((v00[e] + v01[e]) + (v10[e] + v11[e])) * 0.25f;
             st4(y + (size_t)p * Cy + ch, v);
             if (n == 0.f) K = v;
             n += 1.f;
@@ -267,6 +270,51 @@ __global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const float* __restri
     st4(dx + (size_t)p * Cdx + cg * 4, g);
 }
 
+// adjoint of nn.MaxPool2d(2, 2): dy goes to the FIRST maximal element of the 2x2 window in scan order
+// (ATen max_pool2d keeps the running maximum on `val > maxval`), every other position gets 0; the
+// arg-max is recomputed from the pooled layer's input x instead of being stored by the forward
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           int Wl, int Cdy, int Cx, int C, float* __restrict__ dx, int H,
+                                                           int W, int Cdx) {
+    const int nc4 = (C + 3) >> 2;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int Hl = H >> 1;
+    if (i >= (long long)Hl * Wl * nc4) return;
+    const int cg = (int)(i % nc4);
+    const long long p = i / nc4;
+    const int r = (int)(p / Wl), c = (int)(p - (long long)r * Wl);
+    const float* q = x + ((size_t)(2 * r) * W + 2 * c) * Cx + cg * 4;
+    const f32x4 v[4] = {ld4(q), ld4(q + Cx), ld4(q + (size_t)W * Cx), ld4(q + (size_t)W * Cx + Cx)};
+    const f32x4 g = ld4(dy + (size_t)p * Cdy + cg * 4);
+    f32x4 o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        int arg = 0;
+        float m = v[0][e];
+#pragma unroll
+        for (int k = 1; k < 4; ++k)
+            if (v[k][e] > m) { m = v[k][e]; arg = k; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k][e] = (k == arg) ? g[e] : 0.f;
+    }
+    float* d0 = dx + ((size_t)(2 * r) * W + 2 * c) * Cdx + cg * 4;
+    st4(d0, o[0]);
+    st4(d0 + Cdx, o[1]);
+    st4(d0 + (size_t)W * Cdx, o[2]);
+    st4(d0 + (size_t)W * Cdx + Cdx, o[3]);
+    // a floored odd border row / column gets zeros (written by the threads of the last window row / column)
+    const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+    if ((W & 1) && c == Wl - 1) {
+        st4(dx + ((size_t)(2 * r) * W + W - 1) * Cdx + cg * 4, z);
+        st4(dx + ((size_t)(2 * r + 1) * W + W - 1) * Cdx + cg * 4, z);
+    }
+    if ((H & 1) && r == Hl - 1) {
+        st4(dx + ((size_t)(H - 1) * W + 2 * c) * Cdx + cg * 4, z);
+        st4(dx + ((size_t)(H - 1) * W + 2 * c + 1) * Cdx + cg * 4, z);
+        if ((W & 1) && c == Wl - 1) st4(dx + ((size_t)(H - 1) * W + W - 1) * Cdx + cg * 4, z);
+    }
+}
+
 int pixels_per_block(int npix, int C, int* nblk) {
     const int nc4 = (C + 3) / 4;
     int rpi = 256 / nc4;
@@ -298,15 +346,40 @@ extern "C" int dip_upcat_fwd(const DipUpcatDesc* d, void* stream) {
     return 0;
 }
 
-extern "C" int dip_avgpool2_fwd(const float* x, int H, int W, int Cx, int C, float* y, int Cy, float* stats, int nblk,
-                                void* stream) {
-    if (C > 1024) DIP_FAIL("avgpool2_fwd: C > 1024 unsupported");
-    if ((Cx & 3) || (Cy & 3)) DIP_FAIL("avgpool2_fwd: channel strides must be multiples of 4");
+static int pool2_fwd(bool maxp, const float* x, int H, int W, int Cx, int C, float* y, int Cy, float* stats, int nblk,
+                     void* stream) {
+    if (C > 1024) DIP_FAIL("pool2_fwd: C > 1024 unsupported");
+    if ((Cx & 3) || (Cy & 3)) DIP_FAIL("pool2_fwd: channel strides must be multiples of 4");
     int nb;
     const int ppb = pixels_per_block((H / 2) * (W / 2), C, &nb);
-    if (stats != nullptr && nb != nblk) DIP_FAIL("avgpool2_fwd: nblk mismatch (use dip_upcat_nblk(H/2, W/2, C))");
-    hipLaunchKernelGGL(avgpool2_fwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, W, Cx, C, y, H / 2, W / 2, Cy,
-                       stats, ppb);
+    if (stats != nullptr && nb != nblk) DIP_FAIL("pool2_fwd: nblk mismatch (use dip_upcat_nblk(H/2, W/2, C))");
+    if (maxp)
+        hipLaunchKernelGGL(avgpool2_fwd_kernel<true>, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, W, Cx, C, y, H / 2,
+                           W / 2, Cy, stats, ppb);
+    else
+        hipLaunchKernelGGL(avgpool2_fwd_kernel<false>, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, W, Cx, C, y, H / 2,
+                           W / 2, Cy, stats, ppb);
+    DIP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dip_avgpool2_fwd(const float* x, int H, int W, int Cx, int C, float* y, int Cy, float* stats, int nblk,
+                                void* stream) {
+    return pool2_fwd(false, x, H, W, Cx, C, y, Cy, stats, nblk, stream);
+}
+
+extern "C" int dip_maxpool2_fwd(const float* x, int H, int W, int Cx, int C, float* y, int Cy, float* stats, int nblk,
+                                void* stream) {
+    return pool2_fwd(true, x, H, W, Cx, C, y, Cy, stats, nblk, stream);
+}
+
+extern "C" int dip_maxpool2_bwd(const float* dy, const float* x, int H, int W, int Cdy, int Cx, int C, float* dx, int Cdx,
+                                void* stream) {
+    if ((Cdx & 3) || (Cdy & 3) || (Cx & 3)) DIP_FAIL("maxpool2_bwd: channel strides must be multiples of 4");
+    const long long n = (long long)(H / 2) * (W / 2) * ((C + 3) / 4);
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, x,
+                       W / 2, Cdy, Cx, C, dx, H, W, Cdx);
     DIP_CHECK_LAUNCH();
     return 0;
 }

@@ -293,12 +293,12 @@ class SkipEngine:
             self._emit_conv_fwd(s.skip_conv, xin, st["s_y"], s.skip_bn)
             st["s_act"] = Act(st["s_y"], H, W, s.ns, s.skip_bn, self.slope)
         st["d1_y"] = self._buf(Hl * Wl * round_up(s.down_a.Cout, 4))
-        if s.pool == 'avg':
-            # conv(..., downsample_mode='avg'), models/common.py:101-104: full-resolution conv, then the
+        if s.pool in ('avg', 'max'):
+            # conv(..., downsample_mode='avg' | 'max'), models/common.py:101-104: full-resolution conv, then the
             # pooling pass produces the BatchNorm partials of the pooled tensor
             st["d1_full"] = self._buf(H * W * round_up(s.down_a.Cout, 4))
             self._emit_conv_fwd(s.down_a, xin, st["d1_full"], None)
-            self._emit_avgpool(st["d1_full"], H, W, s.down_a.Cout, st["d1_y"], s.down_a_bn)
+            self._emit_avgpool(st["d1_full"], H, W, s.down_a.Cout, st["d1_y"], s.down_a_bn, s.pool)
         else:
             self._emit_conv_fwd(s.down_a, xin, st["d1_y"], s.down_a_bn)
         d1 = Act(st["d1_y"], Hl, Wl, s.down_a.Cout, s.down_a_bn, self.slope)
@@ -378,14 +378,14 @@ class SkipEngine:
         if bn is not None:
             self._emit_bn_finalize(bn, stats_scratch, ntiles, round_up(r.Cout, 32))
 
-    def _emit_avgpool(self, x, H, W, Cc, y, bn: BNRec):
+    def _emit_avgpool(self, x, H, W, Cc, y, bn: BNRec, kind='avg'):
         Cs = round_up(Cc, 4)
         nblk = self.lib.dip_upcat_nblk(H // 2, W // 2, Cc)
         if self._sizing:
             self.stat_need = max(self.stat_need, nblk * 3 * Cs)
             return
-        self.fwd_ops.append((self.lib.dip_avgpool2_fwd, (_ptr(x), H, W, Cs, Cc, _ptr(y), Cs, _ptr(self.stats_scratch),
-                                                         nblk), "pool:" + bn.name))
+        fn = self.lib.dip_maxpool2_fwd if kind == 'max' else self.lib.dip_avgpool2_fwd
+        self.fwd_ops.append((fn, (_ptr(x), H, W, Cs, Cc, _ptr(y), Cs, _ptr(self.stats_scratch), nblk), "pool:" + bn.name))
         self._emit_bn_finalize(bn, self.stats_scratch, nblk, Cs)
 
     def _emit_upcat(self, s, s_act: Optional[Act], deep: Act, cat, H, W):
@@ -459,7 +459,15 @@ class SkipEngine:
                           _ptr(gbuf), Hg, Wg, Cg, r.Cin, 0, r.ks, 1, N.PAD_ZERO, off, r.stride, 0, None,
                           ksplit, _ptr(self.ws_scratch) if ksplit > 1 else None)
         self.keep.append(d)
-        ops.append((self.lib.dip_conv_igemm, (C.byref(d),), "dgrad:" + r.name))
+        if self.lib.dip_conv_variant(C.byref(d)) == 3 and self.two_streams:
+            # 132-column data gradient = 4 thin columns on the vector ALU + 128 columns on the LDS-DMA kernel:
+            # two launches that write disjoint columns, so the thin one goes to the side stream
+            # (_run_backward_two_streams makes the BatchNorm backward of the concat wait for it)
+            ncols = r.Cin - 128
+            ops.append((self.lib.dip_conv_thin4, (C.byref(d), ncols), "dgthin:" + r.name))
+            ops.append((self.lib.dip_conv_igemm_dma_cols, (C.byref(d), ncols), "dgrad:" + r.name))
+        else:
+            ops.append((self.lib.dip_conv_igemm, (C.byref(d),), "dgrad:" + r.name))
         return (gbuf, pad)
 
     def _gradsrc(self, g, Cg, choff=0):
@@ -548,12 +556,17 @@ class SkipEngine:
         self._emit_wgrad(s.down_b, st["d1"], dy_d2, ops)
         g = self._emit_dgrad(s.down_b, st["d1"], dy_d2, ops)
         dy_d1 = self._emit_bn_act_bwd(st["d1"], g, ops)
-        if s.pool == 'avg':                 # adjoint of AvgPool2d(2, 2): dy of the full-resolution conv output
+        if s.pool in ('avg', 'max'):        # adjoint of the pooling: dy of the full-resolution conv output
             Cs1 = round_up(s.down_a.Cout, 4)
             dy_full = self._buf(H * W * Cs1)
             if not self._sizing:
-                ops.append((self.lib.dip_avgpool2_bwd, (_ptr(dy_d1), H, W, Cs1, s.down_a.Cout, _ptr(dy_full), Cs1),
-                            "poolb:" + s.down_a_bn.name))
+                if s.pool == 'avg':
+                    ops.append((self.lib.dip_avgpool2_bwd, (_ptr(dy_d1), H, W, Cs1, s.down_a.Cout, _ptr(dy_full), Cs1),
+                                "poolb:" + s.down_a_bn.name))
+                else:                       # MaxPool2d(2, 2): the arg-max is recomputed from the conv output
+                    ops.append((self.lib.dip_maxpool2_bwd, (_ptr(dy_d1), _ptr(st["d1_full"]), H, W, Cs1, Cs1,
+                                                            s.down_a.Cout, _ptr(dy_full), Cs1),
+                                "poolb:" + s.down_a_bn.name))
             dy_d1 = dy_full
         self._emit_wgrad(s.down_a, xin, dy_d1, ops)
         tgt = ops if i > 0 else self.bwd_input_ops
@@ -631,12 +644,17 @@ class SkipEngine:
             main.wait_event(ev)
 
     def _run_backward_two_streams(self, ops, main):
-        deps = getattr(self, "_bwd_deps", None)
+        deps = self._bwd_deps if getattr(self, "_bwd_deps_for", None) is ops else None
+        self._bwd_deps_for = ops
         if deps is None:         # dgrad+ of a skip conv (main stream) consumes dy of the skip BatchNorm backward (side)
             deps = self._bwd_deps = {f"dgrad+:s{i}.skip_conv": f"bnb_apply:s{i}.skip_bn"
                                      for i, sc in enumerate(self.sc) if sc.ns}
+            # ... and the concat's BatchNorm backward consumes the thin columns of the decoder conv's data gradient
+            deps.update({f"bnb_stats:s{i}.cat_bn": f"dgthin:s{i}.up" for i in range(len(self.sc))})
+            present = {name for _, _, name in ops}          # (a wait on a never-recorded event is illegal under capture)
+            deps = self._bwd_deps = {c: p for c, p in deps.items() if c in present and p in present}
         self._run_two_streams(ops, main,
-                              lambda n: n.startswith(("wgrad:", "wgred:")) or n.endswith(".skip_bn"),
+                              lambda n: n.startswith(("wgrad:", "wgred:", "dgthin:")) or n.endswith(".skip_bn"),
                               lambda n: False, "bwd", deps)
 
     def _run_forward_two_streams(self, ops, main):

@@ -82,6 +82,8 @@ _SIGS = {
     "dip_conv_ntiles": (C.c_int, [C.c_int, C.c_int]),
     "dip_conv_variant": (C.c_int, [C.POINTER(DipConvDesc)]),
     "dip_conv_splitk_finish": (C.c_int, [C.POINTER(DipConvDesc), C.c_void_p]),
+    "dip_conv_thin4": (C.c_int, [C.POINTER(DipConvDesc), C.c_int, C.c_void_p]),
+    "dip_conv_igemm_dma_cols": (C.c_int, [C.POINTER(DipConvDesc), C.c_int, C.c_void_p]),
     "dip_conv_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
                                 C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "dip_conv_wgrad": (C.c_int, [C.POINTER(DipWgradDesc), C.c_void_p]),
@@ -109,6 +111,10 @@ _SIGS = {
     "dip_avgpool2_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                    C.c_int, C.c_void_p]),
     "dip_avgpool2_bwd": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "dip_maxpool2_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                   C.c_int, C.c_void_p]),
+    "dip_maxpool2_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                   C.c_int, C.c_void_p]),
     "dip_upsample_bwd_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                          C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int,
                                          C.c_void_p, C.c_int, C.c_void_p]),

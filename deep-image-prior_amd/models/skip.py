@@ -140,11 +140,13 @@ def skip(
         sp['down_a'], sp['down_a_bn'] = deep_path + ['1'], deep_path + ['2']
         sp['down_b'], sp['down_b_bn'] = deep_path + ['4'], deep_path + ['5']
         sp['pool'] = None
-        if downsample_mode[i] == 'avg':
-            sp['pool'] = 'avg'             # stride-1 conv + AvgPool2d(2, 2): dip_avgpool2_fwd/bwd
+        if downsample_mode[i] in ('avg', 'max'):
+            sp['pool'] = downsample_mode[i]     # stride-1 conv + AvgPool2d / MaxPool2d(2, 2): dip_{avg,max}pool2_fwd/bwd
         elif downsample_mode[i] != 'stride':
-            sp['unsupported'] = (f"downsample_mode={downsample_mode[i]!r} (max-pooling / Lanczos after a stride-1 "
-                                 "conv) has no gfx950 kernel yet")
+            # 'lanczos2' / 'lanczos3': the reference puts a Downsampler with a TRAINABLE dense nf x nf x 8 x 8
+            # (12 x 12) conv weight behind the stride-1 conv (models/common.py:107-110): no kernel for that
+            sp['unsupported'] = (f"downsample_mode={downsample_mode[i]!r} (a trainable dense Lanczos Downsampler "
+                                 "after a stride-1 conv) has no gfx950 kernel")
 
         inner = nn.Sequential()
         if i != n - 1:

@@ -116,6 +116,12 @@ int dip_conv_plan(int Hout, int Wout, int Cin, int Cout, int ks, int stride, int
  * (3x3, 129..160 output channels, split-K), 3 = conv_thin4_kernel (columns 0..Cout-129 on the vector ALU)
  * + conv_igemm_dma_kernel (the other 128 columns): 3x3 data gradients towards a 132-channel tensor */
 int dip_conv_variant(const DipConvDesc* d);
+/* The two launches behind variant 3, exported so that a caller can put them on DIFFERENT streams (they
+ * write disjoint columns of the same output): columns [0, ncols) (ncols = Cout - 128 <= 4) of a 3x3
+ * stride-1 transform-free convolution on the vector ALU, and one 128-column block starting at column
+ * n_base on the LDS-DMA kernel.  Same descriptor as dip_conv_igemm. */
+int dip_conv_thin4(const DipConvDesc* d, int ncols, void* stream);
+int dip_conv_igemm_dma_cols(const DipConvDesc* d, int n_base, void* stream);
 /* second half of a split-K dispatch (d->ksplit > 1): fixed-order sum of the workspace slices, bias,
  * store, BatchNorm partials.  dip_conv_igemm calls it itself; exported for per-kernel timing. */
 int dip_conv_splitk_finish(const DipConvDesc* d, void* stream);
@@ -216,6 +222,13 @@ int dip_upcat_nblk(int H, int W, int C);
 int dip_avgpool2_fwd(const float* x, int H, int W, int Cx, int C, float* y, int Cy, float* stats, int nblk,
                      void* stream);
 int dip_avgpool2_bwd(const float* dy, int H, int W, int Cdy, int C, float* dx, int Cdx, void* stream);
+/* nn.MaxPool2d(2,2) behind a stride-1 conv (conv(..., downsample_mode='max'), models/common.py:105-106):
+ * same contract as dip_avgpool2_fwd; the adjoint routes dy to the first maximal element of each 2x2
+ * window of x (ATen's tie rule), recomputing the arg-max from x, zeros elsewhere. */
+int dip_maxpool2_fwd(const float* x, int H, int W, int Cx, int C, float* y, int Cy, float* stats, int nblk,
+                     void* stream);
+int dip_maxpool2_bwd(const float* dy, const float* x, int H, int W, int Cdy, int Cx, int C, float* dx, int Cdx,
+                     void* stream);
 
 /* Adjoint of the 2x upsample fused with the LeakyReLU/BatchNorm backward phase 1 of the
  * deeper branch: du_d = upsample2x^T(dcat[:, choff:choff+nd]); dz = du_d * lrelu'(a*y+b);

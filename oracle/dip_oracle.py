@@ -63,7 +63,7 @@ class SkipSpec:
     pad: str = "zero"
     upsample_mode: Sequence[str] | str = "nearest"
     need1x1_up: bool = True
-    downsample_mode: Sequence[str] | str = "stride"      # 'stride' | 'avg' (models/common.py:99-112)
+    downsample_mode: Sequence[str] | str = "stride"      # 'stride' | 'avg' | 'max' (models/common.py:99-112)
 
     def __post_init__(self):
         n = len(self.num_channels_down)
@@ -232,9 +232,11 @@ def skip_forward(spec: SkipSpec, sd: Dict[str, torch.Tensor], x: torch.Tensor,
         fd, fu = spec.filter_size_down[i], spec.filter_size_up[i]
         if spec.downsample_mode[i] == "stride":
             d = _conv(x, sd, k.down_a, fd, 2, spec.pad)
-        else:                               # conv(): stride-1 conv followed by nn.AvgPool2d(2, 2), common.py:101-104
-            assert spec.downsample_mode[i] == "avg", spec.downsample_mode[i]
+        elif spec.downsample_mode[i] == "avg":   # conv(): stride-1 conv followed by nn.AvgPool2d(2, 2), common.py:101-104
             d = F.avg_pool2d(_conv(x, sd, k.down_a, fd, 1, spec.pad), 2, 2)
+        else:                               # ... or nn.MaxPool2d(2, 2), common.py:105-106
+            assert spec.downsample_mode[i] == "max", spec.downsample_mode[i]
+            d = F.max_pool2d(_conv(x, sd, k.down_a, fd, 1, spec.pad), 2, 2)
         d = _bn_act(d, sd, k.down_a_bn, masks=masks)
         d = _conv(d, sd, k.down_b, fd, 1, spec.pad)
         d = _bn_act(d, sd, k.down_b_bn, masks=masks)

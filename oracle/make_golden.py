@@ -53,6 +53,11 @@ NETS = {
                      kw=dict(num_channels_down=[16, 32], num_channels_up=[16, 32],
                              num_channels_skip=[4, 4], upsample_mode="bilinear", downsample_mode="avg",
                              need_sigmoid=True, need_bias=True, pad="reflection")),
+    # conv(..., downsample_mode='max'), models/common.py:105-106 (no notebook uses it)
+    "tiny_max": dict(args=(8, 3), hw=(32, 48), seed=8,
+                     kw=dict(num_channels_down=[16, 32], num_channels_up=[16, 32],
+                             num_channels_skip=[4, 4], upsample_mode="bilinear", downsample_mode="max",
+                             need_sigmoid=True, need_bias=True, pad="reflection")),
     # feature_inversion.ipynb:169-174: per-scale filter sizes 7 / 5 / 3, zero padding, avg-pool
     # down-sampling, nearest up-sampling, meshgrid input
     "tiny_feat7": dict(args=(2, 3), hw=(32, 48), seed=7,

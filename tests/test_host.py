@@ -110,7 +110,7 @@ def test_no_silent_fallback():
     bad = skip(4, 3, [8, 8], [8, 8], [4, 4], act_fun="Swish")
     with pytest.raises(NotImplementedError):
         bad(torch.zeros(1, 4, 16, 16))
-    mx = skip(4, 3, [8, 8], [8, 8], [4, 4], downsample_mode="max")     # ('avg' has kernels, 'max' does not)
+    mx = skip(4, 3, [8, 8], [8, 8], [4, 4], downsample_mode="lanczos2")     # ('avg' / 'max' have kernels, Lanczos does not)
     with pytest.raises(NotImplementedError):
         mx(torch.zeros(1, 4, 16, 16))
     with pytest.raises(NotImplementedError):
