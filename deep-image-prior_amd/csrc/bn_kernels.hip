@@ -309,12 +309,12 @@ __global__ __launch_bounds__(256) void fold_to_nchw_kernel(const DipGradSrc src,
 }
 
 __host__ int pixels_per_block(int npix, int C, int* nblk) {
-    // ~1024 blocks, at least 8 row-iterations each
+    // ~1024 blocks for large tensors; small ones: two pixels per thread
     const int nc4 = (C + 3) / 4;
     int rpi = 256 / nc4;
     if (rpi < 1) rpi = 1;
     int ppb = dip_cdiv(npix, 1024);
-    if (ppb < rpi * 8) ppb = rpi * 8;
+    if (ppb < rpi * 2) ppb = rpi * 2;      // small tensors: few sequential pixels per thread (latency-bound)
     *nblk = dip_cdiv(npix, ppb);
     return ppb;
 }

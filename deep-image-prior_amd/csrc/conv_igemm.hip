@@ -357,7 +357,14 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
             f32x4 v = bias;
             const float* wp0 = ws + (size_t)p * d.Cy + ch;
             int k = 0;
-            for (; k + 4 <= ksplit; k += 4) {           // 4 independent loads in flight, fixed add order
+            for (; k + 8 <= ksplit; k += 8) {           // 8 independent loads in flight, fixed add order
+                f32x4 t[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) t[q] = *reinterpret_cast<const f32x4*>(wp0 + (size_t)(k + q) * zs);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v += t[q];
+            }
+            for (; k + 4 <= ksplit; k += 4) {
                 const f32x4 t0 = *reinterpret_cast<const f32x4*>(wp0 + (size_t)(k + 0) * zs);
                 const f32x4 t1 = *reinterpret_cast<const f32x4*>(wp0 + (size_t)(k + 1) * zs);
                 const f32x4 t2 = *reinterpret_cast<const f32x4*>(wp0 + (size_t)(k + 2) * zs);
@@ -404,8 +411,10 @@ int finish_ppb(int npix, int Cy, int* nblk) {
     const int nc4 = Cy / 4;
     int rpi = 256 / nc4;
     if (rpi < 1) rpi = 1;
+    // <= 512 blocks; small images get one pixel row per thread (a split-K layer is latency-bound: 8 blocks
+    // of 4 sequential pixels per thread took 14 us for a 16x16 layer, mostly dependent round trips)
     int ppb = dip_cdiv(npix, 512);
-    if (ppb < rpi * 4) ppb = rpi * 4;
+    if (ppb < rpi) ppb = rpi;
     *nblk = dip_cdiv(npix, ppb);
     return ppb;
 }

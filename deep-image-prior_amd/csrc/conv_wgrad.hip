@@ -40,7 +40,7 @@ __device__ __forceinline__ int wmap_src(int v, int n_in, int reflect) {
 
 template <int KS, int S, int NT, int CB>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d, const int ntx, const int ntiles,
-                                                            const int CinP, const int CoutP) {
+                                                            const int CinP, const int CoutP, const int ragged_parts) {
     using C = WCfg<KS, S, NT, CB>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Us = smem;
@@ -56,11 +56,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d
     // 32*CB input channels.  Workgroups are dispatched in blockIdx order; the ragged tail chunk of a
     // 132-channel layer is light (2 of 9 MFMAs per K step), so it goes FIRST: its workgroups retire early
     // and the slots go to the full chunks, instead of forming a lonely last round behind them.
-    const int cchunk = (blockIdx.y + gridDim.y - 1) % gridDim.y;
+    // (With ragged_parts > 0 there are no tail workgroups at all: see phase 2 below.)
+    const int cchunk = ragged_parts > 0 ? (int)blockIdx.y : (int)((blockIdx.y + gridDim.y - 1) % gridDim.y);
     const int group = blockIdx.z % C::NGROUPS;     // tap group
     const int nblk = blockIdx.z / C::NGROUPS;      // 128 output channels
     const int tap0 = group * NT;
-    const int c0 = cchunk * C::CW;
+    int c0 = cchunk * C::CW;
     const int o0 = nblk * 128;
     const bool wave_active = (o0 + wave * 32) < CoutP;
     const bool do_bias = (d.bias_partial != nullptr) && cchunk == 0 && group == 0;
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d
     const bool has_tr = d.tr.a != nullptr;
     const float slope = d.tr.slope;
     const int c4 = tid & (C::CW / 4 - 1);          // this thread's 4-channel group in the staging
-    const bool cvalid = (c0 + c4 * 4) < d.Cin;
+    bool cvalid = (c0 + c4 * 4) < d.Cin;
     f32x4 ta = f32x4{1.f, 1.f, 1.f, 1.f}, tb = f32x4{0.f, 0.f, 0.f, 0.f};
     if (has_tr && cvalid) {
         ta = *reinterpret_cast<const f32x4*>(d.tr.a + c0 + c4 * 4);
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d
     // (tap, channel) pairs -- taps 0..7 in accumulator 0, tap 8 in rows 0..3 of accumulator 1 -- so the
     // chunk costs 2 MFMAs per K step instead of 9 with 28 of 32 rows idle.
     constexpr bool CAN_PACK = (KS == 3) && (NT == 9) && (CB == 1);
-    const bool pack = CAN_PACK && (d.Cin - c0 <= 4);
+    bool pack = CAN_PACK && (d.Cin - c0 <= 4);
     // accumulators 0 and 1 read through per-lane offsets so that the packed chunk shares the loop
     int aoff0 = l31, aoff1 = C::CW + l31;                        // taps 0 and 1, row = channel l31
     if (pack) {
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d
     // the barrier that ends tile t's reads.  Without it a workgroup alternated between a load phase
     // and an MFMA phase and only the co-resident workgroup could fill the gaps.
     f32x4 ureg[C::U_SLOTS], dreg[8];
-    auto fetch = [&](int tile) {
+    auto fetch = [&](int tile) __attribute__((always_inline)) {
         const int ty = tile / ntx, tx = tile - ty * ntx;
 #pragma unroll
         for (int i = 0; i < C::U_SLOTS; ++i) {
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d
             dreg[i] = v;
         }
     };
-    auto commit = [&]() {                  // registers -> LDS, producer BatchNorm+LeakyReLU on the way
+    auto commit = [&]() __attribute__((always_inline)) {                  // registers -> LDS, producer BatchNorm+LeakyReLU on the way
 #pragma unroll
         for (int i = 0; i < C::U_SLOTS; ++i) {
             const int f = tid + i * 256;
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d
     // (the stride-2 and 5x5 halos are too large to park next to the accumulators without spilling:
     // those variants stage global -> LDS directly, slot by slot)
     constexpr bool PF = (KS <= 3) && (S == 1);
-    auto stage_direct = [&](int tile) {
+    auto stage_direct = [&](int tile) __attribute__((always_inline)) {
         const int ty = tile / ntx, tx = tile - ty * ntx;
 #pragma unroll
         for (int i = 0; i < C::U_SLOTS; ++i) {
@@ -188,12 +189,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d
             *reinterpret_cast<f32x4*>(Ds + f * 4) = v;
         }
     };
-    if (PF && split < ntiles) fetch(split);
-    for (int tile = split; tile < ntiles; tile += d.nsplit) {
+    auto walk = [&](const int first, const int step) __attribute__((always_inline)) {      // the pixel tiles first, first + step, ...
+    if (PF && first < ntiles) fetch(first);
+    for (int tile = first; tile < ntiles; tile += step) {
         __syncthreads();                   // every wave is done with the previous tile
         if constexpr (PF) commit(); else stage_direct(tile);
         __syncthreads();
-        if (PF && tile + d.nsplit < ntiles) fetch(tile + d.nsplit);
+        if (PF && tile + step < ntiles) fetch(tile + step);
         if (wave_active) {
             if constexpr (CAN_PACK) {
 #pragma unroll 2
@@ -236,6 +238,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d
             }
         }
     }
+    };
+    walk(split, d.nsplit);
 
     // ---- write this workgroup's partial slab ----
     if (pack) {
@@ -249,6 +253,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d
                 d.partial[(((size_t)split * 9 + (m >> 2)) * CinP + c) * CoutP + o] = acc[0][r];
                 if (m < 4) d.partial[(((size_t)split * 9 + 8) * CinP + c) * CoutP + o] = acc[(NT * CB > 1) ? 1 : 0][r];
             }
+        }
+        if (c0 > 0) {          // the slab reduction sums the 8 four-row parts of a tail chunk: parts 1..7 are zero here
+#pragma unroll 1
+            for (int t = 0; t < 9; ++t)
+                for (int rr = 4 + half; rr < 32; rr += 2)
+                    if (c0 + rr < CinP) d.partial[(((size_t)split * 9 + t) * CinP + c0 + rr) * CoutP + o] = 0.f;
         }
         if (do_bias) {
             const float tot = bsum + __shfl_xor(bsum, 32);
@@ -276,6 +286,53 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d
             if (half == 0) d.bias_partial[(size_t)split * CoutP + o] = tot;
         }
     }
+
+    // ---- phase 2: the ragged <= 4-channel tail of a 132-channel layer, shared out ------------------
+    // A tail chunk of its own was 128 extra light workgroups behind 512 heavy ones = a lonely second
+    // round (+25 % time for 3 % of the FLOPs).  Instead every full-chunk workgroup also does its share
+    // (every ragged_parts-th tile of its split) of the tail in the (tap, channel)-packed form -- 2 MFMAs per
+    // K step -- and writes it as part `cchunk` (rows CinMain + 4*cchunk ..+3) of the tail's 32 slab rows;
+    // the slab reduction adds the parts.
+    if constexpr (CAN_PACK) {
+        if (ragged_parts > 0) {
+            __syncthreads();
+            const int CinMain = d.Cin & ~31;
+            c0 = CinMain;
+            cvalid = (c0 + c4 * 4) < d.Cin;
+            ta = f32x4{1.f, 1.f, 1.f, 1.f};
+            tb = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (has_tr && cvalid) {
+                ta = *reinterpret_cast<const f32x4*>(d.tr.a + c0 + c4 * 4);
+                tb = *reinterpret_cast<const f32x4*>(d.tr.b + c0 + c4 * 4);
+            }
+            pack = true;
+            {
+                const int ptap = l31 >> 2, pch = l31 & 3;
+                aoff0 = ((ptap / 3) * C::HTW + (ptap % 3)) * C::CW + pch;
+                aoff1 = (2 * C::HTW + 2) * C::CW + pch;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+            walk(split + cchunk * d.nsplit, d.nsplit * ragged_parts);
+            if (wave_active) {
+                const int o = o0 + wave * 32 + l31;
+                const int cbase = CinMain + 4 * cchunk;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = (r & 3) + 8 * (r >> 2) + 4 * half;       // row = tap * 4 + channel
+                    const int c = cbase + (m & 3);
+                    d.partial[(((size_t)split * 9 + (m >> 2)) * CinP + c) * CoutP + o] = acc[0][r];
+                    if (m < 4) d.partial[(((size_t)split * 9 + 8) * CinP + c) * CoutP + o] = acc[1][r];
+                }
+                if (cchunk == 0) {         // parts ragged_parts..7 do not exist: zeros
+#pragma unroll 1
+                    for (int t = 0; t < 9; ++t)
+                        for (int rr = 4 * ragged_parts + half; rr < 32; rr += 2)
+                            d.partial[(((size_t)split * 9 + t) * CinP + CinMain + rr) * CoutP + o] = 0.f;
+                }
+            }
+        }
+    }
 }
 
 template <int KS, int S, int NT, int CB>
@@ -293,9 +350,18 @@ int launch(const DipWgradDesc& d, hipStream_t st, int CinP_slab = 0) {
     const int ntiles = ntx * nty;
     const int CinP = dip_round_up(d.Cin, 32), CoutP = dip_round_up(d.Cout, 32);
     if (d.nsplit < 1 || d.nsplit > ntiles) DIP_FAIL("conv_wgrad: nsplit out of range");
-    dim3 grid(d.nsplit, dip_cdiv(CinP, C::CW), C::NGROUPS * dip_cdiv(CoutP, 128));
+    // a <= 4-channel tail behind 1..8 full 32-channel chunks is shared out among the full-chunk workgroups
+    // (phase 2 of the kernel) instead of getting workgroups of its own
+    int ragged_parts = 0;
+    if (KS == 3 && NT == 9 && CB == 1) {
+        static const bool no_parts = getenv("DIP_WGRAD_NO_RAGGED_PARTS") != nullptr;
+        const int tail = d.Cin & 31, nfull = d.Cin >> 5;
+        if (!no_parts && tail >= 1 && tail <= 4 && nfull >= 1 && nfull <= 8) ragged_parts = nfull;
+    }
+    dim3 grid(d.nsplit, ragged_parts > 0 ? ragged_parts : dip_cdiv(CinP, C::CW), C::NGROUPS * dip_cdiv(CoutP, 128));
     // CinP_slab: row count of the slabs when this launch covers only the leading channels of the layer
-    hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, st, d, ntx, ntiles, CinP_slab > 0 ? CinP_slab : CinP, CoutP);
+    hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, st, d, ntx, ntiles, CinP_slab > 0 ? CinP_slab : CinP, CoutP,
+                       ragged_parts);
     DIP_CHECK_LAUNCH();
     return 0;
 }
@@ -407,8 +473,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         tap = id / (Cout * Cin);
         const size_t slab = (size_t)KK * CinP * CoutP;
         const float* p = partial + ((size_t)tap * CinP + c) * CoutP + o;
+        // the <= 4-channel tail chunk of a 3x3 layer arrives in 8 four-row parts (conv_wgrad_kernel phase 2;
+        // kernels that do not share it out leave parts 1..7 zero)
+        const int tail = Cin & 31;
+        if (KK == 9 && Cin > 32 && tail >= 1 && tail <= 4 && c >= Cin - tail) {
+#pragma unroll 2
+            for (int k = sl; k < nsplit; k += 8)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) s += p[k * slab + (size_t)q * 4 * CoutP];
+        } else {
 #pragma unroll 4
-        for (int k = sl; k < nsplit; k += 8) s += p[k * slab];      // 4 loads in flight, same summation order
+            for (int k = sl; k < nsplit; k += 8) s += p[k * slab];      // 4 loads in flight, same summation order
+        }
     } else if (dbias != nullptr && id < total + Cout) {
         o = id - total;
 #pragma unroll 4

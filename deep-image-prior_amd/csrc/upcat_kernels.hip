@@ -320,7 +320,7 @@ int pixels_per_block(int npix, int C, int* nblk) {
     int rpi = 256 / nc4;
     if (rpi < 1) rpi = 1;
     int ppb = dip_cdiv(npix, 1024);
-    if (ppb < rpi * 8) ppb = rpi * 8;
+    if (ppb < rpi * 2) ppb = rpi * 2;      // small tensors: few sequential pixels per thread (latency-bound)
     *nblk = dip_cdiv(npix, ppb);
     return ppb;
 }
