@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const DipGradSrc src,
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float z = fmaf(a[e], yv[e], b[e]);
-                g[e] = z > 0.f ? du[e] : du[e] * slope;
+                g[e] = dip_mul_rn(du[e], dip_act_grad(z, slope));      // (rounded product: never contracted into the sums)
                 const float xh = (yv[e] - mean[e]) * rstd[e];
                 s1[e] += g[e];
                 s2[e] += g[e] * xh;
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_src_kernel(const DipGradSrc 
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float z = fmaf(a[e], yv[e], b[e]);
-            const float gm = z > 0.f ? du[e] : du[e] * slope;
+            const float gm = dip_mul_rn(du[e], dip_act_grad(z, slope));   // same rounding as the phase-1 value
             const float xh = (yv[e] - mean[e]) * rstd[e];
             g[e] = a[e] * (gm - k1[e] - xh * k2[e]);
         }

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
                     const f32x4 ta = *reinterpret_cast<const f32x4*>(tra + cb + ac4[i] * 4);
                     const f32x4 tb = *reinterpret_cast<const f32x4*>(trb + cb + ac4[i] * 4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = dip_act(fmaf(ta[e], v[e], tb[e]), slope);
+                    for (int e = 0; e < 4; ++e) v[e] = dip_act_leaky(fmaf(ta[e], v[e], tb[e]), slope);
                     *reinterpret_cast<f32x4*>(p) = v;
                 }
             }
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
                     const f32x4 ta = *reinterpret_cast<const f32x4*>(tra + cb + ac4[i] * 4);
                     const f32x4 tb = *reinterpret_cast<const f32x4*>(trb + cb + ac4[i] * 4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = dip_act(fmaf(ta[e], v[e], tb[e]), slope);
+                    for (int e = 0; e < 4; ++e) v[e] = dip_act_leaky(fmaf(ta[e], v[e], tb[e]), slope);
                     *reinterpret_cast<f32x4*>(p) = v;
                 }
             }
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
 #pragma unroll
             for (int ms = 0; ms < C::MS; ++ms)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) f.a[ms][e] = dip_act(fmaf(f.ta[e], f.a[ms][e], f.tb[e]), slope);
+                for (int e = 0; e < 4; ++e) f.a[ms][e] = dip_act_leaky(fmaf(f.ta[e], f.a[ms][e], f.tb[e]), slope);
         }
         SFor<0, 4>::run([&](auto J) {
             constexpr int j = decltype(J)::value;
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
 #pragma unroll
                     for (int ms = 0; ms < C::MS; ++ms)
 #pragma unroll
-                        for (int e = 0; e < 2; ++e) a2[ms][e] = dip_act(fmaf(ta[e], a2[ms][e], tb[e]), slope);
+                        for (int e = 0; e < 2; ++e) a2[ms][e] = dip_act_leaky(fmaf(ta[e], a2[ms][e], tb[e]), slope);
                 }
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
@@ -604,6 +604,7 @@ extern "C" int dip_conv_dma_eligible(const DipConvDesc* dp) {
     if (d.stride != 1 || (d.ks != 1 && d.ks != 3)) return 0;
     const bool has_tr = d.tr.a != nullptr;
     if (has_tr && d.Cin > TRN) return 0;
+    if (has_tr && d.tr.slope <= 0.f) return 0;      // Swish / ELU: the register-staged kernel applies them at staging
     // 1x1 transforms at the fragment read: a zero-padded or dilated gather would turn pad zeros into
     // act(b) there (never happens for the 1x1 convs of this net: off == 0, dil == 1)
     if (has_tr && d.ks == 1 && (d.off != 0 || d.dil != 1)) return 0;

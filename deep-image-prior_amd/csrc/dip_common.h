@@ -30,8 +30,34 @@ extern "C" void dip_set_error(const char* msg);
 static inline int dip_round_up(int x, int m) { return (x + m - 1) / m * m; }
 static inline int dip_cdiv(int a, int b) { return (a + b - 1) / b; }
 
-// max(t, slope*t) == LeakyReLU for slope in (0,1]; slope == 1 -> identity
-__device__ __forceinline__ float dip_act(float t, float slope) { return fmaxf(t, slope * t); }
+// Activation behind a BatchNorm, encoded in DipTransform.slope (models/common.py:76-92 of the reference):
+//   slope in (0, 1]          LeakyReLU(slope): max(t, slope*t); slope == 1 -> identity ('none')
+//   slope == DIP_ACT_SWISH   Swish: t * sigmoid(t)                       (models/common.py:62-73)
+//   slope == DIP_ACT_ELU     nn.ELU(alpha = 1): t > 0 ? t : expm1(t)
+// The branch is wave-uniform.  dip_act_leaky is the LeakyReLU-only form for the LDS-DMA conv kernel,
+// whose K loop is scheduled instruction by instruction (other activations take the register-staged kernel).
+__device__ __forceinline__ float dip_act_leaky(float t, float slope) { return fmaxf(t, slope * t); }
+__device__ __forceinline__ float dip_act(float t, float slope) {
+    if (slope > 0.f) return fmaxf(t, slope * t);
+    if (slope == DIP_ACT_SWISH) return t / (1.f + expf(-t));
+    return t > 0.f ? t : expm1f(t);
+}
+// a * b rounded to fp32 and NOT contractable into a neighbouring add (hipcc fuses across __fmul_rn under its
+// default -ffp-contract=fast): two kernels that must produce the same bits use this
+__device__ __forceinline__ float dip_mul_rn(float a, float b) {
+    float p = a * b;
+    asm volatile("" : "+v"(p));
+    return p;
+}
+// d act / d t
+__device__ __forceinline__ float dip_act_grad(float t, float slope) {
+    if (slope > 0.f) return t > 0.f ? 1.f : slope;
+    if (slope == DIP_ACT_SWISH) {
+        const float sg = 1.f / (1.f + expf(-t));
+        return sg * (1.f + t * (1.f - sg));
+    }
+    return t > 0.f ? 1.f : expf(t);
+}
 
 // mirror index v into [0, n) (ReflectionPad semantics: no edge repeat); requires |overshoot| < n
 __device__ __forceinline__ int dip_reflect(int v, int n) {

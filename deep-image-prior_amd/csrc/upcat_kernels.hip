@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void upsample_bwd_stats_kernel(const float* __
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float z = fmaf(a[e], yv[e], b[e]);
-                g[e] = z > 0.f ? du[e] : du[e] * slope;
+                g[e] = dip_mul_rn(du[e], dip_act_grad(z, slope));      // (rounded product: never contracted into the sums)
                 const float xh = (yv[e] - mean[e]) * rstd[e];
                 s1[e] += g[e];
                 s2[e] += g[e] * xh;

@@ -157,8 +157,6 @@ class SkipEngine:
         for i, s in enumerate(self.sc):
             if s.ns % 4 or s.down_b.Cout % 4 or s.up.Cout % 4 or (s.up.Cin % 4):
                 raise NotImplementedError("dip-amd: internal channel counts must be multiples of 4")
-            if s.skip_conv is not None and s.skip_conv.ks != 1:
-                raise NotImplementedError("dip-amd: filter_skip_size != 1 unsupported")
 
     # ------------------------------------------------------------------ arenas
     def _build_arenas(self, device):
@@ -427,8 +425,8 @@ class SkipEngine:
 
     def _emit_dgrad(self, r: ConvRec, x: Act, dy, ops, accumulate_into=None):
         """Data gradient of conv r wrt its input x.  Returns a DipGradSrc-describing tuple
-        (buf, pad, fold).  accumulate_into = (buf, pad): add a 1x1 conv's gradient into the
-        interior of an existing (padded) gradient buffer."""
+        (buf, pad, fold).  accumulate_into = (buf, pad): add the gradient into an existing (padded)
+        gradient buffer of the same input (skip-branch conv next to down_a)."""
         Ho = (x.H + 2 * r.P - r.ks) // r.stride + 1
         Wo = (x.W + 2 * r.P - r.ks) // r.stride + 1
         reflect = r.pad_mode == N.PAD_REFLECT and r.P > 0
@@ -437,15 +435,21 @@ class SkipEngine:
         off = (r.ks - 1) if reflect else (r.ks - 1 - r.P)
         Cg = x.Cs
         if accumulate_into is not None:
-            assert r.ks == 1
+            # the skip-branch conv (filter_skip_size, 1x1 in every notebook) reads the same input as down_a:
+            # its data gradient is ADDED into down_a's (padded) gradient buffer, at the offset that aligns
+            # the two padded domains (a reflected ring position of the smaller pad is the same virtual pixel)
+            gbuf, gpad = accumulate_into
+            if pad > gpad or r.stride != 1:
+                raise NotImplementedError(f"dip-amd: {r.name}: a skip filter larger than the down filter (with "
+                                          "reflection padding) or a strided skip conv has no gfx950 path")
             if self._sizing:
                 return accumulate_into
-            gbuf, gpad = accumulate_into
+            o = gpad - pad
             Wg2 = x.W + 2 * gpad
-            ybase = _ptr(gbuf, (gpad * Wg2 + gpad) * Cg)
+            ybase = _ptr(gbuf, (o * Wg2 + o) * Cg)
             d = N.DipConvDesc(_ptr(dy), Ho, Wo, round_up(r.Cout, 4), round_up(r.Cout, 4),
                               N.DipTransform(None, None, 1.0), _ptr(self.packed, r.dgrad_off), None,
-                              ybase, x.H, x.W, Cg, r.Cin, Wg2, 1, 1, N.PAD_ZERO, 0, 1, 1, None)
+                              ybase, Hg, Wg, Cg, r.Cin, Wg2, r.ks, 1, N.PAD_ZERO, off, 1, 1, None)
             self.keep.append(d)
             ops.append((self.lib.dip_conv_igemm, (C.byref(d),), "dgrad+:" + r.name))
             return accumulate_into

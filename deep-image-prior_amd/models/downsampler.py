@@ -75,9 +75,10 @@ class _LanczosFn(torch.autograd.Function):
         Ho, Wo = (H + 2 * pad - k) // factor + 1, (W + 2 * pad - k) // factor + 1
         xs = x.detach().contiguous().float()
         y = torch.empty((1, C, Ho, Wo), dtype=torch.float32, device=x.device)
-        st = torch.cuda.current_stream(x.device).cuda_stream
-        N.check(lib.dip_lanczos_down_fwd(xs.data_ptr(), taps.data_ptr(), y.data_ptr(), C, H, W, k, factor, pad, st),
-                "lanczos_down_fwd")
+        with torch.cuda.device(x.device):
+            st = torch.cuda.current_stream(x.device).cuda_stream
+            N.check(lib.dip_lanczos_down_fwd(xs.data_ptr(), taps.data_ptr(), y.data_ptr(), C, H, W, k, factor, pad, st),
+                    "lanczos_down_fwd")
         ctx.meta = (taps, k, factor, pad, C, H, W)
         return y
 
@@ -88,9 +89,10 @@ class _LanczosFn(torch.autograd.Function):
         taps, k, factor, pad, C, H, W = ctx.meta
         g = gy.detach().contiguous().float()
         gx = torch.empty((1, C, H, W), dtype=torch.float32, device=gy.device)
-        st = torch.cuda.current_stream(gy.device).cuda_stream
-        N.check(lib.dip_lanczos_down_bwd(g.data_ptr(), taps.data_ptr(), gx.data_ptr(), C, H, W, k, factor, pad, st),
-                "lanczos_down_bwd")
+        with torch.cuda.device(gy.device):
+            st = torch.cuda.current_stream(gy.device).cuda_stream
+            N.check(lib.dip_lanczos_down_bwd(g.data_ptr(), taps.data_ptr(), gx.data_ptr(), C, H, W, k, factor, pad, st),
+                    "lanczos_down_bwd")
         return gx, None, None, None, None
 
 

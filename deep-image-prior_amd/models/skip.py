@@ -65,13 +65,17 @@ def _attach_engine(model, scale_paths, out_path, need_sigmoid, pad, act_fun):
             setattr(s, k, at(sp[k]) if sp.get(k) is not None else None)
         scales.append(s)
     model.__dict__['_dip_spec'] = (scale_paths, out_path, need_sigmoid, pad, act_fun)
+    # DipTransform.slope code of the activation (include/dip_hip.h): LeakyReLU(0.2) | none | Swish | ELU
+    act_codes = {'LeakyReLU': 0.2, 'none': 1.0, 'Swish': -1.0, 'ELU': -2.0}
     try:
-        if act_fun != 'LeakyReLU':
-            raise NotImplementedError(f"dip-amd: act_fun={act_fun!r} has no gfx950 kernel (LeakyReLU only)")
+        if act_fun not in act_codes:
+            raise NotImplementedError(f"dip-amd: act_fun={act_fun!r} has no gfx950 kernel "
+                                      "(LeakyReLU, Swish, ELU and 'none' do; a module class does not)")
         for sp in scale_paths:
             if sp['unsupported']:
                 raise NotImplementedError("dip-amd: " + sp['unsupported'])
-        model.__dict__['_dip_engine'] = dip_engine.SkipEngine(model, scales, at(out_path), need_sigmoid, pad)
+        model.__dict__['_dip_engine'] = dip_engine.SkipEngine(model, scales, at(out_path), need_sigmoid, pad,
+                                                              act_slope=act_codes[act_fun])
     except NotImplementedError as e:   # surfaces at the first forward(), construction stays cheap
         model.__dict__['_dip_engine'] = e
 

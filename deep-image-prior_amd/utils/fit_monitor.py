@@ -63,23 +63,25 @@ class FitMonitor:
         if o.shape != self.noisy.shape or not o.is_cuda:
             raise ValueError("FitMonitor.update: output shape/device does not match the target image")
         o = o.contiguous().float()
-        stream = torch.cuda.current_stream(self.dev).cuda_stream
-        lptr = None
-        if loss is not None:
-            self._loss = loss.detach().reshape(1).float()          # keep alive until the launch has run
-            lptr = self._loss.data_ptr()
-        check = 1 if (self.engine is not None and self.i % self.show_every) else 0
-        N.check(self.lib.dip_fit_monitor(o.data_ptr(), self.noisy.data_ptr(),
-                                         self.gt.data_ptr() if self.gt is not None else None, self.out_avg.data_ptr(),
-                                         self.n, self.exp_weight, 1 if self.i == 0 else 0, lptr, self.partial.data_ptr(),
-                                         self.records[self.i].data_ptr(), self.state.data_ptr(), check,
-                                         self.backtrack_db, stream), "fit_monitor")
-        if self.engine is not None:
-            params = self.engine.params
-            if self.snapshot is None or self.snapshot.numel() != params.numel() or self.snapshot.device != params.device:
-                self.snapshot = torch.empty_like(params)
-            N.check(self.lib.dip_arena_backtrack(params.data_ptr(), self.snapshot.data_ptr(), params.numel(),
-                                                 self.state.data_ptr(), stream), "arena_backtrack")
+        with torch.cuda.device(self.dev):        # raw HIP launches go to the current device's streams
+            stream = torch.cuda.current_stream(self.dev).cuda_stream
+            lptr = None
+            if loss is not None:
+                self._loss = loss.detach().reshape(1).float()          # keep alive until the launch has run
+                lptr = self._loss.data_ptr()
+            check = 1 if (self.engine is not None and self.i % self.show_every) else 0
+            N.check(self.lib.dip_fit_monitor(o.data_ptr(), self.noisy.data_ptr(),
+                                             self.gt.data_ptr() if self.gt is not None else None,
+                                             self.out_avg.data_ptr(), self.n, self.exp_weight, 1 if self.i == 0 else 0,
+                                             lptr, self.partial.data_ptr(), self.records[self.i].data_ptr(),
+                                             self.state.data_ptr(), check, self.backtrack_db, stream), "fit_monitor")
+            if self.engine is not None:
+                params = self.engine.params
+                if self.snapshot is None or self.snapshot.numel() != params.numel() \
+                        or self.snapshot.device != params.device:
+                    self.snapshot = torch.empty_like(params)
+                N.check(self.lib.dip_arena_backtrack(params.data_ptr(), self.snapshot.data_ptr(), params.numel(),
+                                                     self.state.data_ptr(), stream), "arena_backtrack")
         self._keep = o
         self.i += 1
 

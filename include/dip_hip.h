@@ -30,6 +30,10 @@ extern "C" {
 #define DIP_PAD_ZERO 0
 #define DIP_PAD_REFLECT 1
 
+/* DipTransform.slope codes for activations other than LeakyReLU (act_fun='Swish' | 'ELU') */
+#define DIP_ACT_SWISH (-1.0f)
+#define DIP_ACT_ELU (-2.0f)
+
 #define DIP_UP_NEAREST 0
 #define DIP_UP_BILINEAR 1
 
@@ -37,9 +41,10 @@ int dip_abi_version(void);
 const char* dip_last_error(void);
 
 /* Per-channel input transform fused into a consumer's loader:
- *   u = max(t, slope*t),  t = a[c]*x + b[c]        (slope = 1 -> affine only)
- * This is BatchNorm2d(train)-apply (models/common.py:95-96) + LeakyReLU(0.2)
- * (models/common.py:82) with a = gamma*rstd, b = beta - mean*a.  a == NULL -> identity. */
+ *   u = act(t),  t = a[c]*x + b[c];  act = max(t, slope*t) for slope in (0, 1] (slope = 1 -> affine
+ *   only), t*sigmoid(t) for slope == DIP_ACT_SWISH, ELU(alpha=1) for slope == DIP_ACT_ELU
+ * This is BatchNorm2d(train)-apply (models/common.py:95-96) + act() (models/common.py:76-92:
+ * LeakyReLU(0.2), Swish, ELU, none) with a = gamma*rstd, b = beta - mean*a.  a == NULL -> identity. */
 typedef struct DipTransform {
     const float* a;
     const float* b;

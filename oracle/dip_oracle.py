@@ -64,6 +64,7 @@ class SkipSpec:
     upsample_mode: Sequence[str] | str = "nearest"
     need1x1_up: bool = True
     downsample_mode: Sequence[str] | str = "stride"      # 'stride' | 'avg' | 'max' (models/common.py:99-112)
+    act_fun: str = "LeakyReLU"                           # 'LeakyReLU' | 'Swish' | 'ELU' | 'none' (models/common.py:76-92)
 
     def __post_init__(self):
         n = len(self.num_channels_down)
@@ -189,8 +190,9 @@ def _conv(x, sd, key, k, stride, pad):
     return F.conv2d(x, w, b, stride=stride, padding=to_pad)
 
 
-def _bn_act(x, sd, key, act=True, eps=1e-5, masks=None):
-    """bn() + act(): BatchNorm2d in TRAIN mode (batch stats), LeakyReLU(0.2).
+def _bn_act(x, sd, key, act=True, eps=1e-5, masks=None, act_fun="LeakyReLU"):
+    """bn() + act(): BatchNorm2d in TRAIN mode (batch stats), then act(act_fun), models/common.py:76-92:
+    LeakyReLU(0.2) | Swish (x * sigmoid(x), :62-73) | nn.ELU() | 'none' (empty nn.Sequential).
 
     `masks` (test-only): {bn_key: bool tensor} imposes the LeakyReLU branch pattern of ANOTHER
     implementation.  LeakyReLU's derivative jumps at 0, so two correct fp32 implementations whose
@@ -198,8 +200,13 @@ def _bn_act(x, sd, key, act=True, eps=1e-5, masks=None):
     that single element changes the gradient by O(1/sqrt(numel)) ~ 1e-3 relative.  With the pattern
     imposed, the oracle differentiates exactly the piecewise-linear branch the other side took."""
     x = F.batch_norm(x, None, None, sd[key + ".weight"], sd[key + ".bias"], True, 0.1, eps)
-    if not act:
+    if not act or act_fun == "none":
         return x
+    if act_fun == "Swish":
+        return x * torch.sigmoid(x)
+    if act_fun == "ELU":
+        return F.elu(x)
+    assert act_fun == "LeakyReLU", act_fun
     if masks is not None and key in masks:
         # multiply by a constant slope map (1 on the positive branch, 0.2 on the other)
         slope = masks[key].contiguous().to(x.dtype) * 0.8 + 0.2
@@ -237,15 +244,15 @@ def skip_forward(spec: SkipSpec, sd: Dict[str, torch.Tensor], x: torch.Tensor,
         else:                               # ... or nn.MaxPool2d(2, 2), common.py:105-106
             assert spec.downsample_mode[i] == "max", spec.downsample_mode[i]
             d = F.max_pool2d(_conv(x, sd, k.down_a, fd, 1, spec.pad), 2, 2)
-        d = _bn_act(d, sd, k.down_a_bn, masks=masks)
+        d = _bn_act(d, sd, k.down_a_bn, masks=masks, act_fun=spec.act_fun)
         d = _conv(d, sd, k.down_b, fd, 1, spec.pad)
-        d = _bn_act(d, sd, k.down_b_bn, masks=masks)
+        d = _bn_act(d, sd, k.down_b_bn, masks=masks, act_fun=spec.act_fun)
         if i < spec.n_scales - 1:
             d = scale(i + 1, d)
         d = F.interpolate(d, scale_factor=2, mode=spec.upsample_mode[i])
         if ns:
             s = _conv(x, sd, k.skip_conv, spec.filter_skip_size, 1, spec.pad)
-            s = _bn_act(s, sd, k.skip_bn, masks=masks)
+            s = _bn_act(s, sd, k.skip_bn, masks=masks, act_fun=spec.act_fun)
             y = _concat([s, d])
         else:
             y = d
@@ -255,10 +262,10 @@ def skip_forward(spec: SkipSpec, sd: Dict[str, torch.Tensor], x: torch.Tensor,
         y = _conv(y, sd, k.up, fu, 1, spec.pad)
         if taps is not None:
             taps[f"up{i}_raw"] = y
-        y = _bn_act(y, sd, k.up_bn, masks=masks)
+        y = _bn_act(y, sd, k.up_bn, masks=masks, act_fun=spec.act_fun)
         if spec.need1x1_up:
             y = _conv(y, sd, k.up1, 1, 1, spec.pad)
-            y = _bn_act(y, sd, k.up1_bn, masks=masks)
+            y = _bn_act(y, sd, k.up1_bn, masks=masks, act_fun=spec.act_fun)
         return y
 
     y = scale(0, x)

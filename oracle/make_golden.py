@@ -58,6 +58,20 @@ NETS = {
                      kw=dict(num_channels_down=[16, 32], num_channels_up=[16, 32],
                              num_channels_skip=[4, 4], upsample_mode="bilinear", downsample_mode="max",
                              need_sigmoid=True, need_bias=True, pad="reflection")),
+    # act_fun='Swish' / 'ELU' (models/common.py:62-92; no notebook uses them)
+    "tiny_swish": dict(args=(8, 3), hw=(32, 48), seed=9,
+                       kw=dict(num_channels_down=[16, 32], num_channels_up=[16, 32], num_channels_skip=[4, 4],
+                               upsample_mode="bilinear", act_fun="Swish",
+                               need_sigmoid=True, need_bias=True, pad="reflection")),
+    "tiny_elu": dict(args=(8, 3), hw=(32, 32), seed=10,
+                     kw=dict(num_channels_down=[16, 16], num_channels_up=[16, 16], num_channels_skip=[4, 4],
+                             upsample_mode="nearest", act_fun="ELU",
+                             need_sigmoid=True, need_bias=True, pad="zero")),
+    # filter_skip_size = 3 (models/skip.py:58; every notebook keeps 1)
+    "tiny_skip3": dict(args=(8, 3), hw=(32, 48), seed=11,
+                       kw=dict(num_channels_down=[16, 32], num_channels_up=[16, 32], num_channels_skip=[4, 4],
+                               filter_skip_size=3, upsample_mode="bilinear",
+                               need_sigmoid=True, need_bias=True, pad="reflection")),
     # feature_inversion.ipynb:169-174: per-scale filter sizes 7 / 5 / 3, zero padding, avg-pool
     # down-sampling, nearest up-sampling, meshgrid input
     "tiny_feat7": dict(args=(2, 3), hw=(32, 48), seed=7,

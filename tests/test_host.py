@@ -70,6 +70,38 @@ def test_planner_launch_lists(built):
         eng._build_plan(500, 512, 32)          # ragged Concat crop is not implemented
 
 
+def test_planner_builds_launch_lists_for_every_option(built):
+    """Both planner passes (sizing + emission of the descriptors) run on CPU memory -- nothing is
+    launched -- for every skip() option the backend accepts: per-scale filter sizes 3/5/7, avg / max
+    pooling, Swish / ELU / none, filter_skip_size 3, no skips, no 1x1, zero / reflection padding."""
+    from models.skip import skip
+    from test_net_gpu import NETS
+    import dip_native as N
+    for name, cfg in NETS.items():
+        net = skip(*cfg["args"], **cfg["kw"])
+        eng = net.__dict__["_dip_engine"]
+        assert not isinstance(eng, Exception), (name, eng)
+        eng._build_arenas(torch.device("cpu"))
+        eng._build_plan(64, 96, cfg["args"][0])
+        names = [n for _, _, n in eng.fwd_ops]
+        assert names[-1] == "conv_fwd:out" and sum(n.startswith("conv_fwd:") for n in names) == len(eng.convs), name
+        bnames = [n for _, _, n in eng.bwd_ops]
+        assert sum(n.startswith("wgrad:") for n in bnames) == len(eng.convs), name
+        assert sum(n.startswith("bnb_apply:") for n in bnames) == len(eng.bns), name
+        if cfg["kw"].get("downsample_mode") in ("avg", "max"):
+            assert any(n.startswith("pool:") for n in names) and any(n.startswith("poolb:") for n in bnames), name
+    net = skip(8, 3, [16, 16], [16, 16], [4, 4], act_fun="none", pad="reflection")
+    eng = net.__dict__["_dip_engine"]
+    eng._build_arenas(torch.device("cpu"))
+    eng._build_plan(32, 32, 8)
+    assert eng.slope == 1.0
+    big = skip(8, 3, [16, 16], [16, 16], [4, 4], filter_skip_size=5, filter_size_down=3, pad="reflection")
+    e2 = big.__dict__["_dip_engine"]
+    e2._build_arenas(torch.device("cpu"))
+    with pytest.raises(NotImplementedError, match="skip filter larger"):
+        e2._build_plan(32, 32, 8)
+
+
 def test_get_noise_get_params_semantics():
     from utils.common_utils import get_noise, get_params, np_to_torch, torch_to_np
     gn = np.load(os.path.join(GOLDEN, "get_noise.npz"))
@@ -107,7 +139,7 @@ def test_no_silent_fallback():
     net = skip(4, 3, [8, 8], [8, 8], [4, 4], pad="reflection", upsample_mode="bilinear")
     with pytest.raises(RuntimeError, match="MI355X"):
         net(torch.zeros(1, 4, 16, 16))
-    bad = skip(4, 3, [8, 8], [8, 8], [4, 4], act_fun="Swish")
+    bad = skip(4, 3, [8, 8], [8, 8], [4, 4], act_fun=torch.nn.Tanh)          # (LeakyReLU / Swish / ELU / none have kernels)
     with pytest.raises(NotImplementedError):
         bad(torch.zeros(1, 4, 16, 16))
     mx = skip(4, 3, [8, 8], [8, 8], [4, 4], downsample_mode="lanczos2")     # ('avg' / 'max' have kernels, Lanczos does not)

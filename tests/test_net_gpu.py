@@ -42,6 +42,15 @@ NETS = {
     "tiny_max": dict(args=(8, 3), kw=dict(num_channels_down=[16, 32], num_channels_up=[16, 32],
                                           num_channels_skip=[4, 4], upsample_mode="bilinear", downsample_mode="max",
                                           need_sigmoid=True, need_bias=True, pad="reflection")),
+    "tiny_swish": dict(args=(8, 3), kw=dict(num_channels_down=[16, 32], num_channels_up=[16, 32],
+                                            num_channels_skip=[4, 4], upsample_mode="bilinear", act_fun="Swish",
+                                            need_sigmoid=True, need_bias=True, pad="reflection")),
+    "tiny_elu": dict(args=(8, 3), kw=dict(num_channels_down=[16, 16], num_channels_up=[16, 16],
+                                          num_channels_skip=[4, 4], upsample_mode="nearest", act_fun="ELU",
+                                          need_sigmoid=True, need_bias=True, pad="zero")),
+    "tiny_skip3": dict(args=(8, 3), kw=dict(num_channels_down=[16, 32], num_channels_up=[16, 32],
+                                            num_channels_skip=[4, 4], filter_skip_size=3, upsample_mode="bilinear",
+                                            need_sigmoid=True, need_bias=True, pad="reflection")),
     "tiny_feat7": dict(args=(2, 3), kw=dict(num_channels_down=[8, 16, 16], num_channels_up=[8, 16, 16],
                                             num_channels_skip=[4, 4, 4], filter_size_down=[7, 5, 3],
                                             filter_size_up=[7, 5, 3], upsample_mode="nearest", downsample_mode="avg",

@@ -21,7 +21,7 @@ def _spec(cfg):
                       kw["num_channels_skip"], kw.get("filter_size_down", 3), kw.get("filter_size_up", 3),
                       kw.get("filter_skip_size", 1), True, True, kw.get("pad", "zero"),
                       kw.get("upsample_mode", "nearest"), kw.get("need1x1_up", True),
-                      kw.get("downsample_mode", "stride"))
+                      kw.get("downsample_mode", "stride"), kw.get("act_fun", "LeakyReLU"))
 
 
 @pytest.mark.parametrize("name", list(NETS))

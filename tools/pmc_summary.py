@@ -1,23 +1,22 @@
-"""Per-kernel PMC table from a rocprofv3 rocpd database (one --pmc pass):
-   python tools/pmc_summary.py <dir> [name-filter]      values summed over counter instances, averaged per launch"""
+"""rocprofv3 --pmc pass (rocpd sqlite) -> plain-text per-kernel / per-launch-shape counter summary.
+  python tools/pmc_summary.py <pass_dir> > profiles/r0N_rocprofv3_pmc_<COUNTER>.txt
+Counter values are summed over the XCD instances of a dispatch (rocprofv3 reports one row per instance)."""
 import collections, glob, re, sqlite3, sys
+
 db = glob.glob(sys.argv[1] + "/**/*.db", recursive=True)[0]
-flt = sys.argv[2] if len(sys.argv) > 2 else ""
 cur = sqlite3.connect(db).cursor()
-rows = cur.execute("select dispatch_id, kernel_name, counter_name, value, duration, grid_size, workgroup_size from counters_collection")
 per = collections.OrderedDict()
-for did, kn, cn, val, dur, gs, wg in rows:
-    kn = kn.replace("(anonymous namespace)::", "")
-    short = re.sub(r"^void ", "", kn)
-    short = re.sub(r"\(.*", "", short)[:64]
-    if flt not in short:
-        continue
-    e = per.setdefault((short, gs // wg), {"ids": set(), "dur": 0.0, "c": collections.defaultdict(float)})
-    if did not in e["ids"]:
-        e["ids"].add(did)
-        e["dur"] += dur
-    e["c"][cn] += val
-print(f"{'kernel':64s} {'wgs':>6s} {'n':>4s} {'avg_us':>9s}  counters per launch")
-for (k, g), e in sorted(per.items(), key=lambda x: -x[1]["dur"]):
-    n = len(e["ids"])
-    print(f"{k:64s} {g:6d} {n:4d} {e['dur'] / n / 1e3:9.1f}  " + "  ".join(f"{c}={v / n:.4g}" for c, v in e["c"].items()))
+for did, kn, gs, ws, cn, val, dur in cur.execute(
+        "select dispatch_id, kernel_name, grid_size, workgroup_size, counter_name, value, duration from counters_collection"):
+    e = per.setdefault(did, [re.sub(r"\(anonymous namespace\)::|\(.*", "", kn).replace("void ", ""), gs // max(ws, 1), cn, 0.0, dur])
+    e[3] += val
+groups = collections.OrderedDict()
+for name, wgs, cn, val, dur in per.values():
+    g = groups.setdefault((name, wgs, cn), [0, 0.0, 0.0])
+    g[0] += 1
+    g[1] += val
+    g[2] += dur
+print(f"# source: {db}")
+print(f"{'kernel':66s} {'wgs':>6s} {'n':>4s} {'avg_us':>9s}  counter per launch (KiB of 64-byte requests for FETCH_SIZE / WRITE_SIZE)")
+for (name, wgs, cn), (n, val, dur) in sorted(groups.items(), key=lambda kv: -kv[1][2]):
+    print(f"{name[:66]:66s} {wgs:6d} {n:4d} {dur / n / 1e3:9.1f}  {cn}={val / n:.4g}")

@@ -1,7 +1,7 @@
 """HBM traffic per launch of the dominant kernel from two rocprofv3 --pmc passes of bench.py
 (FETCH_SIZE and WRITE_SIZE need separate passes: TCC has 4 counter slots, MI355X_MICROARCH.md).
 
-  python tools/pmc_traffic.py <fetch_pass_dir> <write_pass_dir> > profiles/r01_pmc_traffic.json
+  python tools/pmc_traffic.py <fetch_pass_dir> <write_pass_dir> > profiles/r0N_pmc_traffic.json
 
 Unit / gfx950 correction: rocprofv3 reports both in KiB of 64-byte requests; for 16-byte-per-lane
 coalesced accesses gfx950 tallies 128-byte requests as 64 bytes (guide: "FETCH_SIZE reports exactly
