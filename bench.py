@@ -363,7 +363,7 @@ def pmc_traffic():
     return None
 
 
-def roofline(eng, per_op_ms):
+def roofline(eng, per_op_ms, with_pmc=True):
     """roofline (dominant conv kernel) and roofline_wgrad (3x3 weight-gradient kernel)."""
     fl = conv_flops(eng)
     dom = dominant_ops(eng, fl)
@@ -377,7 +377,7 @@ def roofline(eng, per_op_ms):
     # every MFMA conv launch (forward, data and weight gradient, all kernels) for the whole-path figure
     all_f = sum(f for k, f in fl.items() if k in per_op_ms)
     all_ms = sum(ms for k, ms in per_op_ms.items() if k in fl)          # (the "#..." parts are not in fl)
-    pmc = pmc_traffic()
+    pmc = pmc_traffic() if with_pmc else None     # the PMC passes were taken on the default workload only
     rl = {"bound": "mfma", "kernel": DOMINANT + " (3x3 stride-1 forward + 3x3 data-gradient launches)",
           "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
           "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
@@ -596,7 +596,7 @@ def main():
         rl = rw = None
         if not args.no_roofline:
             per_op = profile_ops(eng)
-            rl, rw = roofline(eng, per_op)
+            rl, rw = roofline(eng, per_op, with_pmc=(args.config == "default"))
             if args.dump_ops:
                 fl = conv_flops(eng)
                 with open(args.dump_ops, "w") as f:
