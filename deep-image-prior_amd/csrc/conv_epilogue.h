@@ -18,6 +18,7 @@ struct DipEpi {
     float* yt;        // &y[tile origin]
     int row_stride;   // pitch * Cy   (floats between output rows)
     int Cy;           // floats between output pixels
+    int ncols;        // channels stored per pixel (columns n < ncols)
     int rows_left;    // Hout - tile row origin
     int cols_left;    // Wout - tile col origin
     bool full;        // whole 8x16 tile inside the image (workgroup-uniform)
@@ -30,6 +31,7 @@ __device__ __forceinline__ DipEpi dip_epi_make(const DipConvDesc& d, int ty, int
     e.yt = d.y + ((size_t)(ty * TH) * pitch + (size_t)tx * TW) * d.Cy;
     e.row_stride = pitch * d.Cy;
     e.Cy = d.Cy;
+    e.ncols = d.Cy;
     e.rows_left = d.Hout - ty * TH;
     e.cols_left = d.Wout - tx * TW;
     e.full = (e.rows_left >= TH) && (e.cols_left >= TW);
@@ -44,7 +46,7 @@ __device__ __forceinline__ bool dip_epi_valid(const DipEpi& e, int sub, int r, i
 
 // a[r] <- a[r] + bias (+ previous y when accumulating); stores it for channel n < Cy.
 __device__ __forceinline__ void dip_epi_store16(const DipEpi& e, f32x16& a, int sub, int n, float bias, int half) {
-    const bool ncol = n < e.Cy;
+    const bool ncol = n < e.ncols;
     float* p0 = e.yt + (2 * sub) * e.row_stride + (4 * half) * e.Cy + n;
     if (e.accumulate) {
         float old[16];

@@ -510,7 +510,42 @@ extern "C" int dip_conv_plan(int Hout, int Wout, int Cin, int Cout, int ks, int 
     return 0;
 }
 
+// Launch plan of the data gradient of a stride-2 3x3 convolution (dil == 2 descriptor, Hout x Wout = the
+// gradient's domain): the phase mode of the LDS-DMA kernel runs 4 workgroups per 8x16 tile of the
+// half-resolution grid with 4/2/2/1 taps; split-K is bounded by the channel chunks of the 1-tap phase.
+// Falls back to dip_conv_plan's answer (ksplit for the dilated evaluation) when the phase mode cannot run it.
+extern "C" int dip_conv_plan_dil2(int Hout, int Wout, int Cin, int Cout, int ks, int* ksplit, int* stats_rows,
+                                  int64_t* ws_floats) {
+    static const bool off = getenv("DIP_CONV_NO_PHASE") != nullptr || getenv("DIP_CONV_NO_DMA") != nullptr;
+    const int CoutP = dip_round_up(Cout, 32);
+    if (off || ks != 3 || (CoutP % 128) != 0) return dip_conv_plan(Hout, Wout, Cin, Cout, ks, 1, ksplit, stats_rows, ws_floats);
+    const int ntiles = dip_conv_ntiles((Hout + 1) / 2, (Wout + 1) / 2);
+    const int wgs = 4 * ntiles * (CoutP / 128);
+    const int nchunks = dip_cdiv(dip_round_up(Cin, 4), 32);
+    int k = 1;
+    if (wgs < 512) {
+        k = dip_cdiv(720, wgs);
+        if (k > 4) k = 4;
+        if (k > nchunks) k = nchunks;
+    }
+    static const char* force = getenv("DIP_CONV_PHASE_KSPLIT");
+    if (force && atoi(force) >= 1 && atoi(force) <= nchunks) k = atoi(force);
+    const int Cy = dip_round_up(Cout, 4);
+    *ksplit = k;
+    if (k > 1) {
+        int nblk;
+        finish_ppb(Hout * Wout, Cy, &nblk);
+        *stats_rows = nblk;
+        *ws_floats = (int64_t)k * Hout * Wout * Cy;
+    } else {
+        *stats_rows = ntiles;
+        *ws_floats = 0;
+    }
+    return 0;
+}
+
 extern "C" int dip_conv_dma_eligible(const DipConvDesc* dp);
+extern "C" int dip_conv_phase_eligible(const DipConvDesc* dp);
 extern "C" int dip_conv_igemm_dma(const DipConvDesc* dp, int ksplit, void* stream);
 extern "C" int dip_conv_igemm_dma_cols(const DipConvDesc* dp, int n_base, void* stream);
 extern "C" int dip_conv_thin4(const DipConvDesc* dp, int ncols, void* stream);
@@ -520,6 +555,7 @@ extern "C" int dip_conv_variant(const DipConvDesc* dp) {
     static const bool no_dma = getenv("DIP_CONV_NO_DMA") != nullptr;      // A/B switches for profiling
     static const bool no_extra = getenv("DIP_CONV_NO_EXTRA") != nullptr;
     const int CoutP = dip_round_up(d.Cout, 32);
+    if (!no_dma && dip_conv_phase_eligible(dp)) return 4;
     static const bool no_thin4 = getenv("DIP_CONV_NO_THIN4") != nullptr;
     // 129..132 output channels (the data gradient towards [4 skip | 128 up-sampled] channels): the
     // 1..4 leading columns on the vector ALU (conv_thin4.hip), the other 128 on the DMA kernel
@@ -565,7 +601,7 @@ extern "C" int dip_conv_igemm(const DipConvDesc* dp, void* stream) {
         if (rc) return rc;
         return dip_conv_igemm_dma_cols(dp, ncols, stream);
     }
-    if (variant == 1) rc = dip_conv_igemm_dma(dp, ksplit, stream);
+    if (variant == 1 || variant == 4) rc = dip_conv_igemm_dma(dp, ksplit, stream);
     else if (d.ks == 1 && d.stride == 1) rc = launch_bn<1, 1, 32>(d, st, ksplit, d.ws);
     else if (d.ks == 3 && d.stride == 1) rc = launch_bn<3, 1, 32>(d, st, ksplit, d.ws);
     else if (d.ks == 3 && d.stride == 2) rc = launch_bn<3, 2, 16>(d, st, ksplit, d.ws);

@@ -120,7 +120,14 @@ __device__ unsigned g_trace[128 * 8];
 #define PROBE(i) do { } while (0)
 #endif
 
-template <int KS, int BN, bool TR>
+// PH (phase mode, the data gradient of a stride-2 convolution): the descriptor describes the dilated
+// problem (dil == 2, filter d.ks = 2*KS-1, zero padding), the kernel runs it as 4 dense convolutions,
+// one per parity (py, px) of the output pixel: output (2a+py, 2b+px) only sees the filter taps
+// k = k0 + 2j with k0 = (off - p) & 1, which read dy[a + j - (off - p - k0)/2] -- a KS x KS (or smaller)
+// dense filter over the UNdilated input.  9 taps per 4 pixels instead of 36; the terms that remain are
+// summed in the same order as in the dilated evaluation, so the result is bit-identical to it.
+// Workgroup id -> (tile, phase): the 4 phases of a tile are neighbours (same dy halo in L2).
+template <int KS, int BN, bool TR, bool PH = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDesc d, const int ntx, const int ntiles,
                                                                 const int CoutP, const int n_base, const int ksplit,
                                                                 float* __restrict__ ws) {
@@ -145,14 +152,44 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
     const int wn = wave % C::WN;
     const int wm = wave / C::WN;
 
-    const int tile = dip_xcd_remap(blockIdx.x, ntiles);
+    int tile, py = 0, px = 0, k0y = 0, k0x = 0, nky = KS, nkx = KS, offy = d.off, offx = d.off;
+    if constexpr (PH) {
+        // this XCD's contiguous range [a, b) of (tile, phase) pairs, walked phase-major: the 4-tap phase of
+        // all its tiles first, the 1-tap phase last (longest-first keeps the tail of the launch short)
+        const int nwg = 4 * ntiles, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        const int a = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        const int b = a + q + (xcd < r ? 1 : 0);
+        int lin = a, left = idx;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int first = a + ((p - a) & 3);                     // first id >= a with id & 3 == p
+            const int cnt = first < b ? ((b - 1 - first) >> 2) + 1 : 0;
+            if (left >= 0 && left < cnt) lin = first + 4 * left;
+            left -= cnt;
+            if (left < 0) left = -0x40000000;
+        }
+        tile = lin >> 2;
+        const int p2 = d.off & 1;                       // the parity that sees the even taps
+        py = p2 ^ ((lin >> 1) & 1);
+        px = p2 ^ (lin & 1);
+        k0y = (d.off - py) & 1;
+        k0x = (d.off - px) & 1;
+        nky = (d.ks - k0y + 1) >> 1;
+        nkx = (d.ks - k0x + 1) >> 1;
+        offy = (d.off - py - k0y) >> 1;
+        offx = (d.off - px - k0x) >> 1;
+    } else {
+        tile = dip_xcd_remap(blockIdx.x, ntiles);
+    }
+    const int kkr = PH ? nky * nkx : KS * KS;           // taps of this workgroup's filter
     const int ty = tile / ntx, tx = tile - ty * ntx;
     const int n0 = n_base + blockIdx.y * BN;
 
     for (int hp = tid; hp < C::NPIX; hp += 256) {
         const int hr = hp / C::HTW, hc = hp - hr * C::HTW;
-        const int sr = map_src(ty * C::TH + hr - d.off, d.Hin, d.dil, d.pad_mode);
-        const int sc = map_src(tx * C::TW + hc - d.off, d.Win, d.dil, d.pad_mode);
+        const int sr = map_src(ty * C::TH + hr - offy, d.Hin, PH ? 1 : d.dil, d.pad_mode);
+        const int sc = map_src(tx * C::TW + hc - offx, d.Win, PH ? 1 : d.dil, d.pad_mode);
         srcoff[hp] = (sr < 0 || sc < 0) ? -1 : (sr * d.Win + sc);
     }
     // 3x3: the thread that DMA'd a slot transforms it IN PLACE once its own DMA has landed (after its
@@ -161,6 +198,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
     // 1x1: every unit is a new chunk, so the transform stays at the fragment read (2x redundancy only).
     constexpr bool has_tr = TR && (KS == 1);      // transform at fragment read
     const bool fix_inplace = (KS != 1) && (TR || d.pad_mode != DIP_PAD_REFLECT || d.dil != 1);
+    const size_t wtap = (size_t)(d.Cin >> 2) * CoutP * 4;            // floats between taps in the packed weights
+    // packed-weight offset of tap (ky, kx) of this workgroup's filter
+    auto wofs = [&](int ky_, int kx_) -> size_t {
+        if constexpr (PH) return (size_t)((k0y + 2 * ky_) * d.ks + (k0x + 2 * kx_)) * wtap;
+        else return (size_t)(ky_ * KS + kx_) * wtap;
+    };
     const float slope = d.tr.slope;
     if constexpr (TR) {
         for (int c = tid; c < d.Cin; c += 256) {
@@ -171,12 +214,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
 
     const int nchunks = (d.Cin + CCH - 1) / CCH;
     const int last_cc = d.Cin - (nchunks - 1) * CCH;
-    const int cin4 = d.Cin >> 2;
-    const int nunits = nchunks * KK;
+    const int nunits = nchunks * kkr;
     const int z = blockIdx.z;
     const int u0 = (int)(((long long)z * nunits) / ksplit);
     const int u1 = (int)(((long long)(z + 1) * nunits) / ksplit);
-    const int ch0 = u0 / KK;
+    const int ch0 = u0 / kkr;
 
     f32x16 acc[C::MS][C::NS];
 #pragma unroll
@@ -261,9 +303,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
         }
     };
     auto dmaB = [&](int u, int bbuf) {
-        const int ch = u / KK, tap = u - ch * KK;
+        const int ch = u / kkr, tap = u - ch * kkr;
         const int nb4 = (chunk_cc(ch) >> 2) * BN;
-        const float* sb = d.wp + ((size_t)(tap * cin4 + ((ch * CCH) >> 2)) * CoutP) * 4;
+        const int tky = PH ? tap / nkx : tap / KS, tkx = PH ? tap - tky * nkx : tap - tky * KS;
+        const float* sb = d.wp + wofs(tky, tkx) + ((size_t)((ch * CCH) >> 2) * CoutP) * 4;
         const unsigned m0b = lds_base + (unsigned)(2 * C::A_BUF + bbuf * C::B_BUF) * 4u + lds_piece;
 #pragma unroll
         for (int i = 0; i < C::B_SLOTS; ++i) {
@@ -381,11 +424,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
     };
 
     // incremental bookkeeping (no divisions in the loop)
-    int ch = ch0, tap = u0 - ch0 * KK;
-    int ky = tap / KS, kx = tap - ky * KS;
+    int ch = ch0, tap = u0 - ch0 * kkr;
+    int ky = PH ? tap / nkx : tap / KS, kx = PH ? tap - ky * nkx : tap - ky * KS;
     int abuf = 0, bbuf = 0;
-    const size_t wtap = (size_t)cin4 * CoutP * 4;                     // floats between taps in the packed weights
-    const float* wcur = d.wp + (size_t)tap * wtap + (size_t)(ch * (CCH / 4)) * CoutP * 4;
+    const float* wcur = d.wp + wofs(ky, kx) + (size_t)(ch * (CCH / 4)) * CoutP * 4;
     bool have_f0 = false;
     Frag F0;
     set_tap(ky, kx);
@@ -396,11 +438,18 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
         float* Anxt = As + (abuf ^ 1) * C::A_BUF;
         const float* Bcur = Bs + bbuf * C::B_BUF;
         const bool more = (u + 1) < u1;
-        const bool fetch_next = (u == u0 || tap == 0) && (ch + 1) * KK < u1;
-        const bool last_tap = (tap == KK - 1);
+        const bool fetch_next = (u == u0 || tap == 0) && (ch + 1) * kkr < u1;
+        const bool last_tap = (tap == kkr - 1);
         // next unit
         const int ch_n = last_tap ? ch + 1 : ch;
-        const float* wnext = last_tap ? d.wp + (size_t)((ch + 1) * (CCH / 4)) * CoutP * 4 : wcur + wtap;
+        const float* wnext;
+        if constexpr (PH) {
+            const bool row_end = (kx + 1 == nkx);
+            wnext = last_tap ? d.wp + wofs(0, 0) + (size_t)((ch + 1) * (CCH / 4)) * CoutP * 4
+                             : d.wp + wofs(row_end ? ky + 1 : ky, row_end ? 0 : kx + 1) + (size_t)(ch * (CCH / 4)) * CoutP * 4;
+        } else {
+            wnext = last_tap ? d.wp + (size_t)((ch + 1) * (CCH / 4)) * CoutP * 4 : wcur + wtap;
+        }
         const unsigned m0B = lds_base + (unsigned)(2 * C::A_BUF + (bbuf ^ 1) * C::B_BUF) * 4u + lds_piece;
         const unsigned m0A = lds_base + (unsigned)((abuf ^ 1) * C::A_BUF) * 4u + lds_piece;
         const float* asrc = d.x + (ch + 1) * CCH;
@@ -427,7 +476,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
             wcur = wnext;
             bbuf ^= 1;
             if (last_tap) { ch += 1; tap = 0; ky = 0; kx = 0; abuf ^= 1; }
-            else { tap += 1; kx += 1; if (kx == KS) { kx = 0; ky += 1; } }
+            else { tap += 1; kx += 1; if (kx == (PH ? nkx : KS)) { kx = 0; ky += 1; } }
             set_tap(ky, kx);
         };
 
@@ -532,8 +581,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
-                    const int oy = ty * C::TH + 2 * sub + (m >> 4);
-                    const int ox = tx * C::TW + (m & 15);
+                    int oy = ty * C::TH + 2 * sub + (m >> 4);
+                    int ox = tx * C::TW + (m & 15);
+                    if constexpr (PH) { oy = 2 * oy + py; ox = 2 * ox + px; }
                     if (oy < d.Hout && ox < d.Wout && n < d.Cy)
                         wz[((size_t)oy * d.Wout + ox) * d.Cy + n] = acc[ms][ns][r];
                 }
@@ -541,7 +591,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
         }
         return;
     }
-    const DipEpi epi = dip_epi_make(d, ty, tx, C::TH, C::TW);
+    DipEpi epi = dip_epi_make(d, ty, tx, C::TH, C::TW);
+    if constexpr (PH) {                    // tile (ty, tx) of the phase sub-grid: pixels (2a+py, 2b+px)
+        const int pitch = d.y_pitch > 0 ? d.y_pitch : d.Wout;
+        epi.yt = d.y + ((size_t)(2 * ty * C::TH + py) * pitch + (size_t)(2 * tx * C::TW + px)) * d.Cy;
+        epi.row_stride = 2 * pitch * d.Cy;
+        epi.Cy = 2 * d.Cy;
+        epi.rows_left = ((d.Hout - py + 1) >> 1) - ty * C::TH;
+        epi.cols_left = ((d.Wout - px + 1) >> 1) - tx * C::TW;
+        epi.full = (epi.rows_left >= C::TH) && (epi.cols_left >= C::TW);
+    }
     dip_conv_epilogue<C, BN>(d, acc, epi, n0, wn, wm, l31, half, tid, tile, CoutP, smem);
 #ifdef DIP_CLK_PROFILE
     __syncthreads();
@@ -558,21 +617,22 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
 #endif
 }
 
-template <int KS, int BN, bool TR>
+template <int KS, int BN, bool TR, bool PH = false>
 int launch_tr(const DipConvDesc& d, hipStream_t st, int n_base, int grid_y, int ksplit, float* ws) {
     using C = DCfg<KS, BN>;
     static bool attr_set = false;
-    auto kern = conv_igemm_dma_kernel<KS, BN, TR>;
+    auto kern = conv_igemm_dma_kernel<KS, BN, TR, PH>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e != hipSuccess) { dip_set_error(hipGetErrorString(e)); return (int)e; }
         attr_set = true;
     }
-    const int ntx = dip_cdiv(d.Wout, C::TW), nty = dip_cdiv(d.Hout, C::TH);
+    // phase mode tiles the (Hout+1)/2 x (Wout+1)/2 sub-grid of one parity, 4 workgroups per tile
+    const int ntx = dip_cdiv(PH ? (d.Wout + 1) / 2 : d.Wout, C::TW), nty = dip_cdiv(PH ? (d.Hout + 1) / 2 : d.Hout, C::TH);
     const int ntiles = ntx * nty;
     const int CoutP = dip_round_up(d.Cout, 32);
-    dim3 grid(ntiles, grid_y, ksplit);
+    dim3 grid(PH ? 4 * ntiles : ntiles, grid_y, ksplit);
     hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, st, d, ntx, ntiles, CoutP, n_base, ksplit, ws);
     DIP_CHECK_LAUNCH();
     return 0;
@@ -627,9 +687,22 @@ extern "C" int dip_conv_igemm_dma_cols(const DipConvDesc* dp, int n_base, void* 
     return launch<3, 128>(*dp, reinterpret_cast<hipStream_t>(stream), n_base, 1, 1, nullptr);
 }
 
+// true when the descriptor is the data gradient of a stride-2 3x3 convolution that the phase mode runs:
+// dilated input, zero padding, no fused transform / statistics, whole 128-column blocks
+extern "C" int dip_conv_phase_eligible(const DipConvDesc* dp) {
+    const DipConvDesc& d = *dp;
+    static const bool off = getenv("DIP_CONV_NO_PHASE") != nullptr;
+    if (off) return 0;
+    return d.dil == 2 && d.stride == 1 && d.ks == 3 && d.pad_mode == DIP_PAD_ZERO && d.tr.a == nullptr &&
+           d.stats == nullptr && d.off >= 1 && d.off <= 2 && (dip_round_up(d.Cout, 32) % 128) == 0 &&
+           d.ksplit <= (d.Cin + 31) / 32;
+}
+
 extern "C" int dip_conv_igemm_dma(const DipConvDesc* dp, int ksplit, void* stream) {
     const DipConvDesc& d = *dp;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (d.dil == 2 && dip_conv_phase_eligible(dp))
+        return launch_tr<2, 128, false, true>(d, st, 0, dip_round_up(d.Cout, 32) / 128, ksplit, d.ws);
     if (d.ks == 1) return launch_bn<1>(d, st, ksplit, d.ws);
     return launch_bn<3>(d, st, ksplit, d.ws);
 }

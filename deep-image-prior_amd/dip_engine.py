@@ -454,7 +454,10 @@ class SkipEngine:
             ops.append((self.lib.dip_conv_igemm, (C.byref(d),), "dgrad+:" + r.name))
             return accumulate_into
         gbuf = self._buf(Hg * Wg * Cg)
-        ksplit, _, wsf = N.conv_plan(Hg, Wg, round_up(r.Cout, 4), r.Cin, r.ks, 1)
+        if r.stride == 2:
+            ksplit, _, wsf = N.conv_plan_dil2(Hg, Wg, round_up(r.Cout, 4), r.Cin, r.ks)
+        else:
+            ksplit, _, wsf = N.conv_plan(Hg, Wg, round_up(r.Cout, 4), r.Cin, r.ks, 1)
         if self._sizing:
             self.ws_need = max(self.ws_need, wsf)
             return (gbuf, pad)

@@ -86,6 +86,8 @@ _SIGS = {
     "dip_conv_igemm_dma_cols": (C.c_int, [C.POINTER(DipConvDesc), C.c_int, C.c_void_p]),
     "dip_conv_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
                                 C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
+    "dip_conv_plan_dil2": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
+                                     C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "dip_conv_wgrad": (C.c_int, [C.POINTER(DipWgradDesc), C.c_void_p]),
     "dip_conv_wgrad_ntiles": (C.c_int, [C.c_int, C.c_int]),
     "dip_wgrad_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
@@ -176,6 +178,13 @@ def conv_plan(Hout, Wout, Cin, Cout, ks, stride):
     """(ksplit, stats_rows, ws_floats) of dip_conv_plan."""
     k, rows, wsf = C.c_int(), C.c_int(), C.c_int64()
     check(lib().dip_conv_plan(Hout, Wout, Cin, Cout, ks, stride, C.byref(k), C.byref(rows), C.byref(wsf)), "conv_plan")
+    return k.value, rows.value, wsf.value
+
+
+def conv_plan_dil2(Hout, Wout, Cin, Cout, ks):
+    """(ksplit, stats_rows, ws_floats) of dip_conv_plan_dil2 (data gradient of a stride-2 convolution)."""
+    k, rows, wsf = C.c_int(), C.c_int(), C.c_int64()
+    check(lib().dip_conv_plan_dil2(Hout, Wout, Cin, Cout, ks, C.byref(k), C.byref(rows), C.byref(wsf)), "conv_plan_dil2")
     return k.value, rows.value, wsf.value
 
 

@@ -115,11 +115,18 @@ int dip_conv_ntiles(int Hout, int Wout);
  * split-K workspace size in floats (0 when *ksplit == 1) */
 int dip_conv_plan(int Hout, int Wout, int Cin, int Cout, int ks, int stride, int* ksplit, int* stats_rows,
                   int64_t* ws_floats);
+/* launch plan of the data gradient of a stride-2 3x3 convolution (a dil == 2 descriptor; Hout x Wout is
+ * the gradient's domain, Cin/Cout the descriptor's): the LDS-DMA kernel's phase mode evaluates it as 4
+ * dense sub-filter convolutions, one per output-pixel parity (9 taps per 4 pixels instead of 36), with its
+ * own split-K bound.  Other filter sizes / column counts get dip_conv_plan's answer. */
+int dip_conv_plan_dil2(int Hout, int Wout, int Cin, int Cout, int ks, int* ksplit, int* stats_rows,
+                       int64_t* ws_floats);
 /* which kernel dip_conv_igemm launches for `d` (diagnostic; bench.py attributes its HIP-event times
  * with it): 0 = conv_igemm_kernel (operands staged through registers: stride 2, 5x5),
  * 1 = conv_igemm_dma_kernel (LDS-DMA staging: stride-1 1x1 / 3x3), 2 = conv_igemm_kernel N=160 variant
  * (3x3, 129..160 output channels, split-K), 3 = conv_thin4_kernel (columns 0..Cout-129 on the vector ALU)
- * + conv_igemm_dma_kernel (the other 128 columns): 3x3 data gradients towards a 132-channel tensor */
+ * + conv_igemm_dma_kernel (the other 128 columns): 3x3 data gradients towards a 132-channel tensor,
+ * 4 = conv_igemm_dma_kernel in phase mode (dil == 2: data gradient of a stride-2 3x3 convolution) */
 int dip_conv_variant(const DipConvDesc* d);
 /* The two launches behind variant 3, exported so that a caller can put them on DIFFERENT streams (they
  * write disjoint columns of the same output): columns [0, ncols) (ncols = Cout - 128 <= 4) of a 3x3

@@ -101,7 +101,14 @@ def conv_dgrad(dy, w, stride, pad_mode, Hin, Win, split=False):
     dyb = to_nhwc(dy)
     Cg = round_up(Cin, 4)
     g = torch.full((Hg * Wg * Cg,), float("nan"), dtype=torch.float32, device=dev)
-    ksplit, _, wsf = N.conv_plan(Hg, Wg, round_up(Cout, 4), Cin, ks, 1) if split else (1, 0, 0)
+    if not split:
+        ksplit, wsf = 1, 0
+    elif isinstance(split, int) and not isinstance(split, bool):      # forced split-K factor
+        ksplit, wsf = split, split * Hg * Wg * Cg
+    elif stride == 2:
+        ksplit, _, wsf = N.conv_plan_dil2(Hg, Wg, round_up(Cout, 4), Cin, ks)
+    else:
+        ksplit, _, wsf = N.conv_plan(Hg, Wg, round_up(Cout, 4), Cin, ks, 1)
     ws = torch.full((max(wsf, 4),), float("nan"), dtype=torch.float32, device=dev)
     d = N.DipConvDesc(dyb.data_ptr(), Ho, Wo, round_up(Cout, 4), round_up(Cout, 4), N.DipTransform(None, None, 1.0),
                       packed.data_ptr() + 4 * do, None, g.data_ptr(), Hg, Wg, Cg, Cin, 0, ks, 1, N.PAD_ZERO, off,

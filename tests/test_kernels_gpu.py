@@ -3,6 +3,7 @@ reference of the same op, at the layer shapes of the reference nets plus ragged 
 Tolerance: error vs fp64 no worse than 3x the error of torch's own fp32 CPU kernel (plus an
 fp32-roundoff floor) -- i.e. fp32-class numerics, no reduced precision anywhere."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -121,6 +122,67 @@ def test_conv_dgrad(dev, case, split):
         res[dt] = xx.grad
     gx = H.conv_dgrad(dy.to(dev), w.to(dev), stride, pad, Hh, Ww, split=split)
     _check("conv_dgrad", gx, res[torch.float64], res[torch.float32])
+
+
+PHASE_CASES = [
+    # Cin (= columns of the gradient, whole 128-blocks), Cout, pad, H, W
+    (128, 128, REFLECT, 32, 32),
+    (128, 128, ZERO, 16, 32),
+    (128, 256, REFLECT, 19, 27),      # odd sizes: ragged phase sub-grids
+    (128, 128, REFLECT, 18, 22),      # even size: the last padded row / column gets no contribution
+    (256, 36, REFLECT, 18, 22),       # two column blocks; 32 + 4-channel ragged K chunk
+    (128, 64, ZERO, 40, 72),
+]
+
+
+@pytest.mark.parametrize("split", [False, True, 2, 4], ids=["onepass", "planned", "k2", "k4"])
+@pytest.mark.parametrize("case", PHASE_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_dgrad_stride2_phase_mode(dev, case, split):
+    """Data gradient of the stride-2 3x3 convolutions: dip_conv_variant == 4, four dense sub-filter
+    convolutions (one per output parity) on the LDS-DMA kernel instead of a 3x3 over the dilated dy."""
+    Cin, Cout, pad, Hh, Ww = case
+    full = (Cin, Cout, 3, 2, pad, Hh, Ww, False)
+    x, w, b, _, _ = _mk(full, 1)
+    if isinstance(split, int) and not isinstance(split, bool) and split > (round_up(Cout, 4) + 31) // 32:
+        pytest.skip("split-K factor above the channel chunks of the 1-tap phase")
+    res = {}
+    for dt in (torch.float64, torch.float32):
+        xx = x.to(dt).requires_grad_(True)
+        y = _ref_conv(xx, w, None, 2, pad, dt)
+        dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(7))
+        (y * dy.to(dt)).sum().backward()
+        res[dt] = xx.grad
+    # the descriptor H.conv_dgrad builds must be one the phase mode takes
+    Ho, Wo = dy.shape[2:]
+    P = 1 if pad == REFLECT else 0
+    d = N.DipConvDesc(None, Ho, Wo, round_up(Cout, 4), round_up(Cout, 4), N.DipTransform(None, None, 1.0), None, None,
+                      None, Hh + 2 * P, Ww + 2 * P, Cin, Cin, 0, 3, 1, N.PAD_ZERO, 2 if pad == REFLECT else 1, 2, 0, None,
+                      1, None)
+    assert N.lib().dip_conv_variant(C.byref(d)) == 4
+    gx = H.conv_dgrad(dy.to(dev), w.to(dev), 2, pad, Hh, Ww, split=split)
+    _check("conv_dgrad(phase)", gx, res[torch.float64], res[torch.float32])
+
+
+def test_conv_dgrad_phase_mode_equals_dilated_evaluation(dev, tmp_path):
+    """The phase mode keeps the non-zero terms of the dilated evaluation in their order, so one pass of
+    it is bit-identical to the old kernel (run in a subprocess with DIP_CONV_NO_PHASE=1)."""
+    import subprocess
+    import sys
+    case = (128, 128, 3, 2, REFLECT, 32, 48, False)
+    x, w, b, _, _ = _mk(case, 1)
+    y = _ref_conv(x, w, None, 2, REFLECT, torch.float32)
+    dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(7))
+    gx = H.conv_dgrad(dy.to(dev), w.to(dev), 2, REFLECT, 32, 48, split=False).cpu()
+    torch.save({"dy": dy, "w": w}, tmp_path / "in.pt")
+    code = ("import sys, torch; sys.path[:0] = [%r, %r]; import hipops as H, dip_native as N\n"
+            "d = torch.load(%r); dev = torch.device('cuda:0')\n"
+            "g = H.conv_dgrad(d['dy'].to(dev), d['w'].to(dev), 2, N.PAD_REFLECT, 32, 48, split=False)\n"
+            "torch.save(g.cpu(), %r)\n") % (os.path.dirname(__file__), os.path.dirname(N.__file__),
+                                             str(tmp_path / "in.pt"), str(tmp_path / "out.pt"))
+    env = dict(os.environ, DIP_CONV_NO_PHASE="1")
+    subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=300)
+    old = torch.load(tmp_path / "out.pt")
+    assert torch.equal(gx, old)
 
 
 @pytest.mark.parametrize("nsplit", [None, "plan"], ids=["nsplit7", "planned"])
