@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "dip_hip.h"
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -86,6 +87,15 @@ __device__ __forceinline__ void dip_chan_d(double& na, double& ma, double& Ma, d
         Ma = Ma + Mb + d * d * na * f;
     }
     na = n;
+}
+
+// compile-time loop: f(std::integral_constant<int, I>{}) for I in [I0, N)
+template <int I, int N, class F>
+__device__ __forceinline__ void dip_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        dip_static_for<I + 1, N>(f);
+    }
 }
 
 // XCD-aware bijective remap of a linear workgroup id: consecutive ids land on different XCDs
