@@ -295,7 +295,7 @@ def profile_ops(eng, reps=3):
                     mids[k] = ("#thin4", "#dma", torch.cuda.Event(enable_timing=True))
                     mids[k][2].record(stream)
                     lib.dip_conv_igemm_dma_cols(args[0], ncols, sptr)
-                elif variant in (1, 4) and args[0]._obj.ksplit > 1:
+                elif variant in (1, 4, 5) and args[0]._obj.ksplit > 1:
                     lib.dip_conv_igemm_dma(args[0], args[0]._obj.ksplit, sptr)
                     mids[k] = ("#main", "#finish", torch.cuda.Event(enable_timing=True))
                     mids[k][2].record(stream)

@@ -486,8 +486,11 @@ extern "C" int dip_conv_plan(int Hout, int Wout, int Cin, int Cout, int ks, int 
                              int* stats_rows, int64_t* ws_floats) {
     const int ntiles = dip_conv_ntiles(Hout, Wout);
     const int gy = dip_cdiv(dip_round_up(Cout, 32), 128);
-    const int units = units_of(dip_round_up(Cin, 4), ks, stride);
+    int units = units_of(dip_round_up(Cin, 4), ks, stride);
     if (!units) DIP_FAIL("conv_plan: unsupported kernel size / stride");
+    // 3x3 stride 2 normally runs on the LDS-DMA kernel (strided forward mode): 32-channel units
+    static const bool s2dma = getenv("DIP_CONV_NO_S2DMA") == nullptr && getenv("DIP_CONV_NO_DMA") == nullptr;
+    if (s2dma && ks == 3 && stride == 2 && Cin <= 288) units = dip_cdiv(dip_round_up(Cin, 4), 32) * 9;
     int k = 1;
     const int wgs = ntiles * gy;
     if (wgs <= 256) {          // fill ~3 workgroups per CU, but keep >= 2 K-units per slice and <= 24 slices
@@ -564,7 +567,7 @@ extern "C" int dip_conv_variant(const DipConvDesc* dp) {
         return 3;
     // otherwise N = 160 in one pass: a fifth 32-column block spread over the four waves
     if (!no_extra && d.ks == 3 && d.stride == 1 && CoutP == 160 && d.stats == nullptr && (d.Cin % 32) == 0) return 2;
-    if (!no_dma && dip_conv_dma_eligible(dp)) return 1;
+    if (!no_dma && dip_conv_dma_eligible(dp)) return d.stride == 2 ? 5 : 1;
     return 0;
 }
 
@@ -590,7 +593,8 @@ extern "C" int dip_conv_igemm(const DipConvDesc* dp, void* stream) {
     int ksplit = d.ksplit > 1 ? d.ksplit : 1;
     if (ksplit > 1) {
         if (d.ws == nullptr) DIP_FAIL("conv_igemm: ksplit > 1 needs a workspace");
-        const int units = units_of(d.Cin, d.ks, d.stride);
+        int units = units_of(d.Cin, d.ks, d.stride);
+        if (dip_conv_variant(dp) == 5) units = dip_cdiv(d.Cin, 32) * 9;     // 32-channel units of the LDS-DMA kernel
         if (ksplit > units) DIP_FAIL("conv_igemm: ksplit exceeds the number of K units");
     }
     int rc;
@@ -601,7 +605,7 @@ extern "C" int dip_conv_igemm(const DipConvDesc* dp, void* stream) {
         if (rc) return rc;
         return dip_conv_igemm_dma_cols(dp, ncols, stream);
     }
-    if (variant == 1 || variant == 4) rc = dip_conv_igemm_dma(dp, ksplit, stream);
+    if (variant == 1 || variant == 4 || variant == 5) rc = dip_conv_igemm_dma(dp, ksplit, stream);
     else if (d.ks == 1 && d.stride == 1) rc = launch_bn<1, 1, 32>(d, st, ksplit, d.ws);
     else if (d.ks == 3 && d.stride == 1) rc = launch_bn<3, 1, 32>(d, st, ksplit, d.ws);
     else if (d.ks == 3 && d.stride == 2) rc = launch_bn<3, 2, 16>(d, st, ksplit, d.ws);

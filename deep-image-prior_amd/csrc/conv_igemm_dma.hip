@@ -41,7 +41,7 @@ struct SFor<N, N> {
 
 __device__ __attribute__((aligned(16))) float g_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
 
-template <int KS, int BN>
+template <int KS, int BN, int NTAB = 1>
 struct DCfg {
     static constexpr int TH = 8, TW = 16;
     static constexpr int HTH = TH - 1 + KS, HTW = TW - 1 + KS;
@@ -55,7 +55,7 @@ struct DCfg {
     static constexpr int NS = BN / 32 / WN;
     static constexpr int A_SLOTS = (NPIX * 8 + 255) / 256;
     static constexpr int B_SLOTS = (8 * BN + 255) / 256;
-    static constexpr int LDS_BYTES = (2 * A_BUF + 2 * B_BUF + NPIX + 2 * TRN) * 4;
+    static constexpr int LDS_BYTES = (2 * A_BUF + 2 * B_BUF + NTAB * NPIX + 2 * TRN) * 4;
 };
 
 __device__ __forceinline__ int map_src(int v, int n_in, int dil, int reflect) {
@@ -120,18 +120,25 @@ __device__ unsigned g_trace[128 * 8];
 #define PROBE(i) do { } while (0)
 #endif
 
-// PH (phase mode, the data gradient of a stride-2 convolution): the descriptor describes the dilated
+// MODE 1 (phase mode, the data gradient of a stride-2 convolution): the descriptor describes the dilated
 // problem (dil == 2, filter d.ks = 2*KS-1, zero padding), the kernel runs it as 4 dense convolutions,
 // one per parity (py, px) of the output pixel: output (2a+py, 2b+px) only sees the filter taps
 // k = k0 + 2j with k0 = (off - p) & 1, which read dy[a + j - (off - p - k0)/2] -- a KS x KS (or smaller)
 // dense filter over the UNdilated input.  9 taps per 4 pixels instead of 36; the terms that remain are
 // summed in the same order as in the dilated evaluation, so the result is bit-identical to it.
 // Workgroup id -> (tile, phase): the 4 phases of a tile are neighbours (same dy halo in L2).
-template <int KS, int BN, bool TR, bool PH = false>
+// MODE 2 (strided forward: stride 2, filter d.ks = 2*KS-1): the mirror image -- the INPUT is split by the parity
+// (py, px) of its pixel; tap k = k0 + 2j of parity p reads x[2(q + m_min + j) + p], a dense KS x KS (or smaller)
+// filter over the sub-grid of that parity.  One workgroup walks the 4 sub-grids one after the other: K units =
+// (parity, channel chunk, sub-filter tap), 9 per chunk in total as for a stride-1 3x3, and each
+// (parity, chunk) pair has its own halo (gathered by the LDS-DMA with a pixel stride of 2).
+template <int KS, int BN, bool TR, int MODE = 0>
 __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDesc d, const int ntx, const int ntiles,
                                                                 const int CoutP, const int n_base, const int ksplit,
                                                                 float* __restrict__ ws) {
-    using C = DCfg<KS, BN>;
+    constexpr bool PH = (MODE == 1);
+    constexpr bool SF = (MODE == 2);
+    using C = DCfg<KS, BN, SF ? 4 : 1>;
 #ifdef DIP_CLK_PROFILE
     const unsigned long long wall0 = wall_clock64(), clk0 = clock64();
 #endif
@@ -141,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
     float* As = smem;                                   // 2 halo buffers
     float* Bs = smem + 2 * C::A_BUF;                    // 2 weight slabs
     int* srcoff = reinterpret_cast<int*>(Bs + 2 * C::B_BUF);
-    float* tra = reinterpret_cast<float*>(srcoff + C::NPIX);
+    float* tra = reinterpret_cast<float*>(srcoff + (SF ? 4 : 1) * C::NPIX);
     float* trb = tra + TRN;
 
     const int tid = threadIdx.x;
@@ -182,15 +189,34 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
     } else {
         tile = dip_xcd_remap(blockIdx.x, ntiles);
     }
-    const int kkr = PH ? nky * nkx : KS * KS;           // taps of this workgroup's filter
+    int kkr = PH ? nky * nkx : KS * KS;                 // taps of the current filter (SF: of the current parity)
     const int ty = tile / ntx, tx = tile - ty * ntx;
     const int n0 = n_base + blockIdx.y * BN;
 
-    for (int hp = tid; hp < C::NPIX; hp += 256) {
-        const int hr = hp / C::HTW, hc = hp - hr * C::HTW;
-        const int sr = map_src(ty * C::TH + hr - offy, d.Hin, PH ? 1 : d.dil, d.pad_mode);
-        const int sc = map_src(tx * C::TW + hc - offx, d.Win, PH ? 1 : d.dil, d.pad_mode);
-        srcoff[hp] = (sr < 0 || sc < 0) ? -1 : (sr * d.Win + sc);
+    // SF: parity p of an input coordinate v = 2a + p -> first tap k0, taps, and a - q of the first tap
+    auto sf_dim = [&](int p_, int& k0_, int& nk_, int& mmin_) {
+        k0_ = (p_ + d.off) & 1;
+        nk_ = (d.ks - k0_ + 1) >> 1;
+        mmin_ = (k0_ - d.off - p_) >> 1;                // (even numerator)
+    };
+    if constexpr (SF) {
+        for (int i = tid; i < 4 * C::NPIX; i += 256) {
+            const int ph_ = i / C::NPIX, hp = i - ph_ * C::NPIX;
+            const int hr = hp / C::HTW, hc = hp - hr * C::HTW;
+            int a0, a1, my, mx;
+            sf_dim(ph_ >> 1, a0, a1, my);
+            sf_dim(ph_ & 1, a0, a1, mx);
+            const int sr = map_src(2 * (ty * C::TH + hr + my) + (ph_ >> 1), d.Hin, 1, d.pad_mode);
+            const int sc = map_src(2 * (tx * C::TW + hc + mx) + (ph_ & 1), d.Win, 1, d.pad_mode);
+            srcoff[i] = (sr < 0 || sc < 0) ? -1 : (sr * d.Win + sc);
+        }
+    } else {
+        for (int hp = tid; hp < C::NPIX; hp += 256) {
+            const int hr = hp / C::HTW, hc = hp - hr * C::HTW;
+            const int sr = map_src(ty * C::TH + hr - offy, d.Hin, PH ? 1 : d.dil, d.pad_mode);
+            const int sc = map_src(tx * C::TW + hc - offx, d.Win, PH ? 1 : d.dil, d.pad_mode);
+            srcoff[hp] = (sr < 0 || sc < 0) ? -1 : (sr * d.Win + sc);
+        }
     }
     // 3x3: the thread that DMA'd a slot transforms it IN PLACE once its own DMA has landed (after its
     // own vmcnt(0), before the unit's barrier) -- 1/18 of the VALU work of transforming at every
@@ -201,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
     const size_t wtap = (size_t)(d.Cin >> 2) * CoutP * 4;            // floats between taps in the packed weights
     // packed-weight offset of tap (ky, kx) of this workgroup's filter
     auto wofs = [&](int ky_, int kx_) -> size_t {
-        if constexpr (PH) return (size_t)((k0y + 2 * ky_) * d.ks + (k0x + 2 * kx_)) * wtap;
+        if constexpr (PH || SF) return (size_t)((k0y + 2 * ky_) * d.ks + (k0x + 2 * kx_)) * wtap;
         else return (size_t)(ky_ * KS + kx_) * wtap;
     };
     const float slope = d.tr.slope;
@@ -214,11 +240,31 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
 
     const int nchunks = (d.Cin + CCH - 1) / CCH;
     const int last_cc = d.Cin - (nchunks - 1) * CCH;
-    const int nunits = nchunks * kkr;
+    const int nunits = SF ? nchunks * d.ks * d.ks : nchunks * kkr;
     const int z = blockIdx.z;
     const int u0 = (int)(((long long)z * nunits) / ksplit);
     const int u1 = (int)(((long long)(z + 1) * nunits) / ksplit);
-    const int ch0 = u0 / kkr;
+    // SF: units run parity-major: parity ph owns nchunks * taps(ph) consecutive units
+    int ph = 0, mmy = 0, mmx = 0, tap0 = 0;
+    auto sf_set_phase = [&](int ph_) {
+        sf_dim(ph_ >> 1, k0y, nky, mmy);
+        sf_dim(ph_ & 1, k0x, nkx, mmx);
+        kkr = nky * nkx;
+    };
+    int ch0;
+    if constexpr (SF) {
+        int rem = u0;
+        for (ph = 0; ph < 4; ++ph) {
+            sf_set_phase(ph);
+            if (rem < nchunks * kkr) break;
+            rem -= nchunks * kkr;
+        }
+        ch0 = rem / kkr;
+        tap0 = rem - ch0 * kkr;
+    } else {
+        ch0 = u0 / kkr;
+        tap0 = u0 - ch0 * kkr;
+    }
 
     f32x16 acc[C::MS][C::NS];
 #pragma unroll
@@ -249,15 +295,21 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
     constexpr unsigned NONE = 0xffffffffu;
     unsigned aoff[C::A_SLOTS];             // halo piece i: (src_pixel*Cx + c4*4)*4 bytes, NONE = zero pad
     int ac4[C::A_SLOTS];                   // its channel group (un-swizzled), -1 = no such slot
+    // SF: the geometry registers describe the halo that is fetched / fixed up NEXT; gph = its parity
+    int gph = 0;
+    auto load_geom = [&](int ph_) {
+        gph = ph_;
 #pragma unroll
-    for (int i = 0; i < C::A_SLOTS; ++i) {
-        const int f = tid + i * 256;
-        const int hp = f >> 3;
-        const int c4 = (f & 7) ^ (hp & 7);
-        ac4[i] = hp < C::NPIX ? c4 : -1;
-        const int so = hp < C::NPIX ? srcoff[hp] : -1;
-        aoff[i] = so >= 0 ? (unsigned)(so * d.Cx + c4 * 4) * 4u : NONE;
-    }
+        for (int i = 0; i < C::A_SLOTS; ++i) {
+            const int f = tid + i * 256;
+            const int hp = f >> 3;
+            const int c4 = (f & 7) ^ (hp & 7);
+            ac4[i] = hp < C::NPIX ? c4 : -1;
+            const int so = hp < C::NPIX ? srcoff[ph_ * C::NPIX + hp] : -1;
+            aoff[i] = so >= 0 ? (unsigned)(so * d.Cx + c4 * 4) * 4u : NONE;
+        }
+    };
+    load_geom(SF ? ph : 0);
     unsigned boff[C::B_SLOTS];             // weight piece i: ((c4*CoutP + column)*4)*4 bytes
 #pragma unroll
     for (int i = 0; i < C::B_SLOTS; ++i) {
@@ -302,11 +354,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
             }
         }
     };
-    auto dmaB = [&](int u, int bbuf) {
-        const int ch = u / kkr, tap = u - ch * kkr;
+    auto dmaB = [&](const float* sb, int ch, int bbuf) {      // weight slab of one unit: sb = its packed weights
         const int nb4 = (chunk_cc(ch) >> 2) * BN;
-        const int tky = PH ? tap / nkx : tap / KS, tkx = PH ? tap - tky * nkx : tap - tky * KS;
-        const float* sb = d.wp + wofs(tky, tkx) + ((size_t)((ch * CCH) >> 2) * CoutP) * 4;
         const unsigned m0b = lds_base + (unsigned)(2 * C::A_BUF + bbuf * C::B_BUF) * 4u + lds_piece;
 #pragma unroll
         for (int i = 0; i < C::B_SLOTS; ++i) {
@@ -359,11 +408,28 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
         }
     };
 
+    // incremental bookkeeping (no divisions in the loop)
+    int ch = ch0, tap = tap0;
+    int ky = (PH || SF) ? tap / nkx : tap / KS, kx = (PH || SF) ? tap - ky * nkx : tap - ky * KS;
+    int abuf = 0, bbuf = 0;
+    const float* wcur = d.wp + wofs(ky, kx) + (size_t)(ch * (CCH / 4)) * CoutP * 4;
+    // SF: the (parity, chunk) pair after (ph_, ch_); parity 4 = none
+    auto sf_next = [&](int ph_, int ch_, int& phn_, int& chn_) {
+        chn_ = ch_ + 1;
+        phn_ = ph_;
+        if (chn_ == nchunks) { chn_ = 0; phn_ = ph_ + 1; }
+    };
+
     // ---- prologue ----
     dmaA(ch0, 0);
-    dmaB(u0, 0);
+    dmaB(wcur, ch0, 0);
     dma_wait();
     if (fix_inplace) fixA(ch0, As);
+    if constexpr (SF) {                    // geometry of the halo after the first one
+        int phn, chn;
+        sf_next(ph, ch, phn, chn);
+        if (phn < 4 && phn != gph) load_geom(phn);
+    }
     __syncthreads();
     // Halo DMAs of this wave per chunk (wave-uniform).  The unit that issues the next chunk's halo
     // waits only for its weights: loads retire in order and the halo is issued AFTER the weights, so
@@ -423,11 +489,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
         });
     };
 
-    // incremental bookkeeping (no divisions in the loop)
-    int ch = ch0, tap = u0 - ch0 * kkr;
-    int ky = PH ? tap / nkx : tap / KS, kx = PH ? tap - ky * nkx : tap - ky * KS;
-    int abuf = 0, bbuf = 0;
-    const float* wcur = d.wp + wofs(ky, kx) + (size_t)(ch * (CCH / 4)) * CoutP * 4;
     bool have_f0 = false;
     Frag F0;
     set_tap(ky, kx);
@@ -438,12 +499,25 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
         float* Anxt = As + (abuf ^ 1) * C::A_BUF;
         const float* Bcur = Bs + bbuf * C::B_BUF;
         const bool more = (u + 1) < u1;
-        const bool fetch_next = (u == u0 || tap == 0) && (ch + 1) * kkr < u1;
+        // the halo after the current one: chunk chx (SF: of parity phx)
+        int chx = ch + 1, phx = ph;
+        if constexpr (SF) sf_next(ph, ch, phx, chx);
+        const bool fetch_next = (u == u0 || tap == 0) && (SF ? (u - tap + kkr) < u1 : (ch + 1) * kkr < u1);
         const bool last_tap = (tap == kkr - 1);
         // next unit
-        const int ch_n = last_tap ? ch + 1 : ch;
+        const int ch_n = last_tap ? chx : ch;
         const float* wnext;
-        if constexpr (PH) {
+        if constexpr (SF) {
+            const bool row_end = (kx + 1 == nkx);
+            if (!last_tap) {
+                wnext = d.wp + wofs(row_end ? ky + 1 : ky, row_end ? 0 : kx + 1) + (size_t)(ch * (CCH / 4)) * CoutP * 4;
+            } else {                        // first tap of the next (parity, chunk) pair
+                int a0, a1, b0, b1;
+                sf_dim(phx >> 1, a0, a1, b1);
+                sf_dim(phx & 1, b0, a1, b1);
+                wnext = d.wp + (size_t)(a0 * d.ks + b0) * wtap + (size_t)(chx * (CCH / 4)) * CoutP * 4;
+            }
+        } else if constexpr (PH) {
             const bool row_end = (kx + 1 == nkx);
             wnext = last_tap ? d.wp + wofs(0, 0) + (size_t)((ch + 1) * (CCH / 4)) * CoutP * 4
                              : d.wp + wofs(row_end ? ky + 1 : ky, row_end ? 0 : kx + 1) + (size_t)(ch * (CCH / 4)) * CoutP * 4;
@@ -452,9 +526,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
         }
         const unsigned m0B = lds_base + (unsigned)(2 * C::A_BUF + (bbuf ^ 1) * C::B_BUF) * 4u + lds_piece;
         const unsigned m0A = lds_base + (unsigned)((abuf ^ 1) * C::A_BUF) * 4u + lds_piece;
-        const float* asrc = d.x + (ch + 1) * CCH;
+        const float* asrc = d.x + chx * CCH;
         const bool nextB_full = more && chunk_cc(ch_n) == CCH;
-        const bool nextA_full = fetch_next && chunk_cc(ch + 1) == CCH;
+        const bool nextA_full = fetch_next && chunk_cc(chx) == CCH;
 
         auto unit_end = [&]() {             // publish the next unit's operands
             if (!more) return;
@@ -467,7 +541,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
                 if (fetch_next || a_state == 1) a_state = 2;
             }
             if (need_now && a_state == 2) {
-                if (fix_inplace) fixA(ch + 1, Anxt);
+                if (fix_inplace) fixA(chx, Anxt);
                 a_state = 0;
             }
             __syncthreads();
@@ -475,8 +549,24 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
         auto advance = [&]() {              // bookkeeping of unit u+1 (valid only if more)
             wcur = wnext;
             bbuf ^= 1;
-            if (last_tap) { ch += 1; tap = 0; ky = 0; kx = 0; abuf ^= 1; }
-            else { tap += 1; kx += 1; if (kx == (PH ? nkx : KS)) { kx = 0; ky += 1; } }
+            if (last_tap) {
+                if constexpr (SF) {
+                    // into (phx, chx); its halo is landed and fixed up, so the geometry registers move on to the pair
+                    // after it
+                    if (phx != ph) sf_set_phase(phx);
+                    ph = phx;
+                    ch = chx;
+                    int ph2, ch2;
+                    sf_next(ph, ch, ph2, ch2);
+                    if (ph2 < 4 && ph2 != gph) load_geom(ph2);
+                } else {
+                    ch += 1;
+                }
+                tap = 0; ky = 0; kx = 0; abuf ^= 1;
+            } else {
+                tap += 1; kx += 1;
+                if (kx == ((PH || SF) ? nkx : KS)) { kx = 0; ky += 1; }
+            }
             set_tap(ky, kx);
         };
 
@@ -487,7 +577,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
             mma_frag(F0, [&](auto J) {                       // weights of unit u+1
                 if (nextB_full) dmaB_slot(J, wnext, m0B);
             });
-            if (more && !nextB_full) dmaB(u + 1, bbuf ^ 1);  // ragged last chunk: generic issue
+            if (more && !nextB_full) dmaB(wnext, ch_n, bbuf ^ 1);  // ragged last chunk: generic issue
             read_frag(F2, Acur, Bcur, cb, 2);
             mma_frag(F1, [&](auto J) {                       // halo of chunk ch+1, pieces 0..3
                 if (nextA_full) dmaA_slot(J, asrc, m0A, 8);
@@ -497,14 +587,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
                 constexpr int j = decltype(J)::value;
                 if (nextA_full) dmaA_slot(std::integral_constant<int, 4 + j>{}, asrc, m0A, 8);
             });
-            if (fetch_next && !nextA_full) dmaA(ch + 1, abuf ^ 1);
+            if (fetch_next && !nextA_full) dmaA(chx, abuf ^ 1);
             unit_end();
             // The last 16 MFMAs of this unit run AFTER the barrier (their operands are in registers):
             // they cover the next unit's first LDS reads and, one unit after its halo has landed,
             // the in-place fix-up of that halo.
             const bool do_fix = more && a_state == 2;
-            const int cb_n = (ch + 1) * CCH;
-            const bool fix_full = chunk_cc(ch + 1) == CCH;
+            const int cb_n = chx * CCH;
+            const bool fix_full = chunk_cc(chx) == CCH;
             const bool pre = more && chunk_cc(ch_n) == CCH;
             if (more) advance();
             if (pre) read_frag(F0, As + abuf * C::A_BUF, Bs + bbuf * C::B_BUF, ch * CCH, 0);
@@ -522,10 +612,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
             }
         } else {
             // ragged last chunk (cc < 32): issue first, then a rolled loop
-            if (more) dmaB(u + 1, bbuf ^ 1);
-            if (fetch_next) dmaA(ch + 1, abuf ^ 1);
+            if (more) dmaB(wnext, ch_n, bbuf ^ 1);
+            if (fetch_next) dmaA(chx, abuf ^ 1);
             if (a_state == 2) {
-                if (fix_inplace) fixA(ch + 1, Anxt);
+                if (fix_inplace) fixA(chx, Anxt);
                 a_state = 0;
             }
             const int kk8 = cc >> 3;
@@ -617,11 +707,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
 #endif
 }
 
-template <int KS, int BN, bool TR, bool PH = false>
+template <int KS, int BN, bool TR, int MODE = 0>
 int launch_tr(const DipConvDesc& d, hipStream_t st, int n_base, int grid_y, int ksplit, float* ws) {
-    using C = DCfg<KS, BN>;
+    using C = DCfg<KS, BN, MODE == 2 ? 4 : 1>;
+    constexpr bool PH = (MODE == 1);
     static bool attr_set = false;
-    auto kern = conv_igemm_dma_kernel<KS, BN, TR, PH>;
+    auto kern = conv_igemm_dma_kernel<KS, BN, TR, MODE>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
@@ -638,22 +729,22 @@ int launch_tr(const DipConvDesc& d, hipStream_t st, int n_base, int grid_y, int 
     return 0;
 }
 
-template <int KS, int BN>
+template <int KS, int BN, int MODE = 0>
 int launch(const DipConvDesc& d, hipStream_t st, int n_base, int grid_y, int ksplit, float* ws) {
-    return d.tr.a != nullptr ? launch_tr<KS, BN, true>(d, st, n_base, grid_y, ksplit, ws)
-                             : launch_tr<KS, BN, false>(d, st, n_base, grid_y, ksplit, ws);
+    return d.tr.a != nullptr ? launch_tr<KS, BN, true, MODE>(d, st, n_base, grid_y, ksplit, ws)
+                             : launch_tr<KS, BN, false, MODE>(d, st, n_base, grid_y, ksplit, ws);
 }
 
-template <int KS>
+template <int KS, int MODE = 0>
 int launch_bn(const DipConvDesc& d, hipStream_t st, int ksplit, float* ws) {
     const int CoutP = dip_round_up(d.Cout, 32);
     const int nfull = CoutP / 128, rem = CoutP - nfull * 128;
     int rc = 0;
-    if (nfull) rc = launch<KS, 128>(d, st, 0, nfull, ksplit, ws);
+    if (nfull) rc = launch<KS, 128, MODE>(d, st, 0, nfull, ksplit, ws);
     if (rc || !rem) return rc;
-    if (rem <= 32) return launch<KS, 32>(d, st, nfull * 128, 1, ksplit, ws);
-    if (rem <= 64) return launch<KS, 64>(d, st, nfull * 128, 1, ksplit, ws);
-    return launch<KS, 128>(d, st, nfull * 128, 1, ksplit, ws);
+    if (rem <= 32) return launch<KS, 32, MODE>(d, st, nfull * 128, 1, ksplit, ws);
+    if (rem <= 64) return launch<KS, 64, MODE>(d, st, nfull * 128, 1, ksplit, ws);
+    return launch<KS, 128, MODE>(d, st, nfull * 128, 1, ksplit, ws);
 }
 
 }  // namespace
@@ -661,7 +752,12 @@ int launch_bn(const DipConvDesc& d, hipStream_t st, int ksplit, float* ws) {
 // true when this variant can run the descriptor (see the restrictions in the file header)
 extern "C" int dip_conv_dma_eligible(const DipConvDesc* dp) {
     const DipConvDesc& d = *dp;
-    if (d.stride != 1 || (d.ks != 1 && d.ks != 3)) return 0;
+    static const bool no_s2 = getenv("DIP_CONV_NO_S2DMA") != nullptr;
+    if (d.stride == 2) {                             // strided forward mode: 3x3, undilated input
+        if (no_s2 || d.ks != 3 || d.dil != 1 || d.off != 1) return 0;
+    } else if (d.stride != 1 || (d.ks != 1 && d.ks != 3)) {
+        return 0;
+    }
     const bool has_tr = d.tr.a != nullptr;
     if (has_tr && d.Cin > TRN) return 0;
     if (has_tr && d.tr.slope <= 0.f) return 0;      // Swish / ELU: the register-staged kernel applies them at staging
@@ -702,7 +798,8 @@ extern "C" int dip_conv_igemm_dma(const DipConvDesc* dp, int ksplit, void* strea
     const DipConvDesc& d = *dp;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (d.dil == 2 && dip_conv_phase_eligible(dp))
-        return launch_tr<2, 128, false, true>(d, st, 0, dip_round_up(d.Cout, 32) / 128, ksplit, d.ws);
+        return launch_tr<2, 128, false, 1>(d, st, 0, dip_round_up(d.Cout, 32) / 128, ksplit, d.ws);
+    if (d.stride == 2) return launch_bn<2, 2>(d, st, ksplit, d.ws);        // (ks == 3: dip_conv_dma_eligible)
     if (d.ks == 1) return launch_bn<1>(d, st, ksplit, d.ws);
     return launch_bn<3>(d, st, ksplit, d.ws);
 }
