@@ -493,8 +493,10 @@ extern "C" int dip_conv_plan(int Hout, int Wout, int Cin, int Cout, int ks, int 
     if (s2dma && ks == 3 && stride == 2 && Cin <= 288) units = dip_cdiv(dip_round_up(Cin, 4), 32) * 9;
     int k = 1;
     const int wgs = ntiles * gy;
-    if (wgs <= 256) {          // fill ~3 workgroups per CU, but keep >= 2 K-units per slice and <= 24 slices
-        k = 768 / wgs;
+    if (wgs <= 256) {          // one full round of 2 workgroups per CU (768 was 1.3 % slower end to end: a half-empty
+                               // second round + more split-K slices to reduce), >= 2 K-units per slice, <= 24 slices
+        static const char* tw = getenv("DIP_CONV_PLAN_WGS");
+        k = (tw ? atoi(tw) : 512) / wgs;
         if (k > units / 2) k = units / 2;
         if (k > 24) k = 24;
         if (k < 1) k = 1;
