@@ -33,7 +33,12 @@ __device__ __forceinline__ RowLayout row_layout(int C) {
     return L;
 }
 
-__global__ __launch_bounds__(256) void upcat_fwd_kernel(const DipUpcatDesc d, int ppb) {
+// One thread = 4 channels of a 2x2 block of output pixels (low-resolution pixel (i, j) -> outputs (2i..2i+1, 2j..2j+1)):
+// the 3x3 low-resolution neighbourhood is loaded and put through the producer's BatchNorm+activation ONCE (2.25
+// transforms and loads per output instead of 4), the column blends are shared by the two output rows.  Scale-2
+// bilinear weights (align_corners = False): odd outputs (0.75, 0.25) on (i, i+1), even outputs (0.25, 0.75) on
+// (i-1, i), except output 0 = (1, 0) -- exactly upsample_bilinear2d's lambdas (bil_src above).
+__global__ __launch_bounds__(256) void upcat_fwd_kernel(const DipUpcatDesc d, int qpb) {
     __shared__ __attribute__((aligned(16))) float sh[256 * 12];
     const int C = d.ns + d.nd;
     const RowLayout L = row_layout(C);
@@ -42,11 +47,10 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const DipUpcatDesc d, in
     float n = 0.f;
     if (L.active) {
         const int ch = L.cg * 4;
-        const int npix = d.H * d.W;
-        const int p0 = blockIdx.x * ppb, p1 = min(p0 + ppb, npix);
         const int Hl = d.H >> 1, Wl = d.W >> 1;
-        // this thread's channel group never changes: its BatchNorm+LeakyReLU coefficients are loaded
-        // once (inside the loop every tap re-read them: 8 table loads next to 4 data loads per pixel)
+        const int nq = Hl * Wl;
+        const int q0 = blockIdx.x * qpb, q1 = min(q0 + qpb, nq);
+        // this thread's channel group never changes: its BatchNorm+activation coefficients are loaded once
         const bool skip_side = ch < d.ns;
         const DipTransform& tt = skip_side ? d.ts : d.td;
         const int tch = skip_side ? ch : ch - d.ns;
@@ -54,36 +58,20 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const DipUpcatDesc d, in
         const f32x4 tA = has_t ? ld4(tt.a + tch) : f32x4{1.f, 1.f, 1.f, 1.f};
         const f32x4 tB = has_t ? ld4(tt.b + tch) : f32x4{0.f, 0.f, 0.f, 0.f};
         const float tS = has_t ? tt.slope : 1.f;
+        const bool leaky = tS > 0.f;                 // (block-uniform: the branch is outside the element loops)
         auto trr = [&](f32x4 x) {
             f32x4 o;
+            if (leaky) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = dip_act(fmaf(tA[e], x[e], tB[e]), tS);
+                for (int e = 0; e < 4; ++e) o[e] = dip_act_leaky(fmaf(tA[e], x[e], tB[e]), tS);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = dip_act(fmaf(tA[e], x[e], tB[e]), tS);
+            }
             return o;
         };
-        for (int p = p0 + L.prow; p < p1; p += L.rpi) {
-            f32x4 v;
-            if (skip_side) {
-                v = trr(ld4(d.s + (size_t)p * d.Cs_s + ch));
-            } else {
-                const int cd = ch - d.ns;
-                const int r = p / d.W, c = p - r * d.W;
-                if (d.mode == DIP_UP_NEAREST) {
-                    v = trr(ld4(d.d + ((size_t)(r >> 1) * Wl + (c >> 1)) * d.Cs_d + cd));
-                } else {
-                    int r0, r1, c0, c1;
-                    float lr0, lr1, lc0, lc1;
-                    bil_src(r, Hl, r0, r1, lr0, lr1);
-                    bil_src(c, Wl, c0, c1, lc0, lc1);
-                    const f32x4 v00 = trr(ld4(d.d + ((size_t)r0 * Wl + c0) * d.Cs_d + cd));
-                    const f32x4 v01 = trr(ld4(d.d + ((size_t)r0 * Wl + c1) * d.Cs_d + cd));
-                    const f32x4 v10 = trr(ld4(d.d + ((size_t)r1 * Wl + c0) * d.Cs_d + cd));
-                    const f32x4 v11 = trr(ld4(d.d + ((size_t)r1 * Wl + c1) * d.Cs_d + cd));
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        v[e] = lr0 * (lc0 * v00[e] + lc1 * v01[e]) + lr1 * (lc0 * v10[e] + lc1 * v11[e]);
-                }
-            }
-            st4(d.cat + (size_t)p * d.Cs_cat + ch, v);
+        auto emit = [&](size_t p, const f32x4& v) {
+            st4(d.cat + p * d.Cs_cat + ch, v);
             if (n == 0.f) K = v;
             n += 1.f;
 #pragma unroll
@@ -91,6 +79,60 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const DipUpcatDesc d, in
                 const float dv = v[e] - K[e];
                 s1[e] += dv;
                 s2[e] += dv * dv;
+            }
+        };
+        for (int q = q0 + L.prow; q < q1; q += L.rpi) {
+            const int i = q / Wl, j = q - i * Wl;
+            const size_t p00 = (size_t)(2 * i) * d.W + 2 * j;
+            if (skip_side) {
+                const float* sp = d.s + p00 * d.Cs_s + ch;
+                const f32x4 a0 = ld4(sp), a1 = ld4(sp + d.Cs_s), a2 = ld4(sp + (size_t)d.W * d.Cs_s),
+                            a3 = ld4(sp + ((size_t)d.W + 1) * d.Cs_s);
+                emit(p00, trr(a0));
+                emit(p00 + 1, trr(a1));
+                emit(p00 + d.W, trr(a2));
+                emit(p00 + d.W + 1, trr(a3));
+            } else if (d.mode == DIP_UP_NEAREST) {
+                const f32x4 v = trr(ld4(d.d + (size_t)q * d.Cs_d + (ch - d.ns)));
+                emit(p00, v);
+                emit(p00 + 1, v);
+                emit(p00 + d.W, v);
+                emit(p00 + d.W + 1, v);
+            } else {
+                const int cd = ch - d.ns;
+                const int rr[3] = {max(i - 1, 0), i, min(i + 1, Hl - 1)};
+                const int cc[3] = {max(j - 1, 0), j, min(j + 1, Wl - 1)};
+                f32x4 t[3][3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) t[a][b] = ld4(d.d + ((size_t)rr[a] * Wl + cc[b]) * d.Cs_d + cd);
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) t[a][b] = trr(t[a][b]);
+                const float le0 = i > 0 ? 0.25f : 1.f, le1 = i > 0 ? 0.75f : 0.f;
+                const float ce0 = j > 0 ? 0.25f : 1.f, ce1 = j > 0 ? 0.75f : 0.f;
+                f32x4 E[3], O[3];                    // column blends of the three low-resolution rows
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        E[a][e] = ce0 * t[a][0][e] + ce1 * t[a][1][e];
+                        O[a][e] = 0.75f * t[a][1][e] + 0.25f * t[a][2][e];
+                    }
+                f32x4 v00, v01, v10, v11;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v00[e] = le0 * E[0][e] + le1 * E[1][e];
+                    v01[e] = le0 * O[0][e] + le1 * O[1][e];
+                    v10[e] = 0.75f * E[1][e] + 0.25f * E[2][e];
+                    v11[e] = 0.75f * O[1][e] + 0.25f * O[2][e];
+                }
+                emit(p00, v00);
+                emit(p00 + 1, v01);
+                emit(p00 + d.W, v10);
+                emit(p00 + d.W + 1, v11);
             }
         }
     }
@@ -339,9 +381,10 @@ extern "C" int dip_upcat_fwd(const DipUpcatDesc* d, void* stream) {
     if ((d->H & 1) || (d->W & 1)) DIP_FAIL("upcat_fwd: output size must be even");
     if (C > 1024) DIP_FAIL("upcat_fwd: C > 1024 unsupported");
     int nb;
-    const int ppb = pixels_per_block(d->H * d->W, C, &nb);
+    pixels_per_block(d->H * d->W, C, &nb);
     if (nb != d->nblk) DIP_FAIL("upcat_fwd: nblk mismatch (use dip_upcat_nblk)");
-    hipLaunchKernelGGL(upcat_fwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *d, ppb);
+    const int qpb = dip_cdiv((d->H / 2) * (d->W / 2), nb);       // 2x2 output blocks per workgroup
+    hipLaunchKernelGGL(upcat_fwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *d, qpb);
     DIP_CHECK_LAUNCH();
     return 0;
 }
