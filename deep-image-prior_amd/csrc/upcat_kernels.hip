@@ -47,7 +47,9 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const DipUpcatDesc d, in
     float n = 0.f;
     if (L.active) {
         const int ch = L.cg * 4;
-        const int Hl = d.H >> 1, Wl = d.W >> 1;
+        // low-resolution size: (H+1)/2 -- for an odd size the x2 up-sampled tensor is one row / column larger
+        // than the skip branch and Concat's centre crop (models/common.py:29-37, offset (1)//2 = 0) drops its last one
+        const int Hl = (d.H + 1) >> 1, Wl = (d.W + 1) >> 1;
         const int nq = Hl * Wl;
         const int q0 = blockIdx.x * qpb, q1 = min(q0 + qpb, nq);
         // this thread's channel group never changes: its BatchNorm+activation coefficients are loaded once
@@ -84,20 +86,22 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const DipUpcatDesc d, in
         for (int q = q0 + L.prow; q < q1; q += L.rpi) {
             const int i = q / Wl, j = q - i * Wl;
             const size_t p00 = (size_t)(2 * i) * d.W + 2 * j;
+            const bool r1 = 2 * i + 1 < d.H, c1 = 2 * j + 1 < d.W;     // second row / column of the block exists
             if (skip_side) {
                 const float* sp = d.s + p00 * d.Cs_s + ch;
-                const f32x4 a0 = ld4(sp), a1 = ld4(sp + d.Cs_s), a2 = ld4(sp + (size_t)d.W * d.Cs_s),
-                            a3 = ld4(sp + ((size_t)d.W + 1) * d.Cs_s);
+                // (clamped addresses: every load is issued, the ragged ones are not emitted)
+                const f32x4 a0 = ld4(sp), a1 = ld4(sp + (c1 ? d.Cs_s : 0)), a2 = ld4(sp + (r1 ? (size_t)d.W * d.Cs_s : 0)),
+                            a3 = ld4(sp + (r1 ? (size_t)d.W * d.Cs_s : 0) + (c1 ? d.Cs_s : 0));
                 emit(p00, trr(a0));
-                emit(p00 + 1, trr(a1));
-                emit(p00 + d.W, trr(a2));
-                emit(p00 + d.W + 1, trr(a3));
+                if (c1) emit(p00 + 1, trr(a1));
+                if (r1) emit(p00 + d.W, trr(a2));
+                if (r1 && c1) emit(p00 + d.W + 1, trr(a3));
             } else if (d.mode == DIP_UP_NEAREST) {
                 const f32x4 v = trr(ld4(d.d + (size_t)q * d.Cs_d + (ch - d.ns)));
                 emit(p00, v);
-                emit(p00 + 1, v);
-                emit(p00 + d.W, v);
-                emit(p00 + d.W + 1, v);
+                if (c1) emit(p00 + 1, v);
+                if (r1) emit(p00 + d.W, v);
+                if (r1 && c1) emit(p00 + d.W + 1, v);
             } else {
                 const int cd = ch - d.ns;
                 const int rr[3] = {max(i - 1, 0), i, min(i + 1, Hl - 1)};
@@ -130,9 +134,9 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const DipUpcatDesc d, in
                     v11[e] = 0.75f * O[1][e] + 0.25f * O[2][e];
                 }
                 emit(p00, v00);
-                emit(p00 + 1, v01);
-                emit(p00 + d.W, v10);
-                emit(p00 + d.W + 1, v11);
+                if (c1) emit(p00 + 1, v01);
+                if (r1) emit(p00 + d.W, v10);
+                if (r1 && c1) emit(p00 + d.W + 1, v11);
             }
         }
     }
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(256) void upsample_bwd_stats_kernel(const float* __
     __shared__ __attribute__((aligned(16))) float sh[256 * 8];
     const RowLayout L = row_layout(C);
     f32x4 s1 = f32x4{0.f, 0.f, 0.f, 0.f}, s2 = s1;
-    const int Hl = H >> 1, Wl = W >> 1;
+    const int Hl = (H + 1) >> 1, Wl = (W + 1) >> 1;      // (odd sizes: the last up-sampled row / column was cropped away)
     if (L.active) {
         const int ch = L.cg * 4;
         const f32x4 mean = ld4(state + ch), rstd = ld4(state + Cs + ch), a = ld4(state + 2 * Cs + ch),
@@ -177,8 +181,13 @@ __global__ __launch_bounds__(256) void upsample_bwd_stats_kernel(const float* __
 #pragma unroll
                 for (int dr = 0; dr < 2; ++dr)
 #pragma unroll
-                    for (int dc = 0; dc < 2; ++dc)
-                        du += ld4(dcat + ((size_t)(2 * i + dr) * W + (2 * j + dc)) * Cs_cat + choff + ch);
+                    for (int dc = 0; dc < 2; ++dc) {
+                        const int hr = 2 * i + dr, hc = 2 * j + dc;
+                        const f32x4 gq = ld4(dcat + ((size_t)min(hr, H - 1) * W + min(hc, W - 1)) * Cs_cat + choff + ch);
+                        const float wq = (hr < H && hc < W) ? 1.f : 0.f;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) du[e] = fmaf(wq, gq[e], du[e]);
+                    }
             } else {
                 float wr[4], wc[4];
 #pragma unroll
@@ -378,12 +387,11 @@ extern "C" int dip_upcat_nblk(int H, int W, int C) {
 extern "C" int dip_upcat_fwd(const DipUpcatDesc* d, void* stream) {
     const int C = d->ns + d->nd;
     if ((d->ns & 3) || (d->nd & 3)) DIP_FAIL("upcat_fwd: channel counts must be multiples of 4");
-    if ((d->H & 1) || (d->W & 1)) DIP_FAIL("upcat_fwd: output size must be even");
     if (C > 1024) DIP_FAIL("upcat_fwd: C > 1024 unsupported");
     int nb;
     pixels_per_block(d->H * d->W, C, &nb);
     if (nb != d->nblk) DIP_FAIL("upcat_fwd: nblk mismatch (use dip_upcat_nblk)");
-    const int qpb = dip_cdiv((d->H / 2) * (d->W / 2), nb);       // 2x2 output blocks per workgroup
+    const int qpb = dip_cdiv(((d->H + 1) / 2) * ((d->W + 1) / 2), nb);       // 2x2 output blocks per workgroup
     hipLaunchKernelGGL(upcat_fwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *d, qpb);
     DIP_CHECK_LAUNCH();
     return 0;
@@ -441,8 +449,8 @@ extern "C" int dip_upsample_bwd_stats(const float* dcat, int Cs_cat, int choff, 
                                       float* dz, int Cdz, float* partials, int nblk, void* stream) {
     if (C > 1024) DIP_FAIL("upsample_bwd_stats: C > 1024 unsupported");
     int nb;
-    const int ppb = pixels_per_block((H / 2) * (W / 2), C, &nb);
-    if (nb != nblk) DIP_FAIL("upsample_bwd_stats: nblk mismatch (use dip_bn_bwd_nblk(H/2, W/2, C))");
+    const int ppb = pixels_per_block(((H + 1) / 2) * ((W + 1) / 2), C, &nb);
+    if (nb != nblk) DIP_FAIL("upsample_bwd_stats: nblk mismatch (use dip_bn_bwd_nblk((H+1)/2, (W+1)/2, C))");
     hipLaunchKernelGGL(upsample_bwd_stats_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dcat, Cs_cat, choff, H,
                        W, mode, y, Cy, C, state, Cs, slope, dz, Cdz, partials, ppb);
     DIP_CHECK_LAUNCH();

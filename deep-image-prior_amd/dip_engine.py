@@ -242,10 +242,21 @@ class SkipEngine:
 
     def _build_plan(self, H, W, Cin_img):
         div = 2 ** self.nscales
-        if H % div or W % div:
+        if (H % div or W % div) and any(sc.pool is not None for sc in self.sc):
+            # pooling floors the size, so the x2 up-sampled tensor is SMALLER than the skip branch, the concat (and
+            # the net's output) shrinks and crop offsets appear: not built (the reference's own loss then fails on
+            # the shape mismatch with the target image)
             raise NotImplementedError(
-                f"dip-amd: input {H}x{W} must be divisible by 2^{self.nscales} (ragged Concat crop, "
-                "models/common.py:29-37 of the reference, is not implemented)")
+                f"dip-amd: input {H}x{W} must be divisible by 2^{self.nscales} with avg / max down-sampling "
+                "(size-changing Concat crop, models/common.py:29-37)")
+        if (H % div or W % div) and any(sc.ns == 0 for sc in self.sc):
+            # a scale without skip branch has no Concat: its x2 up-sampled tensor keeps the larger size and the crop
+            # further up gets a non-zero offset
+            raise NotImplementedError(
+                f"dip-amd: input {H}x{W} must be divisible by 2^{self.nscales} when a scale has no skip branch "
+                "(Concat crop with offsets, models/common.py:29-37)")
+        if min(H, W) < 2 ** self.nscales:
+            raise NotImplementedError(f"dip-amd: input {H}x{W} is too small for {self.nscales} scales")
         self.H, self.W, self.Cimg = H, W, Cin_img
         self._reset_sizing()
         self._alloc = []
@@ -285,7 +296,9 @@ class SkipEngine:
     def _plan_scale(self, i, xin: Act, H, W):
         s = self.sc[i]
         st = {}
-        Hl, Wl = H // 2, W // 2
+        # strided convs: ceil(S / 2); for an odd S the x2 up-sampled tensor is one larger than the skip branch and
+        # Concat's centre crop (offset 0) drops its last row / column -- dip_upcat_fwd never produces it
+        Hl, Wl = ((H + 1) // 2, (W + 1) // 2) if s.pool is None else (H // 2, W // 2)
         if s.ns:
             st["s_y"] = self._buf(H * W * round_up(s.ns, 4))
             self._emit_conv_fwd(s.skip_conv, xin, st["s_y"], s.skip_bn)
@@ -519,7 +532,7 @@ class SkipEngine:
 
     def _emit_up_bwd(self, deep: Act, dcat, Cs_cat, choff, H, W, mode, ops):
         bn = deep.bn
-        nblk = self.lib.dip_bn_bwd_nblk(H // 2, W // 2, deep.C)
+        nblk = self.lib.dip_bn_bwd_nblk(deep.H, deep.W, deep.C)
         if self._sizing:
             self.bwdp_need = max(self.bwdp_need, nblk * 2 * deep.Cs)
             return None

@@ -72,6 +72,16 @@ NETS = {
                        kw=dict(num_channels_down=[16, 32], num_channels_up=[16, 32], num_channels_skip=[4, 4],
                                filter_skip_size=3, upsample_mode="bilinear",
                                need_sigmoid=True, need_bias=True, pad="reflection")),
+    # sizes that are not divisible by 2^depth: Concat's centre crop (models/common.py:29-37) drops the last row /
+    # column of the x2 up-sampled tensor (SURVEY 8f n3 "ragged crop")
+    "tiny_ragged": dict(args=(8, 3), hw=(37, 50), seed=12,
+                        kw=dict(num_channels_down=[16, 32, 32], num_channels_up=[16, 32, 32],
+                                num_channels_skip=[4, 4, 4], upsample_mode="bilinear",
+                                need_sigmoid=True, need_bias=True, pad="reflection")),
+    "tiny_ragged_nn": dict(args=(8, 3), hw=(45, 39), seed=13,
+                           kw=dict(num_channels_down=[16, 16], num_channels_up=[16, 16],
+                                   num_channels_skip=[4, 4], upsample_mode="nearest",
+                                   need_sigmoid=True, need_bias=True, pad="zero")),
     # feature_inversion.ipynb:169-174: per-scale filter sizes 7 / 5 / 3, zero padding, avg-pool
     # down-sampling, nearest up-sampling, meshgrid input
     "tiny_feat7": dict(args=(2, 3), hw=(32, 48), seed=7,

@@ -66,8 +66,13 @@ def test_planner_launch_lists(built):
     assert N.conv_plan(512, 512, 132, 128, 3, 1) == (1, 2048, 0)
     k, rows, wsf = N.conv_plan(16, 16, 128, 128, 3, 1)
     assert k == 18 and wsf == k * 16 * 16 * 128
-    with pytest.raises(NotImplementedError):
-        eng._build_plan(500, 512, 32)          # ragged Concat crop is not implemented
+    # sizes that are not divisible by 2^depth: strided convs give ceil(S/2) and Concat's centre crop drops the last
+    # row / column of the up-sampled tensor (models/common.py:29-37)
+    eng._reset_sizing()
+    eng.fwd_ops, eng.bwd_ops, eng.bwd_input_ops, eng.keep = [], [], [], []
+    last = eng._plan_scale(0, Act(None, 500, 421, 32), 500, 421)
+    assert (last.H, last.W) == (500, 421)
+    assert [(sc.st["d2"].H, sc.st["d2"].W) for sc in eng.sc] == [(250, 211), (125, 106), (63, 53), (32, 27), (16, 14)]
 
 
 def test_planner_builds_launch_lists_for_every_option(built):
@@ -95,6 +100,17 @@ def test_planner_builds_launch_lists_for_every_option(built):
     eng._build_arenas(torch.device("cpu"))
     eng._build_plan(32, 32, 8)
     assert eng.slope == 1.0
+    pooled = skip(8, 3, [16, 16], [16, 16], [4, 4], downsample_mode="avg", pad="reflection")
+    e3 = pooled.__dict__["_dip_engine"]
+    e3._build_arenas(torch.device("cpu"))
+    with pytest.raises(NotImplementedError, match="divisible"):
+        e3._build_plan(30, 32, 8)              # pooling floors: the concat would shrink (size-changing crop)
+    noskip = skip(8, 3, [16, 16], [16, 16], [4, 0], pad="reflection")
+    e4 = noskip.__dict__["_dip_engine"]
+    e4._build_arenas(torch.device("cpu"))
+    e4._build_plan(32, 48, 8)
+    with pytest.raises(NotImplementedError, match="no skip branch"):
+        e4._build_plan(30, 47, 8)              # the crop further up would need an offset
     big = skip(8, 3, [16, 16], [16, 16], [4, 4], filter_skip_size=5, filter_size_down=3, pad="reflection")
     e2 = big.__dict__["_dip_engine"]
     e2._build_arenas(torch.device("cpu"))

@@ -51,6 +51,13 @@ NETS = {
     "tiny_skip3": dict(args=(8, 3), kw=dict(num_channels_down=[16, 32], num_channels_up=[16, 32],
                                             num_channels_skip=[4, 4], filter_skip_size=3, upsample_mode="bilinear",
                                             need_sigmoid=True, need_bias=True, pad="reflection")),
+    # sizes not divisible by 2^depth (goldens at 37x50 and 45x39): Concat's centre crop
+    "tiny_ragged": dict(args=(8, 3), kw=dict(num_channels_down=[16, 32, 32], num_channels_up=[16, 32, 32],
+                                             num_channels_skip=[4, 4, 4], upsample_mode="bilinear",
+                                             need_sigmoid=True, need_bias=True, pad="reflection")),
+    "tiny_ragged_nn": dict(args=(8, 3), kw=dict(num_channels_down=[16, 16], num_channels_up=[16, 16],
+                                                num_channels_skip=[4, 4], upsample_mode="nearest",
+                                                need_sigmoid=True, need_bias=True, pad="zero")),
     "tiny_feat7": dict(args=(2, 3), kw=dict(num_channels_down=[8, 16, 16], num_channels_up=[8, 16, 16],
                                             num_channels_skip=[4, 4, 4], filter_size_down=[7, 5, 3],
                                             filter_size_up=[7, 5, 3], upsample_mode="nearest", downsample_mode="avg",
@@ -171,7 +178,9 @@ def test_default_net_64_against_oracle_and_digest(dev):
     assert worst <= 1.0, (worst, wk)
 
 
-@pytest.mark.parametrize("hw,mode,nskip", [((96, 64), "bilinear", 4), ((64, 64), "nearest", 128)])
+@pytest.mark.parametrize("hw,mode,nskip", [((96, 64), "bilinear", 4), ((64, 64), "nearest", 128),
+                                           # not divisible by 2^5: ceil sizes 81x103 -> 41x52 -> 21x26 -> 11x13 -> 6x7 -> 3x4
+                                           ((81, 103), "bilinear", 4), ((70, 57), "nearest", 4)])
 def test_against_oracle_fresh_seed(dev, hw, mode, nskip):
     from models.skip import skip
     torch.manual_seed(123)
