@@ -11,6 +11,7 @@
 //    the Philox offset live in device memory, so one optimisation iteration is a STATIC launch list
 //    and can be replayed as a hipGraph (nothing changes on the host between iterations).
 #include "dip_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -91,6 +92,86 @@ __global__ __launch_bounds__(256) void loss_head_fwd_kernel(const DipLossHeadDes
     if (tid == 0) d.partials[blockIdx.x] = red[0];
 }
 
+// Coalesced variant for Cin/4 = NC4 a power of two <= 32 (every net of the notebooks: 128, 16 or 8 channels in front
+// of the output conv): NC4 consecutive lanes share a pixel, each owns 4 channels -- a wave reads 64/NC4 whole pixels
+// = one contiguous run per load instruction (the lane-per-pixel kernel above strides 4*Cu bytes between lanes and
+// ran at 1.8 TB/s) -- computes its 4 x Cout partial products, and an xor-butterfly over the NC4 lanes (fixed order)
+// leaves the sums in every lane; lane o of the group finishes output channel o.
+template <int NC4>
+__global__ __launch_bounds__(256) void loss_head_fwd_coal_kernel(const DipLossHeadDesc d, const int ppb) {
+    __shared__ float red[256];
+    constexpr int PW = 64 / NC4;                 // pixels per wave and step
+    constexpr int PB = 4 * PW;                   // ... per block and step
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cg = lane % NC4, psub = lane / NC4;
+    const bool has_tr = d.tr.a != nullptr;
+    const float slope = has_tr ? d.tr.slope : 1.f;
+    const bool leaky = slope > 0.f;
+    f32x4 ta = f32x4{1.f, 1.f, 1.f, 1.f}, tb = f32x4{0.f, 0.f, 0.f, 0.f};
+    float w[4][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = cg * 4 + e;
+        if (has_tr && c < d.Cin) { ta[e] = d.tr.a[c]; tb[e] = d.tr.b[c]; }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) w[o][e] = (o < d.Cout && c < d.Cin) ? d.w[(size_t)o * d.Cin + c] : 0.f;
+    }
+    const float mybias = (d.bias != nullptr && cg < d.Cout) ? d.bias[cg] : 0.f;
+    const int p0 = blockIdx.x * ppb, p1 = min(p0 + ppb, d.HW);
+    float lsum = 0.f;
+    constexpr int UN = 4;                        // independent loads in flight per thread
+    for (int base = p0 + wave * PW; base < p1; base += UN * PB) {      // (wave-uniform trip count: the shuffles below)
+        const int pb = base + psub;
+        f32x4 u[UN];
+#pragma unroll
+        for (int q = 0; q < UN; ++q) {
+            const int p = pb + q * PB;
+            u[q] = *reinterpret_cast<const f32x4*>(d.u + (size_t)(p < p1 ? p : p0) * d.Cu + cg * 4);
+        }
+#pragma unroll
+        for (int q = 0; q < UN; ++q) {
+            const int p = pb + q * PB;
+            f32x4 v = u[q];
+            if (leaky) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = dip_act_leaky(fmaf(ta[e], v[e], tb[e]), slope);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = dip_act(fmaf(ta[e], v[e], tb[e]), slope);
+            }
+            float part[4];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) part[o] = (w[o][0] * v[0] + w[o][1] * v[1]) + (w[o][2] * v[2] + w[o][3] * v[3]);
+#pragma unroll
+            for (int sft = NC4 / 2; sft >= 1; sft >>= 1)
+#pragma unroll
+                for (int o = 0; o < 4; ++o) part[o] += __shfl_xor(part[o], sft);
+            const float mine = cg == 0 ? part[0] : (cg == 1 ? part[1] : (cg == 2 ? part[2] : part[3]));
+            if (p < p1 && cg < d.Cout) {
+                float y = mine + mybias;
+                if (d.sigmoid) y = sigmoidf_(y);
+                d.out[(size_t)cg * d.HW + p] = y;
+                const float t = d.target[(size_t)cg * d.HW + p];
+                float a = y, b = t;
+                if (d.mask != nullptr) {
+                    const float m = d.mask[(size_t)(d.mask_c == 1 ? 0 : cg) * d.HW + p];
+                    a = y * m;                                     // mse(out * mask, img * mask)
+                    b = t * m;
+                }
+                const float df = a - b;
+                lsum = fmaf(df, df, lsum);
+            }
+        }
+    }
+    red[tid] = lsum;
+    __syncthreads();
+    for (int s2 = 128; s2 >= 1; s2 >>= 1) {
+        if (tid < s2) red[tid] += red[tid + s2];
+        __syncthreads();
+    }
+    if (tid == 0) d.partials[blockIdx.x] = red[0];
+}
+
 // Fixed-order fp64 sum of the per-block partials -> the scalar loss.  A launch of its own on purpose: a
 // "last-arriving block" ticket needs an agent-scope release fence in EVERY block, which on the multi-XCD
 // MI355X writes back / invalidates L2 each time (the ticketed version of this head took 110 us instead
@@ -159,6 +240,8 @@ __global__ void counter_add_kernel(unsigned long long* c, unsigned long long inc
 
 }  // namespace
 
+// the coalesced head needs a lane per output channel inside a pixel's lane group
+#define NC4_MIN_CHECK(cout, nc4) ((nc4) < 4 || (cout) > (nc4))
 static int head_ppb(int HW) {
     int ppb = dip_round_up(dip_cdiv(HW, 1024), 256);      // ~1024 blocks, whole 256-pixel strips
     return ppb < 256 ? 256 : ppb;
@@ -177,7 +260,19 @@ extern "C" int dip_loss_head_fwd(const DipLossHeadDesc* dp, void* stream) {
     const int ppb = head_ppb(d.HW);
     const int nblk = dip_cdiv(d.HW, ppb);
     if (nblk != d.nblk) DIP_FAIL("loss_head: nblk must come from dip_loss_head_nblk");
-    hipLaunchKernelGGL(loss_head_fwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, d, ppb);
+    const int nc4 = (d.Cin + 3) / 4;
+    static const bool no_coal = getenv("DIP_LOSS_HEAD_NO_COAL") != nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    if (no_coal || nc4 > 32 || (nc4 & (nc4 - 1)) != 0 || (NC4_MIN_CHECK(d.Cout, nc4))) {
+        hipLaunchKernelGGL(loss_head_fwd_kernel, dim3(nblk), dim3(256), 0, st, d, ppb);
+    } else {
+        switch (nc4) {
+            case 32: hipLaunchKernelGGL(loss_head_fwd_coal_kernel<32>, dim3(nblk), dim3(256), 0, st, d, ppb); break;
+            case 16: hipLaunchKernelGGL(loss_head_fwd_coal_kernel<16>, dim3(nblk), dim3(256), 0, st, d, ppb); break;
+            case 8: hipLaunchKernelGGL(loss_head_fwd_coal_kernel<8>, dim3(nblk), dim3(256), 0, st, d, ppb); break;
+            default: hipLaunchKernelGGL(loss_head_fwd_coal_kernel<4>, dim3(nblk), dim3(256), 0, st, d, ppb); break;
+        }
+    }
     DIP_CHECK_LAUNCH();
     hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, d.partials, nblk,
                        1.0 / ((double)d.Cout * (double)d.HW), d.loss);
