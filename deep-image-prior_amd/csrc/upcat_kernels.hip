@@ -189,24 +189,13 @@ __global__ __launch_bounds__(256) void upsample_bwd_stats_kernel(const float* __
                         for (int e = 0; e < 4; ++e) du[e] = fmaf(wq, gq[e], du[e]);
                     }
             } else {
-                float wr[4], wc[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    int i0, i1;
-                    float l0, l1;
-                    const int hr = 2 * i - 1 + t;
-                    wr[t] = 0.f;
-                    if (hr >= 0 && hr < H) {
-                        bil_src(hr, Hl, i0, i1, l0, l1);
-                        wr[t] = (i0 == i ? l0 : 0.f) + (i1 == i ? l1 : 0.f);
-                    }
-                    const int hc = 2 * j - 1 + t;
-                    wc[t] = 0.f;
-                    if (hc >= 0 && hc < W) {
-                        bil_src(hc, Wl, i0, i1, l0, l1);
-                        wc[t] = (i0 == j ? l0 : 0.f) + (i1 == j ? l1 : 0.f);
-                    }
-                }
+                // adjoint weights of the scale-2 bilinear up-sampling (align_corners = False) in closed form: high-res
+                // rows 2i-1 .. 2i+2 touch low-res row i with (0.25, 0.75, 0.75, 0.25); row 0 gives all of itself to
+                // i = 0, the last low-res row also collects the clamped upper neighbour, rows outside [0, H) nothing
+                const float wr[4] = {i >= 1 ? 0.25f : 0.f, i == 0 ? 1.f : 0.75f,
+                                     2 * i + 1 < H ? (i == Hl - 1 ? 1.f : 0.75f) : 0.f, 2 * i + 2 < H ? 0.25f : 0.f};
+                const float wc[4] = {j >= 1 ? 0.25f : 0.f, j == 0 ? 1.f : 0.75f,
+                                     2 * j + 1 < W ? (j == Wl - 1 ? 1.f : 0.75f) : 0.f, 2 * j + 2 < W ? 0.25f : 0.f};
                 // all 16 loads of the 4x4 window are issued unconditionally (clamped address, zero
                 // weight outside the image): branching on the weights serialised them
                 f32x4 gw[16];

@@ -11,6 +11,8 @@ LOG=$ROOTD/gpurun_out/round.log
 : > $LOG
 run() { echo "=== $* ===" | tee -a $LOG; local t0=$SECONDS; timeout "${TMO:-600}" "$@" >> $LOG 2>&1; echo "--- rc=$? ($((SECONDS-t0)) s) ---" | tee -a $LOG; }
 nproc >> $LOG; lscpu | grep -E "Model name|^CPU\(s\)" >> $LOG
+# the pool has two speed classes of boxes (~128 and ~140 it/s on the default config): record what this one reports
+(rocm-smi --showperflevel --showclocks --showpower --showmaxpower 2>/dev/null | grep -vE "^=|^$" | head -40) >> $LOG
 run python __graft_entry__.py build
 if [ "${SKIP_TESTS:-0}" != "1" ]; then
 if [ -n "${TESTS:-}" ]; then
