@@ -1,4 +1,6 @@
-// Implicit-GEMM convolution, fully asynchronous staging variant (stride 1, 1x1 and 3x3).
+// Implicit-GEMM convolution, fully asynchronous staging variant: 1x1 and 3x3 at stride 1 (MODE 0), the data
+// gradient of a stride-2 3x3 as four dense sub-filter convolutions (MODE 1) and the stride-2 3x3 forward with the
+// input split by pixel parity (MODE 2) -- see the comment in front of the kernel.
 //
 // Same tile / wave / MFMA layout as conv_igemm.hip (8x16 pixels x BN channels per 4-wave
 // workgroup, two workgroups per CU), but NOTHING is staged through registers any more:
@@ -13,8 +15,9 @@
 // LDS: 2 x 23.0 KB halo + 2 x 16 KB weights + tables = 79.95 KB -> still two workgroups per CU.
 // 3x3: the producer transform is applied IN PLACE in LDS, once per chunk, by the thread that DMA'd
 // the slot (after its own vmcnt(0)); 1x1: at the fragment read.
-// Restrictions (checked by the dispatcher): stride 1, ks in {1,3}, Cin <= 288 when a transform is
-// fused; everything else takes the register-staged kernel in conv_igemm.hip.
+// Restrictions (checked by the dispatcher, dip_conv_dma_eligible / dip_conv_phase_eligible): ks in {1,3} (stride 2:
+// 3x3 only), Cin <= 288 and a LeakyReLU-type activation when a transform is fused; everything else takes the
+// register-staged kernel in conv_igemm.hip.
 #include "dip_common.h"
 #include "conv_epilogue.h"
 #include <stdlib.h>
