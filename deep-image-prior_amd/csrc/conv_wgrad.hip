@@ -566,9 +566,9 @@ static double wgrad_cost(int nt, int n, int chunks, int groups, int oblk, int ta
 // Plan of the 64-channel kernel (conv_wgrad64.hip; chan_block = 2): returns 1 and the pixel split when the layer is
 // in its domain and large enough (>= 512 pixel tiles), else 0.  ONE workgroup per CU with all 512 registers of a
 // lane: faster than conv_wgrad_kernel on its own (128 -> 128 @512^2: 727 -> 644 us) but it cannot share a CU with a
-// convolution workgroup of the other stream, and the two-stream iteration as a whole came out 1.1 % SLOWER with it
-// (126.4 -> 125.0 it/s; on half / three quarters of the CUs 115 / 123).  dip_engine therefore uses it in
-// single-stream mode only.
+// convolution workgroup of the other stream: the two-stream iteration as a whole came out 0.5-1.1 % SLOWER with it on
+// the slow class of boxes of the pool (126.4 -> 125.0 it/s) and 1.2 % faster on the fast class (142.1 -> 143.9).
+// dip_engine uses it only when asked to (DIP_WGRAD_64=1).
 extern "C" int dip_wgrad_plan64(int Hout, int Wout, int Cin, int Cout, int ks, int stride, int* nsplit) {
     const int nt = dip_conv_wgrad_ntiles(Hout, Wout);
     if (!dip_wgrad64_eligible(Cin, ks, stride) || nt < 512) return 0;
