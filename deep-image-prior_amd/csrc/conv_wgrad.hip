@@ -454,6 +454,134 @@ __global__ __launch_bounds__(256) void thin1x1_wgrad_kernel(const DipWgradDesc d
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Weight gradient of a conv with <= 4 INPUT channels (the first conv of a net whose input is an image / a
+// 1..4-plane noise tensor: inpainting 'library' has 1, the snail net 3, the meshgrid input 2): M = taps x 4
+// channels is far too thin for the MFMA kernel, which stages a 32-channel halo per tile (5x5 stride 2, 1 -> 16
+// channels at 448x704: 327 us for 0.06 GFLOP).  Vector-ALU streaming kernel instead: thread (prow, og) owns 4
+// output channels and the KS taps of ONE filter row (blockIdx.y) x 4 channels = KS*16 accumulators, walks its
+// pixels (dy once, KS neighbouring x pixels of 16 bytes each), then the block tree-reduces over prow, one filter
+// column at a time, into one slab per block -- same slab layout as the MFMA kernel, dip_wgrad_reduce finishes it.
+// ------------------------------------------------------------------------------------------
+template <int KS>
+__global__ __launch_bounds__(256) void thin_cin_wgrad_kernel(const DipWgradDesc d, const int CinP, const int CoutP,
+                                                             const int ppb) {
+    __shared__ __attribute__((aligned(16))) float sh[256 * 16];
+    const int nog = (d.Cout + 3) >> 2;                   // groups of 4 output channels (<= 64)
+    const int rpi = 256 / nog;
+    const int prow = threadIdx.x / nog, og = threadIdx.x - prow * nog;
+    const bool active = (int)threadIdx.x < rpi * nog;
+    const int ky = blockIdx.y;
+    float acc[KS][16];                                   // [kx][c * 4 + o]
+#pragma unroll
+    for (int k = 0; k < KS; ++k)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[k][i] = 0.f;
+    f32x4 bsum = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (active) {
+        const bool has_tr = d.tr.a != nullptr;
+        const float slope = has_tr ? d.tr.slope : 1.f;
+        f32x4 ta = f32x4{1.f, 1.f, 1.f, 1.f}, tb = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (has_tr) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (e < d.Cin) { ta[e] = d.tr.a[e]; tb[e] = d.tr.b[e]; }
+        }
+        const int npix = d.Hout * d.Wout;
+        const int p0 = blockIdx.x * ppb, p1 = min(p0 + ppb, npix);
+        const bool reflect = d.pad_mode == DIP_PAD_REFLECT;
+        for (int p = p0 + prow; p < p1; p += rpi) {
+            const int oy = p / d.Wout, ox = p - oy * d.Wout;
+            const f32x4 g = *reinterpret_cast<const f32x4*>(d.dy + (size_t)p * d.Cdy + og * 4);
+            int sy = oy * d.stride + ky - d.off;
+            if (reflect) sy = dip_reflect(sy, d.Hin);
+            const bool yok = (unsigned)sy < (unsigned)d.Hin;
+            f32x4 xs[KS];
+            float ok[KS];
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) {            // all loads first (clamped address, validity as a weight)
+                int sx = ox * d.stride + kx - d.off;
+                if (reflect) sx = dip_reflect(sx, d.Win);
+                const bool v = yok & ((unsigned)sx < (unsigned)d.Win);
+                ok[kx] = v ? 1.f : 0.f;
+                xs[kx] = *reinterpret_cast<const f32x4*>(d.x + (v ? ((size_t)sy * d.Win + sx) * d.Cx : 0));
+            }
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) {
+                f32x4 u = xs[kx];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    // zero padding contributes 0 (not act(b)); channels >= Cin are zero pad channels of x
+                    const float t = has_tr ? dip_act(fmaf(ta[c], u[c], tb[c]), slope) : u[c];
+                    const float uc = (c < d.Cin) ? t * ok[kx] : 0.f;
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) acc[kx][c * 4 + o] = fmaf(uc, g[o], acc[kx][c * 4 + o]);
+                }
+            }
+            bsum += g;
+        }
+    }
+    // block reduction over prow, one filter column (16 values per thread) at a time
+    const int tap0 = ky * KS;
+    for (int kx = 0; kx <= KS; ++kx) {                   // kx == KS: the bias sums (filter row 0 only)
+        if (kx == KS && (ky != 0 || d.bias_partial == nullptr)) break;
+        float* mine = sh + (size_t)threadIdx.x * 16;
+        __syncthreads();                                 // the previous column's reads are done
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            float v = 0.f;
+            if (kx < KS) {
+#pragma unroll
+                for (int k = 0; k < KS; ++k) v = (k == kx) ? acc[k][i] : v;
+            } else {
+                v = i < 4 ? bsum[i] : 0.f;
+            }
+            mine[i] = v;
+        }
+        for (int st = dip_pow2_ceil(rpi) >> 1; st >= 1; st >>= 1) {
+            __syncthreads();
+            if (active && prow < st && prow + st < rpi) {
+                const float* q = sh + (size_t)((prow + st) * nog + og) * 16;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) mine[i] += q[i];
+            }
+        }
+        if (active && prow == 0) {
+            if (kx < KS) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) {
+                        const int oo = og * 4 + o;
+                        if (c < d.Cin && oo < CoutP)
+                            d.partial[(((size_t)blockIdx.x * (KS * KS) + tap0 + kx) * CinP + c) * CoutP + oo] = mine[c * 4 + o];
+                    }
+            } else {
+#pragma unroll
+                for (int o = 0; o < 4; ++o)
+                    if (og * 4 + o < CoutP) d.bias_partial[(size_t)blockIdx.x * CoutP + og * 4 + o] = mine[o];
+            }
+        }
+    }
+}
+
+// pixels per block of the thin-input kernel: <= 512 slabs and <= 64 MB of slabs
+int thin_cin_ppb(int npix, int Cout, int ks, int* nblk) {
+    const int nog = (Cout + 3) / 4;
+    const int rpi = 256 / nog;
+    int ppb = dip_cdiv(npix, 512);
+    if (ppb < rpi * 4) ppb = rpi * 4;
+    const long long slab = (long long)ks * ks * 32 * dip_round_up(Cout, 32);
+    while ((long long)dip_cdiv(npix, ppb) * slab > (16ll << 20)) ppb *= 2;
+    *nblk = dip_cdiv(npix, ppb);
+    return ppb;
+}
+
+bool is_thin_cin(int ks, int Cin, int Cout) {
+    static const bool off = getenv("DIP_WGRAD_NO_THIN_CIN") != nullptr;
+    return !off && Cin <= 4 && Cout <= 256 && (ks == 3 || ks == 5 || ks == 7);
+}
+
 int thin_ppb(int npix, int Cin, int* nblk) {
     const int nc4 = (Cin + 3) / 4;
     int rpi = 256 / nc4;
@@ -530,6 +658,12 @@ extern "C" int dip_wgrad_plan(int Hout, int Wout, int Cin, int Cout, int ks, int
         *nsplit = nblk;
         return 0;
     }
+    if (is_thin_cin(ks, Cin, Cout)) {
+        int nblk;
+        thin_cin_ppb(Hout * Wout, Cout, ks, &nblk);
+        *nsplit = nblk;
+        return 0;
+    }
     const int CinP = dip_round_up(Cin, 32), CoutP = dip_round_up(Cout, 32);
     const int nt = dip_conv_wgrad_ntiles(Hout, Wout);
     const int cw = (ks == 1) ? 128 : 32;
@@ -586,7 +720,7 @@ extern "C" int dip_wgrad_plan2(int Hout, int Wout, int Cin, int Cout, int ks, in
     *chan_block = (ks == 1) ? 4 : 1;
     int rc = dip_wgrad_plan(Hout, Wout, Cin, Cout, ks, stride, nsplit);
     if (rc) return rc;
-    if (is_thin(ks, Cin, Cout) || (ks != 3 && ks != 1)) return 0;
+    if (is_thin(ks, Cin, Cout) || is_thin_cin(ks, Cin, Cout) || (ks != 3 && ks != 1)) return 0;
     const int nt = dip_conv_wgrad_ntiles(Hout, Wout);
     static const bool off = getenv("DIP_WGRAD_NO_SMALL_PLAN") != nullptr;
     if (nt > 256 || off) return 0;
@@ -636,6 +770,19 @@ extern "C" int dip_conv_wgrad(const DipWgradDesc* dp, void* stream) {
         } else {
             hipLaunchKernelGGL(thin1x1_wgrad_kernel<8>, dim3(nblk), dim3(256), 256 * 40 * 4, st, d, CinP, CoutP, ppb);
         }
+        DIP_CHECK_LAUNCH();
+        return 0;
+    }
+    if (is_thin_cin(d.ks, d.Cin, d.Cout)) {
+        int nblk;
+        const int ppb = thin_cin_ppb(d.Hout * d.Wout, d.Cout, d.ks, &nblk);
+        if (nblk != d.nsplit) DIP_FAIL("conv_wgrad: the <= 4 input channel path needs nsplit from dip_wgrad_plan");
+        if (d.Cx < 4) DIP_FAIL("conv_wgrad: channel stride of x must be >= 4");
+        const int CinP = dip_round_up(d.Cin, 32), CoutP = dip_round_up(d.Cout, 32);
+        const dim3 grid(nblk, d.ks);
+        if (d.ks == 3) hipLaunchKernelGGL(thin_cin_wgrad_kernel<3>, grid, dim3(256), 0, st, d, CinP, CoutP, ppb);
+        else if (d.ks == 5) hipLaunchKernelGGL(thin_cin_wgrad_kernel<5>, grid, dim3(256), 0, st, d, CinP, CoutP, ppb);
+        else hipLaunchKernelGGL(thin_cin_wgrad_kernel<7>, grid, dim3(256), 0, st, d, CinP, CoutP, ppb);
         DIP_CHECK_LAUNCH();
         return 0;
     }

@@ -163,7 +163,8 @@ int dip_conv_wgrad(const DipWgradDesc* d, void* stream);
 /* number of 4x16 output tiles walked by the wgrad workgroups (upper bound for nsplit) */
 int dip_conv_wgrad_ntiles(int Hout, int Wout);
 /* nsplit (number of partial slabs) to run dip_conv_wgrad with; mandatory for 1x1 convs with
- * Cout <= 8, which take a thin vector-ALU streaming kernel with one slab per block */
+ * Cout <= 8 and for 3x3 / 5x5 / 7x7 convs with <= 4 INPUT channels (the first conv of a net), which take thin
+ * vector-ALU streaming kernels with one slab per block */
 int dip_wgrad_plan(int Hout, int Wout, int Cin, int Cout, int ks, int stride, int* nsplit);
 /* the full launch plan: nsplit plus the tap_groups / chan_block fields of DipWgradDesc.  Large layers
  * get (nsplit as dip_wgrad_plan, 1, 4); layers with <= 256 pixel tiles (<= 128x128 outputs) trade

@@ -132,7 +132,7 @@ def conv_wgrad(x, dy, ks, stride, pad_mode, tr=(None, None, 1.0), nsplit=None, b
     CinP, CoutP = round_up(Cin, 32), round_up(Cout, 32)
     nt = lib.dip_conv_wgrad_ntiles(Ho, Wo)
     planned, pg, pcb = N.wgrad_plan2(Ho, Wo, Cin, Cout, ks, stride)
-    thin = ks == 1 and Cout <= 8
+    thin = (ks == 1 and Cout <= 8) or (Cin <= 4 and ks in (3, 5, 7))      # streaming kernels: one slab per block
     if thin or nsplit == "plan":
         nsplit, tap_groups, chan_block = planned, pg, pcb
     else:

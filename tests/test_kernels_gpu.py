@@ -61,6 +61,10 @@ CONV_CASES = [
     (2, 16, 7, 1, ZERO, 24, 32, False),          # feature_inversion.ipynb: 7x7 filters, zero pad, meshgrid input
     (20, 16, 7, 1, ZERO, 16, 16, True),          # 7x7 decoder conv on [4 skip | 16] channels
     (16, 32, 7, 2, REFLECT, 32, 32, True),       # 7x7 stride 2
+    # <= 4 input channels: the thin weight-gradient kernel of a net's first conv (thin_cin_wgrad_kernel)
+    (4, 32, 3, 1, REFLECT, 19, 27, True),
+    (1, 128, 5, 2, ZERO, 40, 36, False),         # inpainting 'library': 1 input plane, 5x5 stride 2
+    (3, 200, 3, 1, ZERO, 16, 16, True),          # 50 output groups: 5 pixel rows per block step (not a power of two)
 ]
 
 
