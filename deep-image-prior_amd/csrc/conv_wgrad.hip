@@ -40,7 +40,8 @@ __device__ __forceinline__ int wmap_src(int v, int n_in, int reflect) {
 
 template <int KS, int S, int NT, int CB>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d, const int ntx, const int ntiles,
-                                                            const int CinP, const int CoutP, const int ragged_parts) {
+                                                            const int CinP, const int CoutP, const int ragged_parts,
+                                                            const int kw) {
     using C = WCfg<KS, S, NT, CB>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Us = smem;
@@ -52,7 +53,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d
     const int l31 = lane & 31;
     const int half = lane >> 5;
 
-    const int split = blockIdx.x;
+    // kw = 1: the four waves own four 32-column blocks.  Narrow layers (<= 64 / <= 32 output columns) would leave
+    // two / three waves idle: there kw = 2 / 4 waves share a column block and split the K steps (pixel pairs) of
+    // every tile between them, each writing a slab of its own (slab index blockIdx.x * kw + wk).
+    const int wcol = wave % (4 / kw), wk = wave / (4 / kw);
+    const int walker = blockIdx.x, nwalk = gridDim.x;      // pixel-tile walkers
+    const int split = walker * kw + wk;                    // slab
     // 32*CB input channels.  Workgroups are dispatched in blockIdx order; the ragged tail chunk of a
     // 132-channel layer is light (2 of 9 MFMAs per K step), so it goes FIRST: its workgroups retire early
     // and the slots go to the full chunks, instead of forming a lonely last round behind them.
@@ -63,7 +69,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d
     const int tap0 = group * NT;
     int c0 = cchunk * C::CW;
     const int o0 = nblk * 128;
-    const bool wave_active = (o0 + wave * 32) < CoutP;
+    const bool wave_active = (o0 + wcol * 32) < CoutP;
     const bool do_bias = (d.bias_partial != nullptr) && cchunk == 0 && group == 0;
 
     f32x16 acc[NT * CB];
@@ -199,10 +205,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d
         if (wave_active) {
             if constexpr (CAN_PACK) {
 #pragma unroll 2
-                for (int s = 0; s < C::NPX / 2; ++s) {
+                for (int s = wk; s < C::NPX / 2; s += kw) {
                     const int px = 2 * s + half;
                     const int r = px >> 4, c = px & 15;
-                    const float b = Ds[px * 128 + wave * 32 + l31];
+                    const float b = Ds[px * 128 + wcol * 32 + l31];
                     bsum += b;
                     const float* ub = Us + ((r * S) * C::HTW + c * S) * C::CW;
                     acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ub[aoff0], b, acc[0], 0, 0, 0);
@@ -216,10 +222,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d
                 }
             } else {
 #pragma unroll 2
-                for (int s = 0; s < C::NPX / 2; ++s) {
+                for (int s = wk; s < C::NPX / 2; s += kw) {
                     const int px = 2 * s + half;
                     const int r = px >> 4, c = px & 15;
-                    const float b = Ds[px * 128 + wave * 32 + l31];
+                    const float b = Ds[px * 128 + wcol * 32 + l31];
                     bsum += b;
                     const float* ub = Us + ((r * S) * C::HTW + c * S) * C::CW + l31;
 #pragma unroll
@@ -239,12 +245,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d
         }
     }
     };
-    walk(split, d.nsplit);
+    walk(walker, nwalk);
 
     // ---- write this workgroup's partial slab ----
     if (pack) {
       if (wave_active) {
-        const int o = o0 + wave * 32 + l31;
+        const int o = o0 + wcol * 32 + l31;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = (r & 3) + 8 * (r >> 2) + 4 * half;       // row = tap * 4 + channel
@@ -266,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d
         }
       }
     } else if (wave_active) {
-        const int o = o0 + wave * 32 + l31;
+        const int o = o0 + wcol * 32 + l31;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int tap = tap0 + t;
@@ -313,9 +319,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
-            walk(split + cchunk * d.nsplit, d.nsplit * ragged_parts);
+            walk(walker + cchunk * nwalk, nwalk * ragged_parts);       // (kw == 1 here)
             if (wave_active) {
-                const int o = o0 + wave * 32 + l31;
+                const int o = o0 + wcol * 32 + l31;
                 const int cbase = CinMain + 4 * cchunk;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -335,6 +341,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d
     }
 }
 
+// waves that share a 32-column block (and split the K steps) in layers with <= 64 / <= 32 output columns
+int wgrad_kw(int CoutP) {
+    static const bool off = getenv("DIP_WGRAD_NO_KW") != nullptr;
+    if (off) return 1;
+    return CoutP <= 32 ? 4 : (CoutP <= 64 ? 2 : 1);
+}
+
 template <int KS, int S, int NT, int CB>
 int launch(const DipWgradDesc& d, hipStream_t st, int CinP_slab = 0) {
     using C = WCfg<KS, S, NT, CB>;
@@ -349,7 +362,7 @@ int launch(const DipWgradDesc& d, hipStream_t st, int CinP_slab = 0) {
     const int ntx = dip_cdiv(d.Wout, C::TW), nty = dip_cdiv(d.Hout, C::TH);
     const int ntiles = ntx * nty;
     const int CinP = dip_round_up(d.Cin, 32), CoutP = dip_round_up(d.Cout, 32);
-    if (d.nsplit < 1 || d.nsplit > ntiles) DIP_FAIL("conv_wgrad: nsplit out of range");
+    if (d.nsplit < 1) DIP_FAIL("conv_wgrad: nsplit out of range");
     // a <= 4-channel tail behind 1..8 full 32-channel chunks is shared out among the full-chunk workgroups
     // (phase 2 of the kernel) instead of getting workgroups of its own
     int ragged_parts = 0;
@@ -358,10 +371,14 @@ int launch(const DipWgradDesc& d, hipStream_t st, int CinP_slab = 0) {
         const int tail = d.Cin & 31, nfull = d.Cin >> 5;
         if (!no_parts && tail >= 1 && tail <= 4 && nfull >= 1 && nfull <= 8) ragged_parts = nfull;
     }
-    dim3 grid(d.nsplit, ragged_parts > 0 ? ragged_parts : dip_cdiv(CinP, C::CW), C::NGROUPS * dip_cdiv(CoutP, 128));
+    // narrow layers: kw waves per 32-column block, each with a slab of its own (d.nsplit counts slabs)
+    int kw = wgrad_kw(CoutP);
+    if (ragged_parts > 0 || (d.nsplit % kw) != 0) kw = 1;
+    if (d.nsplit / kw > ntiles) DIP_FAIL("conv_wgrad: nsplit out of range (more walkers than pixel tiles)");
+    dim3 grid(d.nsplit / kw, ragged_parts > 0 ? ragged_parts : dip_cdiv(CinP, C::CW), C::NGROUPS * dip_cdiv(CoutP, 128));
     // CinP_slab: row count of the slabs when this launch covers only the leading channels of the layer
     hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, st, d, ntx, ntiles, CinP_slab > 0 ? CinP_slab : CinP, CoutP,
-                       ragged_parts);
+                       ragged_parts, kw);
     DIP_CHECK_LAUNCH();
     return 0;
 }
@@ -678,7 +695,7 @@ extern "C" int dip_wgrad_plan(int Hout, int Wout, int Cin, int Cout, int ks, int
     if (n < 1) n = 1;
     const long long slab = (long long)ks * ks * CinP * CoutP;
     while (n > 1 && (long long)n * slab > (64ll << 20)) n /= 2;
-    *nsplit = n;
+    *nsplit = n * wgrad_kw(CoutP);         // narrow layers: kw slabs per workgroup
     return 0;
 }
 
@@ -750,7 +767,7 @@ extern "C" int dip_wgrad_plan2(int Hout, int Wout, int Cin, int Cout, int ks, in
             }
         }
     }
-    *nsplit = bn;
+    *nsplit = bn * ((ks == 3) ? wgrad_kw(CoutP) : 1);
     *tap_groups = bg;
     *chan_block = bcb;
     return 0;
