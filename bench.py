@@ -581,6 +581,14 @@ def main():
     # "other_mode"): at 512x512 the GPU is throughput-bound and the eager two-stream schedule wins, small
     # nets are launch-bound and the graph wins.
     modes = {"graph": [True], "eager": [False], "auto": [False, True]}["eager" if args.no_graph else args.mode]
+    # per-launch HIP-event timing for the roofline objects: BEFORE any hipGraph exists in the process (see
+    # dip_optim._LIVE_GRAPHS: event churn after a graph had been torn down crashed the ROCm 7.2 runtime now and then)
+    per_op = None
+    if rank == 0 and not args.no_roofline:
+        for _ in range(max(3, min(args.warmup, 10))):
+            fits[0].step()
+        torch.cuda.synchronize()
+        per_op = profile_ops(fits[0].engine)
     runs = []
     for use_graph in modes:
         t, graphed, note = timed_run(fits, args.steps, args.warmup, use_graph, barrier)
@@ -595,7 +603,6 @@ def main():
         eng = fits[0].engine
         rl = rw = None
         if not args.no_roofline:
-            per_op = profile_ops(eng)
             rl, rw = roofline(eng, per_op, with_pmc=(args.config == "default"))
             if args.dump_ops:
                 fl = conv_flops(eng)

@@ -151,6 +151,9 @@ class FusedAdam:
         return max(counts) if counts else self.step_count
 
 
+_LIVE_GRAPHS = []
+
+
 class GraphedIteration:
     """One optimisation iteration -- optimizer.zero_grad(); closure(); optimizer.step(), i.e. the body
     of the reference's optimize() loop (utils/common_utils.py:226-230) -- captured ONCE into a
@@ -228,6 +231,11 @@ class GraphedIteration:
             torch.cuda.synchronize(device)
             self.iterations += max(int(warmup), 1)
             self.graph = torch.cuda.CUDAGraph()
+            # Captured graphs are never destroyed before the interpreter exits: with ROCm 7.2, eager launches and
+            # event churn AFTER a hipGraphExec of this iteration had been destroyed aborted the process with glibc
+            # heap-corruption errors in 10-25 % of the runs of the small configurations (bench.py: eager run ->
+            # graph run -> per-launch event timing); with the graphs kept alive the sequence is clean.
+            _LIVE_GRAPHS.append((self.graph, self.capture_stream, self.branch_streams))
             with torch.cuda.graph(self.graph, stream=self.capture_stream):
                 main = torch.cuda.current_stream(device)
                 start = torch.cuda.Event()
