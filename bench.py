@@ -581,8 +581,9 @@ def main():
     # "other_mode"): at 512x512 the GPU is throughput-bound and the eager two-stream schedule wins, small
     # nets are launch-bound and the graph wins.
     modes = {"graph": [True], "eager": [False], "auto": [False, True]}["eager" if args.no_graph else args.mode]
-    # per-launch HIP-event timing for the roofline objects: BEFORE any hipGraph exists in the process (see
-    # dip_optim._LIVE_GRAPHS: event churn after a graph had been torn down crashed the ROCm 7.2 runtime now and then)
+    # per-launch HIP-event timing for the roofline objects: BEFORE any hipGraph exists in the process (event churn
+    # after a captured graph had been torn down aborted 10-25 % of the small-config runs on ROCm 7.2 with glibc
+    # heap-corruption errors; in this order: 0 / 60)
     per_op = None
     if rank == 0 and not args.no_roofline:
         for _ in range(max(3, min(args.warmup, 10))):

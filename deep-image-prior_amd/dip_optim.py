@@ -14,6 +14,8 @@ concurrent branches of ONE graph (grouped multi-instance execution for small ima
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 import dip_native as N
@@ -231,11 +233,13 @@ class GraphedIteration:
             torch.cuda.synchronize(device)
             self.iterations += max(int(warmup), 1)
             self.graph = torch.cuda.CUDAGraph()
-            # Captured graphs are never destroyed before the interpreter exits: with ROCm 7.2, eager launches and
-            # event churn AFTER a hipGraphExec of this iteration had been destroyed aborted the process with glibc
-            # heap-corruption errors in 10-25 % of the runs of the small configurations (bench.py: eager run ->
-            # graph run -> per-launch event timing); with the graphs kept alive the sequence is clean.
-            _LIVE_GRAPHS.append((self.graph, self.capture_stream, self.branch_streams))
+            # ROCm 7.2: per-launch event timing AFTER a captured graph of this iteration had been destroyed aborted
+            # 10-25 % of bench.py's small-config runs with glibc heap-corruption errors (bench.py now takes those
+            # timings before any graph exists: 0 / 30).  DIP_KEEP_GRAPHS=1 keeps every captured graph alive until the
+            # interpreter exits instead -- not the default, because eager iterations run ~11 % slower while a
+            # graph of the same net is alive (128 -> 113 it/s at 512x512).
+            if os.environ.get("DIP_KEEP_GRAPHS", "0") == "1":
+                _LIVE_GRAPHS.append((self.graph, self.capture_stream, self.branch_streams))
             with torch.cuda.graph(self.graph, stream=self.capture_stream):
                 main = torch.cuda.current_stream(device)
                 start = torch.cuda.Event()
