@@ -75,6 +75,34 @@ def test_planner_launch_lists(built):
     assert [(sc.st["d2"].H, sc.st["d2"].W) for sc in eng.sc] == [(250, 211), (125, 106), (63, 53), (32, 27), (16, 14)]
 
 
+def test_launch_plans_of_the_round2_kernels(built):
+    """Host-side launch plans (no GPU): phase-mode split-K of the stride-2 data gradients, slabs of the narrow-layer /
+    thin-input weight gradients, domain of the 64-channel kernel."""
+    import dip_native as N
+    # stride-2 data gradient (dil == 2 descriptors): 4 workgroups per 8x16 tile of the half-resolution grid
+    assert N.conv_plan_dil2(258, 258, 128, 128, 3) == (1, 17 * 9, 0)            # 612 workgroups: one pass
+    k, rows, wsf = N.conv_plan_dil2(130, 130, 128, 128, 3)
+    assert 1 < k <= 4 and wsf == k * 130 * 130 * 128                             # bounded by the 1-tap phase's 4 chunks
+    assert N.conv_plan_dil2(258, 258, 128, 32, 3)[0] == N.conv_plan(258, 258, 128, 32, 3, 1)[0]   # not whole 128-blocks
+    assert N.conv_plan_dil2(260, 260, 128, 128, 5)[0] == N.conv_plan(260, 260, 128, 128, 5, 1)[0]  # 5x5: dilated path
+    # split-K fills one round of 2 workgroups per CU
+    assert N.conv_plan(128, 128, 128, 128, 3, 1)[0] == 4 and N.conv_plan(128, 128, 128, 128, 3, 2)[0] == 4
+    # weight gradient: nsplit counts SLABS; narrow layers write 4 / 2 per workgroup (waves split the K steps)
+    n16 = N.wgrad_plan2(224, 352, 16, 16, 3, 1)[0]
+    n64 = N.wgrad_plan2(224, 352, 16, 64, 3, 1)[0]
+    assert n16 % 4 == 0 and n64 % 2 == 0 and n16 == 2 * n64
+    assert N.wgrad_plan2(512, 512, 132, 128, 3, 1) == (128, 1, 1)
+    assert N.wgrad_plan2(16, 16, 128, 16, 3, 1) == (16, 9, 1)                   # 4 walkers x 4 slabs, 9 tap groups
+    # <= 4 input channels: one slab per block of the streaming kernel, at most 512
+    for args in ((224, 352, 1, 16, 5, 2), (128, 192, 3, 8, 3, 2), (512, 512, 2, 128, 7, 1)):
+        n, g, cb = N.wgrad_plan2(*args)
+        assert 1 <= n <= 512 and n == N.wgrad_plan(*args)
+    # the opt-in 64-channel kernel: 3x3 stride 1, whole 64-chunks (+ <= 4 tail), >= 512 pixel tiles
+    assert N.wgrad_plan64(512, 512, 132, 128, 3, 1) == 128 and N.wgrad_plan64(512, 512, 256, 128, 3, 1) == 64
+    assert N.wgrad_plan64(64, 64, 128, 128, 3, 1) is None and N.wgrad_plan64(512, 512, 128, 128, 3, 2) is None
+    assert N.wgrad_plan64(512, 512, 96, 128, 3, 1) is None
+
+
 def test_planner_builds_launch_lists_for_every_option(built):
     """Both planner passes (sizing + emission of the descriptors) run on CPU memory -- nothing is
     launched -- for every skip() option the backend accepts: per-scale filter sizes 3/5/7, avg / max
