@@ -38,7 +38,7 @@ __device__ __forceinline__ int wmap_src(int v, int n_in, int reflect) {
     return (v < 0 || v >= n_in) ? -1 : v;
 }
 
-template <int KS, int S, int NT, int CB>
+template <int KS, int S, int NT, int CB, bool SLIDE = false>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d, const int ntx, const int ntiles,
                                                             const int CinP, const int CoutP, const int ragged_parts,
                                                             const int kw) {
@@ -195,7 +195,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d
             *reinterpret_cast<f32x4*>(Ds + f * 4) = v;
         }
     };
-    auto walk = [&](const int first, const int step) __attribute__((always_inline)) {      // the pixel tiles first, first + step, ...
+    // the pixel tiles first, first + step, ...; packc = integral_constant<bool>: the SLIDE kernel's compile-time
+    // choice between the (tap, channel)-packed loop of a ragged tail (phase 2) and the sliding-window loop (phase 1)
+    auto walk = [&](auto packc, const int first, const int step) __attribute__((always_inline)) {
+    constexpr bool PACKED = decltype(packc)::value;
     if (PF && first < ntiles) fetch(first);
     for (int tile = first; tile < ntiles; tile += step) {
         __syncthreads();                   // every wave is done with the previous tile
@@ -203,7 +206,57 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d
         __syncthreads();
         if (PF && tile + step < ntiles) fetch(tile + step);
         if (wave_active) {
-            if constexpr (CAN_PACK) {
+            if constexpr (SLIDE) {
+                // Sliding A-operand window (3x3, stride 1).  A K step pairs the pixels (row r, col j) [lanes 0..31] and
+                // (row r, col j + 8) [lanes 32..63]; tap kx of step j reads halo column j + kx (+ 8), which is the
+                // value tap kx + 1 read one step earlier: the window a[ky][.] is kept in registers, so a step costs
+                // NKY new ds_read_b32 (+ 1 for dy) for its 3*NKY MFMAs instead of one read per MFMA.  The column of
+                // step j + 1 is read one step ahead (ring of 4), the MFMA that needs the newest value goes last.
+                constexpr int NKY = NT / 3;
+                const int ky0 = tap0 / 3;
+                if constexpr (PACKED) {
+#pragma unroll 2
+                    for (int s = wk; s < C::NPX / 2; s += kw) {
+                        const int px = 2 * s + half;
+                        const int r = px >> 4, c = px & 15;
+                        const float b = Ds[px * 128 + wcol * 32 + l31];
+                        bsum += b;
+                        const float* ub = Us + (r * C::HTW + c) * C::CW;
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ub[aoff0], b, acc[0], 0, 0, 0);
+                        acc[NT > 1 ? 1 : 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ub[aoff1], b, acc[NT > 1 ? 1 : 0], 0, 0, 0);
+                    }
+                } else {
+#pragma unroll 1
+                    for (int r = wk; r < C::TH; r += kw) {
+                        const float* urow = Us + ((r + ky0) * C::HTW + 8 * half) * C::CW + l31;
+                        const float* drow = Ds + (r * C::TW + 8 * half) * 128 + wcol * 32 + l31;
+                        float a[NKY][4];
+#pragma unroll
+                        for (int ky = 0; ky < NKY; ++ky)
+#pragma unroll
+                            for (int q = 0; q < 3; ++q) a[ky][q] = urow[(ky * C::HTW + q) * C::CW];
+                        float b = drow[0];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            float bn = 0.f;
+                            if (j < 7) {            // operands of step j + 1, in flight under this step's MFMAs
+                                bn = drow[(j + 1) * 128];
+#pragma unroll
+                                for (int ky = 0; ky < NKY; ++ky) a[ky][(j + 3) & 3] = urow[(ky * C::HTW + j + 3) * C::CW];
+                            }
+                            bsum += b;
+#pragma unroll
+                            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                                for (int ky = 0; ky < NKY; ++ky)
+                                    acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ky][(j + kx) & 3], b,
+                                                                                            acc[ky * 3 + kx], 0, 0, 0);
+                            b = bn;
+                            __builtin_amdgcn_sched_barrier(0);      // keep the loads of later steps out of this one
+                        }
+                    }
+                }
+            } else if constexpr (CAN_PACK) {
 #pragma unroll 2
                 for (int s = wk; s < C::NPX / 2; s += kw) {
                     const int px = 2 * s + half;
@@ -245,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d
         }
     }
     };
-    walk(walker, nwalk);
+    walk(std::false_type{}, walker, nwalk);
 
     // ---- write this workgroup's partial slab ----
     if (pack) {
@@ -319,7 +372,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
-            walk(walker + cchunk * nwalk, nwalk * ragged_parts);       // (kw == 1 here)
+            walk(std::true_type{}, walker + cchunk * nwalk, nwalk * ragged_parts);       // (kw == 1 here)
             if (wave_active) {
                 const int o = o0 + wcol * 32 + l31;
                 const int cbase = CinMain + 4 * cchunk;
@@ -348,11 +401,11 @@ int wgrad_kw(int CoutP) {
     return CoutP <= 32 ? 4 : (CoutP <= 64 ? 2 : 1);
 }
 
-template <int KS, int S, int NT, int CB>
+template <int KS, int S, int NT, int CB, bool SLIDE = false>
 int launch(const DipWgradDesc& d, hipStream_t st, int CinP_slab = 0) {
     using C = WCfg<KS, S, NT, CB>;
     static bool attr_set = false;
-    auto kern = conv_wgrad_kernel<KS, S, NT, CB>;
+    auto kern = conv_wgrad_kernel<KS, S, NT, CB, SLIDE>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
@@ -375,6 +428,8 @@ int launch(const DipWgradDesc& d, hipStream_t st, int CinP_slab = 0) {
     int kw = wgrad_kw(CoutP);
     if (ragged_parts > 0 || (d.nsplit % kw) != 0) kw = 1;
     if (d.nsplit / kw > ntiles) DIP_FAIL("conv_wgrad: nsplit out of range (more walkers than pixel tiles)");
+    if (SLIDE && ragged_parts == 0 && KS == 3 && NT == 9 && (d.Cin & 31) >= 1 && (d.Cin & 31) <= 4)
+        return launch<KS, S, NT, CB, false>(d, st, CinP_slab);      // a packed tail chunk in phase 1: the one-loop kernel
     dim3 grid(d.nsplit / kw, ragged_parts > 0 ? ragged_parts : dip_cdiv(CinP, C::CW), C::NGROUPS * dip_cdiv(CoutP, 128));
     // CinP_slab: row count of the slabs when this launch covers only the leading channels of the layer
     hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, st, d, ntx, ntiles, CinP_slab > 0 ? CinP_slab : CinP, CoutP,
@@ -808,6 +863,10 @@ extern "C" int dip_conv_wgrad(const DipWgradDesc* dp, void* stream) {
     if (d.ks == 3 && (g != 1 && g != 3 && g != 9)) DIP_FAIL("conv_wgrad: tap_groups must be 1, 3 or 9");
     if (d.ks == 3 && d.stride == 1 && d.chan_block == 2) return dip_conv_wgrad64(dp, stream);
     if (d.ks == 3 && d.stride == 1) {
+        // sliding A-operand window (see the kernel); DIP_WGRAD_NO_SLIDE=1 keeps the one-read-per-MFMA loop (A/B)
+        static const bool slide = getenv("DIP_WGRAD_NO_SLIDE") == nullptr;
+        if (slide && g == 1) return launch<3, 1, 9, 1, true>(d, st);
+        if (slide && g == 3) return launch<3, 1, 3, 1, true>(d, st);
         return g == 1 ? launch<3, 1, 9, 1>(d, st) : (g == 3 ? launch<3, 1, 3, 1>(d, st) : launch<3, 1, 1, 1>(d, st));
     }
     if (d.ks == 3 && d.stride == 2)

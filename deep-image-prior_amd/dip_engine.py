@@ -623,7 +623,7 @@ class SkipEngine:
         scale's concat, so it runs next to the encoder convs (scratch of its own).
         Fork: an event on the main stream in front of a run of side ops; join: main waits for the
         side stream in front of every op `join_before_fn` selects and at the end.  `deps` =
-        {consumer op name: producer op name}: the consumer's stream waits for an event recorded right
+        {consumer op name: [producer op names]}: the consumer's stream waits for an event recorded right
         after the producer (finer than a join: the main stream does not wait for the weight-gradient
         kernels queued behind the producer).  The side work fills the partially occupied last round of
         workgroups / the latency-bound low-resolution kernels of the main stream instead of idling CUs."""
@@ -635,7 +635,7 @@ class SkipEngine:
         check = N.check
         events = self._events
         deps = deps or {}
-        producers = set(deps.values())
+        producers = {p for ps in deps.values() for p in ps}
 
         def event(tag):
             ev = events.get(tag)
@@ -656,8 +656,8 @@ class SkipEngine:
                 ev.record(side)
                 main.wait_event(ev)
                 pending = False
-            if name in deps:
-                (side if on_side else main).wait_event(event((key, "dep", deps[name])))
+            for prod in deps.get(name, ()):
+                (side if on_side else main).wait_event(event((key, "dep", prod)))
             rc = fn(*args, sptr if on_side else mptr)
             if rc:
                 check(rc, name)
@@ -670,19 +670,39 @@ class SkipEngine:
             ev.record(side)
             main.wait_event(ev)
 
+    _BWD_SIDE = staticmethod(lambda n: n.startswith(("wgrad:", "wgred:", "dgthin:")) or n.endswith(".skip_bn"))
+
+    def _backward_deps(self, ops):
+        """{consumer op: [producer ops]} of the backward list whose two ends run on different streams.
+        * dgrad+ of a skip conv (main stream) consumes dy of the skip BatchNorm backward (side stream);
+        * the thin columns of a 132-column data gradient ("dgthin:X", side stream) are written into the same
+          gradient buffer as the 128 columns of "dgrad:X" (main): whatever main-stream op follows "dgrad:X" reads
+          (or accumulates into) that buffer and must wait for them -- derived from the op list, for ANY conv X
+          (decoder convs in the notebooks' nets; a 129..132-channel down_a / down_b is legal too)."""
+        names = [name for _, _, name in ops]
+        present = set(names)
+        deps = {}
+        for i, sc in enumerate(self.sc):
+            c, p = f"dgrad+:s{i}.skip_conv", f"bnb_apply:s{i}.skip_bn"
+            if sc.ns and c in present and p in present:        # (a wait on a never-recorded event is illegal under capture)
+                deps.setdefault(c, []).append(p)
+        for k, name in enumerate(names):
+            if not name.startswith("dgthin:"):
+                continue
+            main_part = "dgrad:" + name[len("dgthin:"):]
+            j = names.index(main_part, k)
+            consumer = next((n for n in names[j + 1:] if not self._BWD_SIDE(n)), None)
+            if consumer is not None:
+                deps.setdefault(consumer, []).append(name)
+            # (no main-stream op behind it: the final join of _run_two_streams covers it)
+        return deps
+
     def _run_backward_two_streams(self, ops, main):
         deps = self._bwd_deps if getattr(self, "_bwd_deps_for", None) is ops else None
-        self._bwd_deps_for = ops
-        if deps is None:         # dgrad+ of a skip conv (main stream) consumes dy of the skip BatchNorm backward (side)
-            deps = self._bwd_deps = {f"dgrad+:s{i}.skip_conv": f"bnb_apply:s{i}.skip_bn"
-                                     for i, sc in enumerate(self.sc) if sc.ns}
-            # ... and the concat's BatchNorm backward consumes the thin columns of the decoder conv's data gradient
-            deps.update({f"bnb_stats:s{i}.cat_bn": f"dgthin:s{i}.up" for i in range(len(self.sc))})
-            present = {name for _, _, name in ops}          # (a wait on a never-recorded event is illegal under capture)
-            deps = self._bwd_deps = {c: p for c, p in deps.items() if c in present and p in present}
-        self._run_two_streams(ops, main,
-                              lambda n: n.startswith(("wgrad:", "wgred:", "dgthin:")) or n.endswith(".skip_bn"),
-                              lambda n: False, "bwd", deps)
+        if deps is None:
+            deps = self._bwd_deps = self._backward_deps(ops)
+            self._bwd_deps_for = ops
+        self._run_two_streams(ops, main, self._BWD_SIDE, lambda n: False, "bwd", deps)
 
     def _run_forward_two_streams(self, ops, main):
         self._run_two_streams(ops, main, lambda n: n.endswith((".skip_conv", ".skip_bn")),

@@ -1,0 +1,57 @@
+"""CPU arms of the BASELINE.json configs[1] end-quality check, produced by the REAL reference.
+
+    python oracle/make_end_quality_golden.py <size> <iters> <threads> [<threads> ...]
+
+For every thread count (= another summation order inside ATen/oneDNN, nothing else) it runs the
+reference's own `get_net` (models/__init__.py:8) + `get_noise` (utils/common_utils.py:127) +
+`optimize('adam', ...)` (utils/common_utils.py:198-232) on the denoising notebook's closure
+(denoising.ipynb:204-221: reg-noise, forward, EMA of the output, MSE, backward) at <size>^2 for
+<iters> iterations on torch CPU fp32, and appends {"psnr_gt", "psnr_gt_sm", "loss", "threads", "sec"}
+to tests/golden/end_quality_<size>_<iters>.json.  The problem (clean / noisy image), the reg-noise
+generator and the PSNR definition are shared with the GPU arm (tests/end_quality_cpu.py), so the
+GPU test only has to run the HIP fit and compare with the committed arms.
+
+Build container only (needs /root/reference); ~12 minutes per arm at 256^2 x 1800 on 8 cores.
+Test infrastructure only."""
+import json
+import os
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import _refload  # noqa: E402
+
+
+def main():
+    size, iters = int(sys.argv[1]), int(sys.argv[2])
+    threads = [int(t) for t in sys.argv[3:]] or [os.cpu_count()]
+    assert _refload.available(), "needs the reference checkout"
+    RM = _refload.load_ref_models()
+    RU = _refload.load_ref_common_utils()
+    import end_quality_cpu as E     # problem(), run_fit(): shared with the GPU arm
+    path = os.path.join(ROOT, "tests", "golden", f"end_quality_{size}_{iters}.json")
+    arms = json.load(open(path))["cpu_arms"] if os.path.exists(path) else []
+    for th in threads:
+        torch.set_num_threads(th)
+        torch.manual_seed(0)
+        net = RM.get_net(32, 'skip', 'reflection', skip_n33d=128, skip_n33u=128, skip_n11=4, num_scales=5,
+                         upsample_mode='bilinear')
+        z = RU.get_noise(32, 'noise', (size, size))
+        clean, noisy = E.problem(size)
+        res = E.run_fit(net, lambda c: RU.optimize('adam', RU.get_params('net', net, z), c, 0.01, iters),
+                        z, noisy, clean, iters, "cpu")
+        res["threads"] = th
+        print(json.dumps(res), flush=True)
+        arms = [a for a in arms if a["threads"] != th] + [res]
+        with open(path, "w") as f:
+            json.dump({"size": size, "iters": iters, "sigma": E.SIGMA, "reg_noise_std": E.REG, "lr": 0.01,
+                       "source": "real reference (/root/reference) on torch CPU fp32, oracle/make_end_quality_golden.py",
+                       "cpu_arms": sorted(arms, key=lambda a: a["threads"])}, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

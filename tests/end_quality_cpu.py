@@ -27,24 +27,26 @@ REG = 1. / 30.
 TAIL = 20
 
 
-def problem():
+def problem(size=None):
     """Clean image: smooth colour gradients + one step edge; noisy = clip(clean + N(0, sigma^2))."""
+    size = size or SIZE
     rng = np.random.RandomState(0)
-    yy, xx = np.mgrid[0:SIZE, 0:SIZE] / float(SIZE)
+    yy, xx = np.mgrid[0:size, 0:size] / float(size)
     clean = np.stack([0.5 + 0.4 * np.sin(6 * xx) * np.cos(4 * yy), 0.5 + 0.4 * np.cos(5 * xx + 2 * yy),
                       0.3 + 0.5 * (xx > 0.5)]).astype(np.float32)
     noisy = np.clip(clean + rng.normal(scale=SIGMA, size=clean.shape), 0, 1).astype(np.float32)
     return clean, noisy
 
 
-def build():
+def build(size=None):
     """Default net + z exactly as the notebook builds them (torch.manual_seed(0))."""
+    size = size or SIZE
     from models import get_net
     from utils.common_utils import get_noise
     torch.manual_seed(0)
     net = get_net(32, 'skip', 'reflection', skip_n33d=128, skip_n33u=128, skip_n11=4, num_scales=5,
                   upsample_mode='bilinear')
-    z = get_noise(32, 'noise', (SIZE, SIZE))
+    z = get_noise(32, 'noise', (size, size))
     return net, z
 
 

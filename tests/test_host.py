@@ -146,6 +146,34 @@ def test_planner_builds_launch_lists_for_every_option(built):
         e2._build_plan(32, 32, 8)
 
 
+def test_backward_stream_dependencies_follow_the_op_list(built):
+    """Two-stream backward: every side-stream "dgthin:X" launch (the thin columns of a 132-column data gradient) must
+    be waited for by the main-stream op that follows "dgrad:X" -- for ANY conv X, not only the decoder convs of the
+    notebooks' nets (round-2 advisor finding: a 132-channel down_b raced)."""
+    from models.skip import skip
+    net = skip(8, 3, [132, 132], [128, 128], [4, 4], upsample_mode="bilinear", pad="reflection")
+    eng = net.__dict__["_dip_engine"]
+    eng._build_arenas(torch.device("cpu"))
+    eng._build_plan(512, 512, 8)
+    names = [n for _, _, n in eng.bwd_ops]
+    thin = [n for n in names if n.startswith("dgthin:")]
+    assert "dgthin:s0.down_b" in thin and "dgthin:s0.up" in thin, thin
+    deps = eng._backward_deps(eng.bwd_ops)
+    waited = {p for ps in deps.values() for p in ps}
+    assert set(thin) <= waited, (thin, deps)
+    for consumer, prods in deps.items():
+        assert not eng._BWD_SIDE(consumer) or consumer.endswith(".skip_bn") or consumer.startswith("dgrad+"), consumer
+        for p in prods:
+            assert names.index(p) < names.index(consumer), (p, consumer)
+            if p.startswith("dgthin:"):
+                # nothing on the main stream may touch the buffer between the 128-column launch and the wait
+                j = names.index("dgrad:" + p[len("dgthin:"):])
+                between = [n for n in names[j + 1:names.index(consumer)] if not eng._BWD_SIDE(n)]
+                assert between == [], (p, consumer, between)
+    assert deps["bnb_stats:s0.down_a_bn"] == ["dgthin:s0.down_b"]
+    assert deps["dgrad+:s1.skip_conv"] == ["bnb_apply:s1.skip_bn"]      # (a stride-2 down_a has no thin launch)
+
+
 def test_get_noise_get_params_semantics():
     from utils.common_utils import get_noise, get_params, np_to_torch, torch_to_np
     gn = np.load(os.path.join(GOLDEN, "get_noise.npz"))
