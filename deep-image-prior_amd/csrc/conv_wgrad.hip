@@ -714,9 +714,6 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 }  // namespace
 
-extern "C" int dip_wgrad64_eligible(int Cin, int ks, int stride);
-extern "C" int dip_conv_wgrad64(const DipWgradDesc* dp, void* stream);
-
 extern "C" int dip_conv_wgrad_ntiles(int Hout, int Wout) { return dip_cdiv(Wout, 16) * dip_cdiv(Hout, 4); }
 
 // Number of partial slabs (= nsplit of DipWgradDesc) the weight-gradient kernels should be run
@@ -767,23 +764,6 @@ static double wgrad_cost(int nt, int n, int chunks, int groups, int oblk, int ta
     const double t_main = rounds * tiles * t_tile + 4.0;
     const double t_slab = 2.0 * n * slab_bytes / 3.0e6 + 3.0;
     return t_main + t_slab;
-}
-
-// Plan of the 64-channel kernel (conv_wgrad64.hip; chan_block = 2): returns 1 and the pixel split when the layer is
-// in its domain and large enough (>= 512 pixel tiles), else 0.  ONE workgroup per CU with all 512 registers of a
-// lane: faster than conv_wgrad_kernel on its own (128 -> 128 @512^2: 727 -> 644 us) but it cannot share a CU with a
-// convolution workgroup of the other stream: the two-stream iteration as a whole came out 0.5-1.1 % SLOWER with it on
-// the slow class of boxes of the pool (126.4 -> 125.0 it/s) and 1.2 % faster on the fast class (142.1 -> 143.9).
-// dip_engine uses it only when asked to (DIP_WGRAD_64=1).
-extern "C" int dip_wgrad_plan64(int Hout, int Wout, int Cin, int Cout, int ks, int stride, int* nsplit) {
-    const int nt = dip_conv_wgrad_ntiles(Hout, Wout);
-    if (!dip_wgrad64_eligible(Cin, ks, stride) || nt < 512) return 0;
-    const int per_split = ((Cin & ~31) / 64) * dip_cdiv(dip_round_up(Cout, 32), 128);
-    int n = 256 / per_split;
-    if (n > nt / 2) n = nt / 2;
-    if (n < 1) n = 1;
-    *nsplit = n;
-    return 1;
 }
 
 extern "C" int dip_wgrad_plan2(int Hout, int Wout, int Cin, int Cout, int ks, int stride, int* nsplit, int* tap_groups,
@@ -861,7 +841,6 @@ extern "C" int dip_conv_wgrad(const DipWgradDesc* dp, void* stream) {
     const int g = d.tap_groups > 1 ? d.tap_groups : 1;
     if (d.ks == 1 && d.stride == 1) return d.chan_block == 1 ? launch<1, 1, 1, 1>(d, st) : launch<1, 1, 1, 4>(d, st);
     if (d.ks == 3 && (g != 1 && g != 3 && g != 9)) DIP_FAIL("conv_wgrad: tap_groups must be 1, 3 or 9");
-    if (d.ks == 3 && d.stride == 1 && d.chan_block == 2) return dip_conv_wgrad64(dp, stream);
     if (d.ks == 3 && d.stride == 1) {
         // sliding A-operand window (see the kernel); DIP_WGRAD_NO_SLIDE=1 keeps the one-read-per-MFMA loop (A/B)
         static const bool slide = getenv("DIP_WGRAD_NO_SLIDE") == nullptr;

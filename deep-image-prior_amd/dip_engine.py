@@ -420,13 +420,6 @@ class SkipEngine:
         Wo = (x.W + 2 * r.P - r.ks) // r.stride + 1
         CinP, CoutP = round_up(r.Cin, 32), round_up(r.Cout, 32)
         nsplit, tap_groups, chan_block = N.wgrad_plan2(Ho, Wo, r.Cin, r.Cout, r.ks, r.stride)
-        if os.environ.get("DIP_WGRAD_64") == "1":
-            # opt-in: the one-workgroup-per-CU kernel for the large layers (faster on its own, but it cannot share
-            # a CU with the other stream's convolutions: -1.1 ... +1.2 % end to end depending on the box, see
-            # dip_wgrad_plan64)
-            n64 = N.wgrad_plan64(Ho, Wo, r.Cin, r.Cout, r.ks, r.stride)
-            if n64 is not None:
-                nsplit, tap_groups, chan_block = n64, 1, 2
         slab = r.ks * r.ks * CinP * CoutP
         if self._sizing:
             self.wg_need = max(self.wg_need, nsplit * slab)

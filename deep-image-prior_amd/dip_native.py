@@ -1,7 +1,7 @@
 """ctypes binding of libdip_hip.so (C ABI: include/dip_hip.h).
 
 The product path has NO fallback: if the shared library is missing, `lib()` raises.  Build it
-with `python __graft_entry__.py build` (hipcc --offload-arch=gfx950) or `make -C csrc`.
+with `python __graft_entry__.py build` (hipcc --offload-arch=gfx950; the one build recipe).
 """
 from __future__ import annotations
 
@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdip_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 PAD_ZERO, PAD_REFLECT = 0, 1
 UP_NEAREST, UP_BILINEAR = 0, 1
@@ -86,7 +86,6 @@ _SIGS = {
     "dip_conv_igemm_dma_cols": (C.c_int, [C.POINTER(DipConvDesc), C.c_int, C.c_void_p]),
     "dip_conv_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
                                 C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
-    "dip_wgrad_plan64": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "dip_conv_plan_dil2": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
                                      C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "dip_conv_wgrad": (C.c_int, [C.POINTER(DipWgradDesc), C.c_void_p]),
@@ -180,12 +179,6 @@ def conv_plan(Hout, Wout, Cin, Cout, ks, stride):
     k, rows, wsf = C.c_int(), C.c_int(), C.c_int64()
     check(lib().dip_conv_plan(Hout, Wout, Cin, Cout, ks, stride, C.byref(k), C.byref(rows), C.byref(wsf)), "conv_plan")
     return k.value, rows.value, wsf.value
-
-
-def wgrad_plan64(Hout, Wout, Cin, Cout, ks, stride):
-    """nsplit of the 64-channel weight-gradient kernel, or None when the layer is outside its domain."""
-    n = C.c_int()
-    return n.value if lib().dip_wgrad_plan64(Hout, Wout, Cin, Cout, ks, stride, C.byref(n)) == 1 else None
 
 
 def conv_plan_dil2(Hout, Wout, Cin, Cout, ks):

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DIP_ABI_VERSION 2
+#define DIP_ABI_VERSION 3
 
 #define DIP_PAD_ZERO 0
 #define DIP_PAD_REFLECT 1
@@ -156,8 +156,7 @@ typedef struct DipWgradDesc {
     int32_t nsplit;
     int32_t tap_groups;           /* 3x3 MFMA kernel: the 9 taps are spread over 1, 3 or 9 workgroups (more, lighter
                                      workgroups for low-resolution layers); 0 = 1.  From dip_wgrad_plan2. */
-    int32_t chan_block;           /* 1x1 MFMA kernel: input channels per workgroup / 32: 4 (default, 0) or 1;
-                                     3x3 stride 1: 2 = the 64-channel one-workgroup-per-CU kernel (dip_wgrad_plan64) */
+    int32_t chan_block;           /* 1x1 MFMA kernel: input channels per workgroup / 32: 4 (default, 0) or 1 */
 } DipWgradDesc;
 int dip_conv_wgrad(const DipWgradDesc* d, void* stream);
 /* number of 4x16 output tiles walked by the wgrad workgroups (upper bound for nsplit) */
@@ -172,11 +171,6 @@ int dip_wgrad_plan(int Hout, int Wout, int Cin, int Cout, int ks, int stride, in
  * runs ~150 light workgroups instead of 4 heavy ones. */
 int dip_wgrad_plan2(int Hout, int Wout, int Cin, int Cout, int ks, int stride, int* nsplit, int* tap_groups,
                     int* chan_block);
-/* plan of the 64-channel 3x3 kernel (DipWgradDesc.chan_block = 2): 1 + *nsplit when the layer is in its domain
- * (stride 1, 64..256 channels in whole 64-chunks + a <= 4-channel tail, >= 512 pixel tiles), else 0.  That kernel owns
- * a CU (one workgroup, 512 registers per lane): faster alone, slower when another stream's convolutions want to
- * share the CU -- for single-stream callers. */
-int dip_wgrad_plan64(int Hout, int Wout, int Cin, int Cout, int ks, int stride, int* nsplit);
 int dip_wgrad_reduce(const float* partial, const float* bias_partial, int nsplit, int ks, int Cin,
                      int Cout, float* dw /*OIHW*/, float* dbias /*or NULL*/, void* stream);
 

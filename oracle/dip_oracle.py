@@ -190,7 +190,7 @@ def _conv(x, sd, key, k, stride, pad):
     return F.conv2d(x, w, b, stride=stride, padding=to_pad)
 
 
-def _bn_act(x, sd, key, act=True, eps=1e-5, masks=None, act_fun="LeakyReLU"):
+def _bn_act(x, sd, key, act=True, eps=1e-5, masks=None, act_fun="LeakyReLU", zrec=None):
     """bn() + act(): BatchNorm2d in TRAIN mode (batch stats), then act(act_fun), models/common.py:76-92:
     LeakyReLU(0.2) | Swish (x * sigmoid(x), :62-73) | nn.ELU() | 'none' (empty nn.Sequential).
 
@@ -200,6 +200,8 @@ def _bn_act(x, sd, key, act=True, eps=1e-5, masks=None, act_fun="LeakyReLU"):
     that single element changes the gradient by O(1/sqrt(numel)) ~ 1e-3 relative.  With the pattern
     imposed, the oracle differentiates exactly the piecewise-linear branch the other side took."""
     x = F.batch_norm(x, None, None, sd[key + ".weight"], sd[key + ".bias"], True, 0.1, eps)
+    if zrec is not None and act:
+        zrec[key] = x.detach().float()       # (test-only) the pre-activation: tests/parity.mask_report
     if not act or act_fun == "none":
         return x
     if act_fun == "Swish":
@@ -226,10 +228,12 @@ def _concat(inputs):
 
 
 def skip_forward(spec: SkipSpec, sd: Dict[str, torch.Tensor], x: torch.Tensor,
-                 taps: Optional[dict] = None, masks: Optional[dict] = None) -> torch.Tensor:
+                 taps: Optional[dict] = None, masks: Optional[dict] = None,
+                 zrec: Optional[dict] = None) -> torch.Tensor:
     """Forward of the skip encoder-decoder; ``sd`` is keyed like the reference state_dict.
 
-    ``taps`` (optional dict) receives named intermediate tensors for per-layer parity tests.
+    ``taps`` (optional dict) receives named intermediate tensors for per-layer parity tests;
+    ``zrec`` (optional dict) the output of every BatchNorm that is followed by an activation.
     """
     keys, out_key = scale_keys(spec)
 
@@ -244,15 +248,15 @@ def skip_forward(spec: SkipSpec, sd: Dict[str, torch.Tensor], x: torch.Tensor,
         else:                               # ... or nn.MaxPool2d(2, 2), common.py:105-106
             assert spec.downsample_mode[i] == "max", spec.downsample_mode[i]
             d = F.max_pool2d(_conv(x, sd, k.down_a, fd, 1, spec.pad), 2, 2)
-        d = _bn_act(d, sd, k.down_a_bn, masks=masks, act_fun=spec.act_fun)
+        d = _bn_act(d, sd, k.down_a_bn, masks=masks, act_fun=spec.act_fun, zrec=zrec)
         d = _conv(d, sd, k.down_b, fd, 1, spec.pad)
-        d = _bn_act(d, sd, k.down_b_bn, masks=masks, act_fun=spec.act_fun)
+        d = _bn_act(d, sd, k.down_b_bn, masks=masks, act_fun=spec.act_fun, zrec=zrec)
         if i < spec.n_scales - 1:
             d = scale(i + 1, d)
         d = F.interpolate(d, scale_factor=2, mode=spec.upsample_mode[i])
         if ns:
             s = _conv(x, sd, k.skip_conv, spec.filter_skip_size, 1, spec.pad)
-            s = _bn_act(s, sd, k.skip_bn, masks=masks, act_fun=spec.act_fun)
+            s = _bn_act(s, sd, k.skip_bn, masks=masks, act_fun=spec.act_fun, zrec=zrec)
             y = _concat([s, d])
         else:
             y = d
@@ -262,10 +266,10 @@ def skip_forward(spec: SkipSpec, sd: Dict[str, torch.Tensor], x: torch.Tensor,
         y = _conv(y, sd, k.up, fu, 1, spec.pad)
         if taps is not None:
             taps[f"up{i}_raw"] = y
-        y = _bn_act(y, sd, k.up_bn, masks=masks, act_fun=spec.act_fun)
+        y = _bn_act(y, sd, k.up_bn, masks=masks, act_fun=spec.act_fun, zrec=zrec)
         if spec.need1x1_up:
             y = _conv(y, sd, k.up1, 1, 1, spec.pad)
-            y = _bn_act(y, sd, k.up1_bn, masks=masks, act_fun=spec.act_fun)
+            y = _bn_act(y, sd, k.up1_bn, masks=masks, act_fun=spec.act_fun, zrec=zrec)
         return y
 
     y = scale(0, x)
@@ -385,8 +389,8 @@ class OracleNet(torch.nn.Module):
     def sd(self):
         return {k: p for k, p in zip(self.names, self.params)}
 
-    def forward(self, x, taps=None, masks=None):
-        return skip_forward(self.spec, self.sd(), x, taps, masks)
+    def forward(self, x, taps=None, masks=None, zrec=None):
+        return skip_forward(self.spec, self.sd(), x, taps, masks, zrec)
 
 
 def optimize_adam(parameters, closure, LR, num_iter):

@@ -17,6 +17,14 @@ Iteration-1 criterion:
     cancel, so their bound is absolute:  ||g_hip_k|| <= RATIO * ||g_ref32_k|| + ZFLOOR * max_k ||g64_k||.
 The unmasked comparison (against g64n, the oracle's own branch pattern) is reported next to the
 masked one so the effect of imposing the HIP branch pattern stays visible.
+
+Binding on top of the ratio (round-3, VERDICT r02 "make parity binding"):
+  * SURVEY 8c's plain criterion: rel-L2 of every non-zero gradient tensor against the fp64 truth <= REL_L2
+    (1e-4) -- `check()` asserts it next to the ratio;
+  * the masked truth cannot hide a real error: the elements whose LeakyReLU branch differs between the HIP
+    forward and the fp64 oracle are counted (`mask_report`); they must be fewer than MASK_FRAC of the elements
+    of their tensor and every one of them must sit at |z| <= MASK_Z * rms(z) of the fp64 pre-activation, i.e.
+    inside the roundoff band around the kink, where both branches are a correct fp32 answer.
 """
 import numpy as np
 import torch
@@ -26,6 +34,9 @@ import dip_oracle as O
 RATIO = 4.0        # summation-order factor (sequential fp32 MFMA accumulation over K <= 2304 / 4096-pixel slabs)
 FLOOR = 2e-5       # fp32 roundoff floor, relative to the tensor's own norm
 ZFLOOR = 1e-7      # roundoff floor of the analytically-zero tensors, relative to the largest gradient norm
+REL_L2 = 1e-4      # every non-zero gradient tensor, rel-L2 against the fp64 truth
+MASK_FRAC = 1e-5   # LeakyReLU branch mismatches HIP vs fp64 oracle: fraction of a tensor's elements ...
+MASK_Z = 1e-5      # ... and how far from the kink (|z| / rms(z)) a mismatching element may sit
 
 
 def zero_grad_keys(spec, sd=None):
@@ -65,14 +76,15 @@ def zero_grad_keys(spec, sd=None):
     return out
 
 
-def oracle_grads(spec, sd, z, loss_fn, dtype, masks=None, z_requires_grad=False):
+def oracle_grads(spec, sd, z, loss_fn, dtype, masks=None, z_requires_grad=False, zrec=None):
     """Oracle forward/backward in `dtype` (fp64 = the truth, fp32 = the reference's own roundoff).
-    `masks`: LeakyReLU branch pattern of the HIP forward (hipops.lrelu_masks)."""
+    `masks`: LeakyReLU branch pattern of the HIP forward (hipops.lrelu_masks); `zrec`: dict that receives the
+    oracle's pre-activations (for mask_report)."""
     onet = O.OracleNet(spec, {k: v.to(dtype) for k, v in sd.items()})
     zz = z.to(dtype)
     if z_requires_grad:
         zz = zz.clone().requires_grad_(True)
-    out = onet(zz, None, masks)
+    out = onet(zz, None, masks, zrec)
     loss = loss_fn(out, dtype)
     loss.backward()
     grads = {k: p.grad.detach() for k, p in zip(onet.names, onet.params)}
@@ -87,7 +99,7 @@ def grad_report(named_grads, g64, g32, g64n, zero_keys, ratio=RATIO, floor=FLOOR
     dbl = lambda t: torch.as_tensor(t).detach().cpu().double()
     gscale = max(dbl(v).norm().item() for k, v in g64.items() if k not in zero_keys)
     rep = {"worst": 0.0, "worst_key": None, "worst_unmasked": 0.0, "worst_unmasked_key": None, "worst_zero": 0.0,
-           "n_zero": 0, "worst_rel": 0.0}
+           "n_zero": 0, "worst_rel": 0.0, "worst_rel_key": None, "worst_rel_ref": 0.0}
     for k, g in named_grads.items():
         g = dbl(g)
         t, tn, r = dbl(g64[k]), dbl(g64n[k]), dbl(g32[k])
@@ -104,8 +116,11 @@ def grad_report(named_grads, g64, g32, g64n, zero_keys, ratio=RATIO, floor=FLOOR
             tol = ratio * e_ref + floor * t.norm().item() + 1e-30
             q = e_hip / tol
             qn = (g - tn).norm().item() / (ratio * e_ref + floor * tn.norm().item() + 1e-30)
-            rep["worst_rel"] = max(rep["worst_rel"], e_hip / (t.norm().item() + 1e-30))
             desc = f"{k} (err {e_hip:.2e}, ref-fp32 err {e_ref:.2e}, |g| {t.norm().item():.2e})"
+            rel = e_hip / (t.norm().item() + 1e-30)
+            if rel > rep["worst_rel"]:
+                rep["worst_rel"], rep["worst_rel_key"] = rel, desc
+            rep["worst_rel_ref"] = max(rep["worst_rel_ref"], e_ref / (tn.norm().item() + 1e-30))
         if q > rep["worst"]:
             rep["worst"], rep["worst_key"] = q, desc
         if qn > rep["worst_unmasked"]:
@@ -113,10 +128,45 @@ def grad_report(named_grads, g64, g32, g64n, zero_keys, ratio=RATIO, floor=FLOOR
     return rep
 
 
+def mask_report(masks_hip, zrec):
+    """LeakyReLU branch pattern of the HIP forward (hipops.lrelu_masks) against the fp64 oracle's own
+    pre-activations `zrec` (oracle_grads(..., zrec=...) of the unmasked fp64 run): per BatchNorm the number of
+    elements on different branches and how far from the kink the farthest of them sits."""
+    rep = {"n": 0, "frac": 0.0, "frac_key": None, "zrel": 0.0, "zrel_key": None, "numel": 0}
+    for key, m in masks_hip.items():
+        z = zrec[key]
+        diff = m.to(torch.bool) != (z > 0)
+        n = int(diff.sum())
+        rep["n"] += n
+        rep["numel"] += z.numel()
+        if n:
+            frac = n / z.numel()
+            zrel = float(z[diff].abs().max()) / (float(z.double().pow(2).mean().sqrt()) + 1e-30)
+            if frac > rep["frac"]:
+                rep["frac"], rep["frac_key"] = frac, key
+            if zrel > rep["zrel"]:
+                rep["zrel"], rep["zrel_key"] = zrel, key
+    return rep
+
+
+def check(rep, mrep=None):
+    """The binding assertions of the iteration-1 gradient criterion (see the module docstring)."""
+    assert rep["worst"] <= 1.0, fmt(rep)
+    assert rep["worst_zero"] <= 1.0, fmt(rep)
+    assert rep["worst_rel"] <= REL_L2, f"rel-L2 {rep['worst_rel']:.2e} > {REL_L2} [{rep['worst_rel_key']}]; " + fmt(rep)
+    if mrep is not None:
+        assert mrep["frac"] < MASK_FRAC and mrep["zrel"] <= MASK_Z, fmt_masks(mrep)
+
+
+def fmt_masks(mrep):
+    return (f"LeakyReLU branch mismatches vs fp64 oracle: {mrep['n']} of {mrep['numel']} elements, worst tensor "
+            f"{mrep['frac']:.1e} [{mrep['frac_key']}], farthest from the kink |z|/rms {mrep['zrel']:.1e} [{mrep['zrel_key']}]")
+
+
 def fmt(rep):
     return (f"grad err/tol masked {rep['worst']:.2f} [{rep['worst_key']}], unmasked {rep['worst_unmasked']:.2f} "
             f"[{rep['worst_unmasked_key']}], zero-tensors {rep['worst_zero']:.2f} (n={rep['n_zero']}), "
-            f"worst rel-L2 {rep['worst_rel']:.2e}")
+            f"worst rel-L2 {rep['worst_rel']:.2e} (reference fp32 vs its fp64: {rep['worst_rel_ref']:.2e})")
 
 
 def psnr(a, b):

@@ -45,21 +45,25 @@ def _iter1(dev, net, spec, z, loss_cpu, loss_gpu, tag):
     t0 = time.time()
     out32, l32, g32 = PT.oracle_grads(spec, sd, z, loss_cpu, torch.float32)
     t32 = time.time() - t0
-    _, _, g64n = PT.oracle_grads(spec, sd, z, loss_cpu, torch.float64)
+    zrec = {}
+    _, _, g64n = PT.oracle_grads(spec, sd, z, loss_cpu, torch.float64, zrec=zrec)
     net = net.to(dev)
     out = net(z.to(dev))
     loss = loss_gpu(out)
     loss.backward()
     torch.cuda.synchronize()
-    _, _, g64 = PT.oracle_grads(spec, sd, z, loss_cpu, torch.float64, H.lrelu_masks(net, spec))
+    hmasks = H.lrelu_masks(net, spec)
+    _, _, g64 = PT.oracle_grads(spec, sd, z, loss_cpu, torch.float64, hmasks)
+    mrep = PT.mask_report(hmasks, zrec) if spec.act_fun == "LeakyReLU" else None
+    del zrec
     psnr = PT.psnr(out.detach().cpu().numpy(), out32.numpy())
     rel = abs(loss.item() - l32) / abs(l32)
     rep = PT.grad_report({k: p.grad for k, p in net.named_parameters()}, g64, g32, g64n, PT.zero_grad_keys(spec, sd))
     print(f"{tag}: out PSNR {psnr:.1f} dB, loss rel {rel:.2e}, {PT.fmt(rep)}; oracle fp32 fwd+bwd {t32:.1f} s "
-          f"({torch.get_num_threads()} threads)")
+          f"({torch.get_num_threads()} threads)" + ("; " + PT.fmt_masks(mrep) if mrep else ""))
     assert psnr >= 100.0, psnr
     assert rel <= 1e-5, rel
-    assert rep["worst"] <= 1.0, PT.fmt(rep)
+    PT.check(rep, mrep)
     return net, out
 
 

@@ -22,7 +22,7 @@ def test_cabi_exports_every_declared_symbol(built):
     L = ctypes.CDLL(dip_native.LIB_PATH)
     for name in declared:
         assert hasattr(L, name), name
-    assert built.dip_abi_version() == 2
+    assert built.dip_abi_version() == dip_native.ABI_VERSION == 3
     # struct layouts agree with the header's field order (sizes on LP64)
     assert ctypes.sizeof(dip_native.DipTransform) == 24
     assert ctypes.sizeof(dip_native.DipGradSrc) == 24
@@ -97,10 +97,6 @@ def test_launch_plans_of_the_round2_kernels(built):
     for args in ((224, 352, 1, 16, 5, 2), (128, 192, 3, 8, 3, 2), (512, 512, 2, 128, 7, 1)):
         n, g, cb = N.wgrad_plan2(*args)
         assert 1 <= n <= 512 and n == N.wgrad_plan(*args)
-    # the opt-in 64-channel kernel: 3x3 stride 1, whole 64-chunks (+ <= 4 tail), >= 512 pixel tiles
-    assert N.wgrad_plan64(512, 512, 132, 128, 3, 1) == 128 and N.wgrad_plan64(512, 512, 256, 128, 3, 1) == 64
-    assert N.wgrad_plan64(64, 64, 128, 128, 3, 1) is None and N.wgrad_plan64(512, 512, 128, 128, 3, 2) is None
-    assert N.wgrad_plan64(512, 512, 96, 128, 3, 1) is None
 
 
 def test_planner_builds_launch_lists_for_every_option(built):

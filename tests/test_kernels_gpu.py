@@ -214,10 +214,10 @@ def test_conv_wgrad(dev, case, nsplit):
                                  (132, 128, 3, 1, 16, 32, 9, 0, 8), (132, 128, 3, 1, 32, 32, 3, 0, 5),
                                  (128, 128, 3, 2, 32, 32, 9, 0, 4), (32, 128, 3, 2, 32, 64, 3, 0, 2),
                                  (128, 128, 1, 1, 32, 32, 0, 1, 16), (128, 64, 1, 1, 16, 48, 0, 1, 3),
-                                 # chan_block 2 = the 64-channel kernel of the large layers (conv_wgrad64.hip)
-                                 (128, 128, 3, 1, 16, 32, 0, 2, 4), (132, 128, 3, 1, 24, 40, 0, 2, 5),
-                                 (64, 128, 3, 1, 16, 16, 0, 2, 3), (260, 96, 3, 1, 12, 20, 0, 2, 2),
-                                 (192, 256, 3, 1, 8, 16, 0, 2, 2), (129, 128, 3, 1, 19, 27, 0, 2, 7)],
+                                 # ragged sizes / channel tails through the sliding-window loop and its packed tail phase
+                                 (132, 128, 3, 1, 24, 40, 0, 0, 5), (260, 96, 3, 1, 12, 20, 0, 0, 2),
+                                 (192, 256, 3, 1, 8, 16, 0, 0, 2), (129, 128, 3, 1, 19, 27, 0, 0, 7),
+                                 (132, 128, 3, 1, 19, 27, 3, 0, 7)],
                          ids=lambda c: "x".join(map(str, c)))
 def test_conv_wgrad_tap_groups_and_channel_blocks(dev, cfg):
     """The low-resolution launch shapes of dip_wgrad_plan2: the 9 taps of a 3x3 weight gradient spread

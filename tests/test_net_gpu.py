@@ -69,11 +69,19 @@ def _psnr(a, b):
     return O.psnr(np.asarray(a), np.asarray(b))
 
 
-def _grad_report(named_grads, g64, g32, g64n, spec, sd=None):
+def _grad_report(named_grads, g64, g32, g64n, spec, sd=None, masks=None, zrec=None):
     """parity.grad_report: purely relative bound per tensor, absolute roundoff floor only for the
-    analytically-zero tensors (enumerated from the spec and, for BatchNorm gammas, the state_dict)."""
+    analytically-zero tensors (enumerated from the spec and, for BatchNorm gammas, the state_dict);
+    parity.check asserts it together with the plain rel-L2 <= 1e-4 criterion and the bound on the LeakyReLU
+    branch mismatches between the HIP forward (`masks`) and the fp64 oracle (`zrec`)."""
     rep = PT.grad_report(named_grads, g64, g32, g64n, PT.zero_grad_keys(spec, sd))
-    return rep["worst"], PT.fmt(rep)
+    mrep = None
+    if masks is not None and zrec and getattr(spec, "act_fun", "LeakyReLU") == "LeakyReLU":
+        mrep = PT.mask_report(masks, zrec)
+    txt = PT.fmt(rep) + ("; " + PT.fmt_masks(mrep) if mrep else "")
+    print(txt)
+    PT.check(rep, mrep)
+    return rep["worst"], txt
 
 
 @pytest.mark.parametrize("name", list(NETS))
@@ -105,9 +113,11 @@ def test_golden_reference_vectors(dev, name):
     zc, tc, mc = (torch.from_numpy(gold[k]) for k in ("z", "target", "mask"))
     lf = lambda o, dt: torch.nn.functional.mse_loss(o * mc.to(dt), tc.to(dt) * mc.to(dt))
     import hipops
-    _, _, g64 = _oracle_grads(_spec(cfg), learn, zc, lf, torch.float64, hipops.lrelu_masks(net, _spec(cfg)))
-    _, _, g64n = _oracle_grads(_spec(cfg), learn, zc, lf, torch.float64)
-    worst, wk = _grad_report(grads, g64, {k: gold["grad/" + k] for k in grads}, g64n, _spec(cfg), learn)
+    hmasks = hipops.lrelu_masks(net, _spec(cfg))
+    _, _, g64 = _oracle_grads(_spec(cfg), learn, zc, lf, torch.float64, hmasks)
+    zrec = {}
+    _, _, g64n = _oracle_grads(_spec(cfg), learn, zc, lf, torch.float64, zrec=zrec)
+    worst, wk = _grad_report(grads, g64, {k: gold["grad/" + k] for k in grads}, g64n, _spec(cfg), learn, masks=hmasks, zrec=zrec)
     print(f"{name}: out PSNR {psnr:.1f} dB, loss rel {rel:.2e}, worst grad err/tol {worst:.2f} ({wk})")
     assert psnr >= 100.0, psnr
     assert rel <= 1e-5, rel
@@ -169,11 +179,13 @@ def test_default_net_64_against_oracle_and_digest(dev):
     sd = {k: v.detach().cpu() for k, v in net.state_dict().items() if k in O.param_shapes(O.default_spec())}
     lf = lambda o_, dt: torch.nn.functional.mse_loss(o_, target.to(dt))
     import hipops
-    _, _, g64 = _oracle_grads(O.default_spec(), sd, z, lf, torch.float64, hipops.lrelu_masks(net, O.default_spec()))
-    _, _, g64n = _oracle_grads(O.default_spec(), sd, z, lf, torch.float64)
+    hmasks = hipops.lrelu_masks(net, O.default_spec())
+    _, _, g64 = _oracle_grads(O.default_spec(), sd, z, lf, torch.float64, hmasks)
+    zrec = {}
+    _, _, g64n = _oracle_grads(O.default_spec(), sd, z, lf, torch.float64, zrec=zrec)
     _, l32, g32 = _oracle_grads(O.default_spec(), sd, z, lf, torch.float32)
     assert abs(l32 - dg["loss"]) <= 1e-6 * dg["loss"]           # the oracle reproduces the reference digest
-    worst, wk = _grad_report({k: p.grad for k, p in net.named_parameters()}, g64, g32, g64n, O.default_spec(), sd)
+    worst, wk = _grad_report({k: p.grad for k, p in net.named_parameters()}, g64, g32, g64n, O.default_spec(), sd, masks=hmasks, zrec=zrec)
     print(f"default net 64x64: worst grad err/tol {worst:.2f} ({wk})")
     assert worst <= 1.0, (worst, wk)
 
@@ -193,7 +205,8 @@ def test_against_oracle_fresh_seed(dev, hw, mode, nskip):
     target = torch.rand(1, 3, *hw)
     spec = O.SkipSpec(32, 3, [128] * 5, [128] * 5, [nskip] * 5, pad="reflection", upsample_mode=mode)
     lf = lambda o_, dt: torch.nn.functional.mse_loss(o_, target.to(dt))
-    _, _, g64n = _oracle_grads(spec, sd, z, lf, torch.float64)
+    zrec = {}
+    _, _, g64n = _oracle_grads(spec, sd, z, lf, torch.float64, zrec=zrec)
     oo, lo, g32 = _oracle_grads(spec, sd, z, lf, torch.float32)
     net = net.to(dev)
     out = net(z.to(dev))
@@ -201,10 +214,11 @@ def test_against_oracle_fresh_seed(dev, hw, mode, nskip):
     loss.backward()
     torch.cuda.synchronize()
     import hipops
-    _, _, g64 = _oracle_grads(spec, sd, z, lf, torch.float64, hipops.lrelu_masks(net, spec))
+    hmasks = hipops.lrelu_masks(net, spec)
+    _, _, g64 = _oracle_grads(spec, sd, z, lf, torch.float64, hmasks)
     psnr = _psnr(out.detach().cpu().numpy(), oo.numpy())
     rel = abs(loss.item() - lo) / lo
-    worst, wk = _grad_report({k: p.grad for k, p in net.named_parameters()}, g64, g32, g64n, spec, sd)
+    worst, wk = _grad_report({k: p.grad for k, p in net.named_parameters()}, g64, g32, g64n, spec, sd, masks=hmasks, zrec=zrec)
     print(f"oracle {hw} {mode} skip{nskip}: PSNR {psnr:.1f} dB, loss rel {rel:.2e}, grad err/tol {worst:.2f} ({wk})")
     assert psnr >= 100.0 and rel <= 1e-5 and worst <= 1.0, (psnr, rel, worst, wk)
 
@@ -231,7 +245,8 @@ def test_super_resolution_closure_against_oracle(dev):
     def lf(o_, dt):
         return torch.nn.functional.mse_loss(O.downsampler_forward(o_, 4, "lanczos2", 0.5, True), lr.to(dt)) \
             + tv_w * tv_loss(o_, beta=0.5)
-    _, _, g64n = _oracle_grads(spec, sd, z, lf, torch.float64)
+    zrec = {}
+    _, _, g64n = _oracle_grads(spec, sd, z, lf, torch.float64, zrec=zrec)
     oo, lo, g32 = _oracle_grads(spec, sd, z, lf, torch.float32)
     net = net.to(dev)
     down = Downsampler(n_planes=3, factor=4, kernel_type="lanczos2", phase=0.5, preserve_size=True).to(dev)
@@ -242,10 +257,11 @@ def test_super_resolution_closure_against_oracle(dev):
     loss.backward()
     torch.cuda.synchronize()
     import hipops
-    _, _, g64 = _oracle_grads(spec, sd, z, lf, torch.float64, hipops.lrelu_masks(net, spec))
+    hmasks = hipops.lrelu_masks(net, spec)
+    _, _, g64 = _oracle_grads(spec, sd, z, lf, torch.float64, hmasks)
     psnr = _psnr(out.detach().cpu().numpy(), oo.numpy())
     rel = abs(loss.item() - lo) / lo
-    worst, wk = _grad_report({k: p.grad for k, p in net.named_parameters()}, g64, g32, g64n, spec, sd)
+    worst, wk = _grad_report({k: p.grad for k, p in net.named_parameters()}, g64, g32, g64n, spec, sd, masks=hmasks, zrec=zrec)
     print(f"SR closure: PSNR {psnr:.1f} dB, loss rel {rel:.2e}, grad err/tol {worst:.2f} ({wk})")
     assert psnr >= 100.0 and rel <= 1e-5 and worst <= 1.0, (psnr, rel, worst, wk)
 

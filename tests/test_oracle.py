@@ -132,3 +132,36 @@ def test_closure_bookkeeping_restates_the_notebook_rule():
     for o in outs[1:]:
         ema = ema * 0.5 + o * 0.5
     assert torch.allclose(book.out_avg, ema)
+
+
+def test_parity_mask_report_and_check_logic():
+    """tests/parity.py (the checker of the GPU parity tests) on synthetic data: branch mismatches are counted per
+    BatchNorm, their distance from the kink is measured against rms(z), and check() refuses both a mismatch far
+    from the kink and a gradient tensor beyond the plain rel-L2 bound."""
+    import parity as PT
+    torch.manual_seed(0)
+    z = torch.randn(1, 8, 64, 64)
+    z[0, 0, 0, 0], z[0, 3, 5, 7] = 3e-7, -2e-7
+    m = z > 0
+    m[0, 0, 0, 0], m[0, 3, 5, 7] = False, True                  # two flips inside the roundoff band
+    rep = PT.mask_report({"bn": m}, {"bn": z})
+    assert rep["n"] == 2 and abs(rep["frac"] - 2 / z.numel()) < 1e-12 and rep["zrel"] < 1e-6
+    zr = torch.randn(1, 8, 512, 512)
+    zr[0, 0, 0, 0] = 3e-7
+    mr = zr > 0
+    mr[0, 0, 0, 0] = False
+    ok = {"worst": 0.5, "worst_zero": 0.1, "worst_rel": 2e-5, "worst_rel_key": "w", "worst_key": "w", "worst_unmasked": 1.0,
+          "worst_unmasked_key": "w", "n_zero": 0, "worst_rel_ref": 1e-5}
+    PT.check(ok, PT.mask_report({"bn": mr}, {"bn": zr}))
+    mr[0, 1, 0, 0] = ~mr[0, 1, 0, 0]                            # a flip of an element that is NOT near zero
+    with pytest.raises(AssertionError):
+        PT.check(ok, PT.mask_report({"bn": mr}, {"bn": zr}))
+    with pytest.raises(AssertionError):
+        PT.check(dict(ok, worst_rel=3e-4))
+    # oracle_grads hands the pre-activations out
+    spec = O.SkipSpec(4, 3, [8, 8], [8, 8], [4, 4], pad="reflection", upsample_mode="bilinear")
+    sd = {k: torch.randn(s) * 0.2 for k, s in O.param_shapes(spec).items()}
+    zrec = {}
+    PT.oracle_grads(spec, sd, torch.rand(1, 4, 16, 16), lambda o, dt: o.pow(2).mean(), torch.float64, zrec=zrec)
+    keys, _ = O.scale_keys(spec)
+    assert set(zrec) == {b for k in keys for b in (k.skip_bn, k.down_a_bn, k.down_b_bn, k.up_bn, k.up1_bn) if b}
