@@ -191,13 +191,15 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const DipGradSrc src,
 // ------------------------------------------------------------------------------------------
 // backward phase 2: reduce partials (fp64, fixed order) -> dgamma, dbeta, k1 = S1/N, k2 = S2/N
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nblk, int Cs,
-                                                              int C, int npix, float* dgamma, float* dbeta,
-                                                              float* coef) {
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nblk,
+                                                              const float* __restrict__ partials_lo, int nblk_lo,
+                                                              int c_lo, int Cs, int C, int npix, float* dgamma,
+                                                              float* dbeta, float* coef) {
     // block = 256 partial rows x 4 channels (16-byte loads), fp64, fixed-order tree
     __shared__ double sh[256][8];
     const int row = threadIdx.x;
     const int c0 = blockIdx.x * 4;
+    if (c0 < c_lo) { partials = partials_lo; nblk = nblk_lo; }      // (channels of the thin-column launch)
     double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll 2
     for (int t = row; t < nblk; t += 256) {
@@ -352,7 +354,16 @@ extern "C" int dip_bn_bwd_stats(const DipGradSrc* src, const float* y, int H, in
 extern "C" int dip_bn_bwd_finalize(const float* partials, int nblk, int Cs, int C, int npix, float* dgamma,
                                    float* dbeta, float* coef, void* stream) {
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(dip_cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, partials,
-                       nblk, Cs, C, npix, dgamma, dbeta, coef);
+                       nblk, nullptr, 0, 0, Cs, C, npix, dgamma, dbeta, coef);
+    DIP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dip_bn_bwd_finalize2(const float* partials, int nblk, const float* partials_lo, int nblk_lo, int c_lo,
+                                    int Cs, int C, int npix, float* dgamma, float* dbeta, float* coef, void* stream) {
+    if ((c_lo & 3) || (c_lo > 0 && partials_lo == nullptr)) DIP_FAIL("bn_bwd_finalize2: c_lo must be a multiple of 4");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(dip_cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, partials,
+                       nblk, partials_lo, nblk_lo, c_lo, Cs, C, npix, dgamma, dbeta, coef);
     DIP_CHECK_LAUNCH();
     return 0;
 }

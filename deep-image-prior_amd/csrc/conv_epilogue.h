@@ -23,6 +23,7 @@ struct DipEpi {
     int cols_left;    // Wout - tile col origin
     bool full;        // whole 8x16 tile inside the image (workgroup-uniform)
     bool accumulate;
+    int oy0, ox0;     // tile origin in the output domain
 };
 
 __device__ __forceinline__ DipEpi dip_epi_make(const DipConvDesc& d, int ty, int tx, int TH, int TW) {
@@ -36,6 +37,8 @@ __device__ __forceinline__ DipEpi dip_epi_make(const DipConvDesc& d, int ty, int
     e.cols_left = d.Wout - tx * TW;
     e.full = (e.rows_left >= TH) && (e.cols_left >= TW);
     e.accumulate = d.accumulate != 0;
+    e.oy0 = ty * TH;
+    e.ox0 = tx * TW;
     return e;
 }
 
@@ -104,6 +107,71 @@ __device__ __forceinline__ void dip_epi_stats16(const DipEpi& e, const f32x16& a
 // issued just before stay in flight.
 __device__ __forceinline__ void dip_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Fused phase 1 of a BatchNorm(+activation) backward (DipConvDesc.bnb_*): the tile's values (already stored) are the
+// gradient g wrt the activated output on a domain padded by bnb_pad; per channel  s1 = sum g*act'(z),
+// s2 = sum g*act'(z)*xhat  with y taken at the mirror pixel of a ring position (the reflection fold is linear).
+// Lane = channel, so the 16 y loads of an accumulator are the same two 128-byte runs per instruction as its stores.
+template <class C, int BN>
+__device__ __forceinline__ void dip_conv_epilogue_bnb(const DipConvDesc& d, f32x16 (&acc)[C::MS][C::NS], const DipEpi& e,
+                                                      int n0, int wn, int wm, int l31, int half, int tid, int tile,
+                                                      float* red) {
+    const int pad = d.bnb_pad;
+    const int Hi = d.Hout - 2 * pad, Wi = d.Wout - 2 * pad;
+    const int Cs = d.bnb_Cs;
+    dip_lds_barrier();                     // every wave is done reading the staging buffers (`red` aliases them)
+#pragma unroll
+    for (int ns = 0; ns < C::NS; ++ns) {
+        const int n = n0 + (wn * C::NS + ns) * 32 + l31;
+        const bool nv = n < d.Cout;
+        const int nn = nv ? n : 0;
+        const float mean = d.bnb_state[nn], rstd = d.bnb_state[Cs + nn], sa = d.bnb_state[2 * Cs + nn],
+                    sb = d.bnb_state[3 * Cs + nn];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int ms = 0; ms < C::MS; ++ms) {
+            const int sub = wm * C::MS + ms;
+            float yv[16];
+            bool ok[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                ok[r] = nv && dip_epi_valid(e, sub, r, half);
+                const int oy = e.oy0 + 2 * sub + (r >> 3), ox = e.ox0 + (r & 3) + 8 * ((r >> 2) & 1) + 4 * half;
+                const int iy = ok[r] ? dip_reflect(oy - pad, Hi) : 0, ix = ok[r] ? dip_reflect(ox - pad, Wi) : 0;
+                yv[r] = d.bnb_y[((size_t)iy * Wi + ix) * d.bnb_Cy + nn];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float z = fmaf(sa, yv[r], sb);
+                const float gm = ok[r] ? dip_mul_rn(acc[ms][ns][r], dip_act_grad(z, d.bnb_slope)) : 0.f;
+                const float xh = (yv[r] - mean) * rstd;
+                s1 += gm;
+                s2 = fmaf(gm, xh, s2);
+            }
+            __builtin_amdgcn_sched_barrier(0);      // one accumulator's 16 loads in flight at a time (register budget)
+        }
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        if (half == 0) {
+            float* q = red + ((wm * (C::WN * C::NS * 32)) + (wn * C::NS + ns) * 32 + l31) * 2;
+            q[0] = s1; q[1] = s2;
+        }
+    }
+    dip_lds_barrier();
+    if (tid < BN) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < C::WM; ++w) {
+            const float* q = red + (w * (C::WN * C::NS * 32) + tid) * 2;
+            s1 += q[0]; s2 += q[1];
+        }
+        const int n = n0 + tid;
+        if (n < Cs) {
+            float* o = d.bnb_partials + (size_t)tile * 2 * Cs + n;
+            o[0] = s1; o[Cs] = s2;
+        }
+    }
+}
+
 // Whole-tile epilogue for a wave's acc[MS][NS]; C supplies TH, TW, MS, NS, WN, WM.  `red` is LDS
 // scratch of WM * WN*NS*32 * 3 floats (the staging buffers, dead by now).
 template <class C, int BN>
@@ -121,6 +189,11 @@ __device__ __forceinline__ void dip_conv_epilogue(const DipConvDesc& d, f32x16 (
         const int n = n0 + (wn * C::NS + ns) * 32 + l31;
 #pragma unroll
         for (int ms = 0; ms < C::MS; ++ms) dip_epi_store16(e, acc[ms][ns], wm * C::MS + ms, n, bias[ns], half);
+    }
+    if (d.bnb_y != nullptr) {
+        dip_conv_epilogue_bnb<C, BN>(d, acc, e, n0, wn, wm, l31, half, tid, tile, red);
+        if (d.stats == nullptr) return;
+        dip_lds_barrier();                 // (`red` is about to be reused)
     }
     if (d.stats == nullptr) return;
     dip_lds_barrier();                     // every wave is done reading the staging buffers

@@ -573,6 +573,15 @@ extern "C" int dip_conv_variant(const DipConvDesc* dp) {
     return 0;
 }
 
+// fused BatchNorm-backward partials (bnb_* fields) ride in the shared one-pass epilogue (conv_epilogue.h):
+// every one-pass variant except the phase mode (4 workgroups per tile, interleaved pixels) and the N = 160 variant
+extern "C" int dip_conv_bnb_fusable(const DipConvDesc* dp) {
+    static const bool off = getenv("DIP_NO_BNB_FUSE") != nullptr;
+    if (off || dp->ksplit > 1) return 0;
+    const int v = dip_conv_variant(dp);
+    return (v == 0 || v == 1 || v == 3) ? 1 : 0;
+}
+
 // second half of a split-K dispatch: sums the d.ksplit workspace slices in a fixed order, adds the
 // bias, stores and emits the BatchNorm partials (exported so that a profiler can time it on its own)
 extern "C" int dip_conv_splitk_finish(const DipConvDesc* dp, void* stream) {
@@ -593,6 +602,12 @@ extern "C" int dip_conv_igemm(const DipConvDesc* dp, void* stream) {
     if (d.dil != 1 && d.dil != 2) DIP_FAIL("conv_igemm: dil must be 1 or 2");
     if (d.tr.a != nullptr && d.Cin > TR_MAX) DIP_FAIL("conv_igemm: more than 512 input channels with a fused transform");
     int ksplit = d.ksplit > 1 ? d.ksplit : 1;
+    if (d.bnb_y != nullptr) {
+        if (!dip_conv_bnb_fusable(dp)) DIP_FAIL("conv_igemm: fused BatchNorm-backward partials need a one-pass launch (dip_conv_bnb_fusable)");
+        if (d.bnb_state == nullptr || d.bnb_partials == nullptr || d.bnb_Cs < d.Cout || d.bnb_pad < 0 ||
+            d.Hout <= 2 * d.bnb_pad || d.Wout <= 2 * d.bnb_pad)
+            DIP_FAIL("conv_igemm: inconsistent bnb_* fields");
+    }
     if (ksplit > 1) {
         if (d.ws == nullptr) DIP_FAIL("conv_igemm: ksplit > 1 needs a workspace");
         int units = units_of(d.Cin, d.ks, d.stride);

@@ -102,7 +102,8 @@ __global__ __launch_bounds__(256) void conv_thin4_kernel(const DipConvDesc d, co
         }
     }
     const int oy = ty * T4_TH + py, ox = tx * T4_TW + px;
-    if (oy < d.Hout && ox < d.Wout) {
+    const bool inside = oy < d.Hout && ox < d.Wout;
+    if (inside) {
         const int pitch = d.y_pitch > 0 ? d.y_pitch : d.Wout;
         float* p = d.y + ((size_t)oy * pitch + ox) * d.Cy;
         if (d.bias != nullptr) {
@@ -114,12 +115,45 @@ __global__ __launch_bounds__(256) void conv_thin4_kernel(const DipConvDesc d, co
             if (d.accumulate) acc += *reinterpret_cast<const f32x4*>(p);
             *reinterpret_cast<f32x4*>(p) = acc;
         } else {
-            for (int n = 0; n < ncols; ++n) p[n] = d.accumulate ? p[n] + acc[n] : acc[n];
+            for (int n = 0; n < ncols; ++n) {
+                acc[n] = d.accumulate ? p[n] + acc[n] : acc[n];
+                p[n] = acc[n];
+            }
+        }
+    }
+    // fused phase 1 of the BatchNorm backward of these columns (DipConvDesc.bnb_*, see conv_epilogue.h): one row of
+    // {sum g*act'(z), sum g*act'(z)*xhat} per workgroup in bnb_partials_thin (channels 0..3)
+    if (d.bnb_y != nullptr) {
+        f32x4 s1 = f32x4{0.f, 0.f, 0.f, 0.f}, s2 = s1;
+        if (inside) {
+            const int pad = d.bnb_pad, Hi = d.Hout - 2 * pad, Wi = d.Wout - 2 * pad, Cs = d.bnb_Cs;
+            const int iy = dip_reflect(oy - pad, Hi), ix = dip_reflect(ox - pad, Wi);
+            const f32x4 yv = *reinterpret_cast<const f32x4*>(d.bnb_y + ((size_t)iy * Wi + ix) * d.bnb_Cy);
+            const f32x4 mean = *reinterpret_cast<const f32x4*>(d.bnb_state), rstd = *reinterpret_cast<const f32x4*>(d.bnb_state + Cs),
+                        sa = *reinterpret_cast<const f32x4*>(d.bnb_state + 2 * Cs), sb = *reinterpret_cast<const f32x4*>(d.bnb_state + 3 * Cs);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                if (n < ncols) {
+                    const float z = fmaf(sa[n], yv[n], sb[n]);
+                    const float gm = dip_mul_rn(acc[n], dip_act_grad(z, d.bnb_slope));
+                    s1[n] = gm;
+                    s2[n] = gm * ((yv[n] - mean[n]) * rstd[n]);
+                }
+            }
+        }
+        __syncthreads();                    // the halo is dead: reuse it for the tree (256 threads x 8 floats)
+        dip_tree_sum8(halo, 1, 256, tid, 0, true, s1, s2);
+        if (tid == 0) {
+            float* o = d.bnb_partials_thin + (size_t)blockIdx.x * 2 * d.bnb_Cs;
+            *reinterpret_cast<f32x4*>(o) = s1;
+            *reinterpret_cast<f32x4*>(o + d.bnb_Cs) = s2;
         }
     }
 }
 
 }  // namespace
+
+extern "C" int dip_conv_thin4_ntiles(int Hout, int Wout) { return dip_cdiv(Wout, T4_TW) * dip_cdiv(Hout, T4_TH); }
 
 // columns [0, ncols) (ncols <= 4) of a 3x3 stride-1, undilated, transform-free convolution
 extern "C" int dip_conv_thin4(const DipConvDesc* dp, int ncols, void* stream) {
@@ -127,6 +161,8 @@ extern "C" int dip_conv_thin4(const DipConvDesc* dp, int ncols, void* stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (d.ks != 3 || d.stride != 1 || d.dil != 1 || d.tr.a != nullptr || ncols < 1 || ncols > 4 || (d.Cin & 3))
         DIP_FAIL("conv_thin4: unsupported configuration");
+    if (d.bnb_y != nullptr && (d.bnb_partials_thin == nullptr || (d.bnb_Cy & 3) || (d.bnb_Cs & 3)))
+        DIP_FAIL("conv_thin4: fused BatchNorm-backward partials need bnb_partials_thin and 4-aligned strides");
     const int ntx = dip_cdiv(d.Wout, T4_TW), nty = dip_cdiv(d.Hout, T4_TH);
     hipLaunchKernelGGL(conv_thin4_kernel, dim3(ntx * nty), dim3(256), 0, st, d, ntx, dip_round_up(d.Cout, 32), ncols);
     DIP_CHECK_LAUNCH();

@@ -107,8 +107,16 @@ class SkipEngine:
         self.slope = act_slope
         self.nscales = len(scales)
         self.fwd_id = 0
-        self._side = None
+        self._aux = {}                 # (capture | eager, device) -> ([side stream, bulk stream], events)
         self.two_streams = os.environ.get("DIP_TWO_STREAMS", "1") != "0"
+        # backward schedule (see _run_two_streams): the weight gradients emitted before the backward walk reaches
+        # scale `defer_scale` are held back until then, later ones until the end of their scale's decoder / encoder
+        # part (-1: every one is launched where it is emitted)
+        self.defer_scale = int(os.environ.get("DIP_DEFER_WGRAD", "2")) if self.two_streams else -1
+        # forward: skip-branch convs below this many pixels stay on the main stream (a fork + join costs more
+        # than the ~8 us launch it would overlap)
+        self.side_min_pixels = int(os.environ.get("DIP_SIDE_MIN_PIXELS", "0"))
+        self._fwd_side, self._deferred, self._entered_defer_scale, self._fused_bnb = set(), [], False, {}
         self.device = None
         self.shape_key = None
         self.lib = None
@@ -239,6 +247,7 @@ class SkipEngine:
         self.stat_need = self.wg_need = self.wgb_need = self.bwdp_need = self.ws_need = 4
         self.stat2_need = self.ws2_need = 4            # scratch of the skip-branch convs (side stream)
         self.bwdp2_need = 4                            # ... and of the skip-branch BatchNorm backward
+        self.bwdp3_need = 4                            # fused BatchNorm-backward partials of the thin data-gradient columns
 
     def _build_plan(self, H, W, Cin_img):
         div = 2 ** self.nscales
@@ -276,6 +285,11 @@ class SkipEngine:
                 self.stats_scratch2 = self._new(self.stat2_need)
                 self.ws_scratch2 = self._new(self.ws2_need)
                 self.bwd_scratch2 = self._new(self.bwdp2_need)
+                self.bwd_scratch3 = self._new(self.bwdp3_need)
+            self._fused_bnb = {}
+            self._deferred = []
+            self._fwd_side = set()
+            self._entered_defer_scale = False
             self.x_nhwc = self._buf(H * W * round_up(Cin_img, 4))
             xin = Act(self.x_nhwc, H, W, Cin_img)
             last = self._plan_scale(0, xin, H, W)
@@ -285,12 +299,13 @@ class SkipEngine:
             # backward: head, out conv, then the scales from the top
             self.dy_out = self._buf(H * W * round_up(oc.Cout, 4))
             pre = []
-            self._emit_wgrad(oc, last, self.dy_out, pre)
-            du_last = self._emit_dgrad(oc, last, self.dy_out, pre)
+            self._emit_wgrad(oc, last, self.dy_out, pre, scale=0)
+            du_last = self._emit_dgrad(oc, last, self.dy_out, pre, fuse_bn=True)
             dy_last = self._emit_bn_act_bwd(last, du_last, pre)
             self.dbg_top = {"du_last": du_last, "dy_last": dy_last, "last": last}
             self.last_act = last                         # input of the output conv (utils/loss_head.MSEHead)
             self.bwd_ops = pre + self._bwd_scale_ops(0, dy_last)
+            self.bwd_ops += self._flush_deferred_wgrads()       # (fewer scales than defer_scale)
         self.shape_key = (H, W, Cin_img)
 
     def _plan_scale(self, i, xin: Act, H, W):
@@ -365,6 +380,8 @@ class SkipEngine:
         # the skip-branch convs run on the side stream next to the encoder convs of their scale
         # (_run_two_streams), so they get scratch of their own
         side = r.name.endswith("skip_conv")
+        if side and Ho * Wo >= self.side_min_pixels and bn is not None:
+            self._fwd_side.update(("conv_fwd:" + r.name, "bn_fin:" + bn.name))
         if self._sizing:
             if side:
                 if bn is not None:
@@ -415,11 +432,22 @@ class SkipEngine:
         self.fwd_ops.append((self.lib.dip_upcat_fwd, (C.byref(d),), "upcat:" + s.cat_bn.name))
         self._emit_bn_finalize(s.cat_bn, self.stats_scratch, nblk, Cs_cat)
 
-    def _emit_wgrad(self, r: ConvRec, x: Act, dy, ops):
+    def _flush_deferred_wgrads(self):
+        ops, self._deferred = self._deferred, []
+        return ops
+
+    def _emit_wgrad(self, r: ConvRec, x: Act, dy, ops, scale=None):
+        """Weight (+ bias) gradient of conv r.  scale = index of the scale being walked: the two launches are held
+        back (self._deferred) and enter the list in batches -- those of the high-resolution decoder layers when the
+        backward walk reaches self.defer_scale, the others at the end of their scale's decoder / encoder part -- so
+        that the bulk stream forks off the main stream once per batch (every fork is an event on the main stream: a
+        ~6 us bubble in the dependent chain) and the big ones run underneath the low-resolution walk."""
         Ho = (x.H + 2 * r.P - r.ks) // r.stride + 1
         Wo = (x.W + 2 * r.P - r.ks) // r.stride + 1
         CinP, CoutP = round_up(r.Cin, 32), round_up(r.Cout, 32)
         nsplit, tap_groups, chan_block = N.wgrad_plan2(Ho, Wo, r.Cin, r.Cout, r.ks, r.stride)
+        if scale is not None and self.defer_scale >= 0:
+            ops = self._deferred            # enters the list at the next _flush_deferred_wgrads()
         slab = r.ks * r.ks * CinP * CoutP
         if self._sizing:
             self.wg_need = max(self.wg_need, nsplit * slab)
@@ -436,10 +464,13 @@ class SkipEngine:
                     (_ptr(self.wg_scratch), _ptr(self.wgb_scratch) if has_b else None, nsplit, r.ks, r.Cin, r.Cout,
                      _ptr(self.grads, r.w_off), _ptr(self.grads, r.b_off) if has_b else None), "wgred:" + r.name))
 
-    def _emit_dgrad(self, r: ConvRec, x: Act, dy, ops, accumulate_into=None):
+    def _emit_dgrad(self, r: ConvRec, x: Act, dy, ops, accumulate_into=None, fuse_bn=False):
         """Data gradient of conv r wrt its input x.  Returns a DipGradSrc-describing tuple
         (buf, pad, fold).  accumulate_into = (buf, pad): add the gradient into an existing (padded)
-        gradient buffer of the same input (skip-branch conv next to down_a)."""
+        gradient buffer of the same input (skip-branch conv next to down_a).
+        fuse_bn: x is consumed by this conv only, so the launch's output is the complete gradient wrt x's BatchNorm
+        (+activation) output: phase 1 of that BatchNorm's backward rides in the launch's epilogue (DipConvDesc.bnb_*)
+        when the launch is a one-pass one, and _emit_bn_act_bwd skips its statistics pass (self._fused_bnb)."""
         Ho = (x.H + 2 * r.P - r.ks) // r.stride + 1
         Wo = (x.W + 2 * r.P - r.ks) // r.stride + 1
         reflect = r.pad_mode == N.PAD_REFLECT and r.P > 0
@@ -471,15 +502,34 @@ class SkipEngine:
             ksplit, _, wsf = N.conv_plan_dil2(Hg, Wg, round_up(r.Cout, 4), r.Cin, r.ks)
         else:
             ksplit, _, wsf = N.conv_plan(Hg, Wg, round_up(r.Cout, 4), r.Cin, r.ks, 1)
-        if self._sizing:
+        sizing = self._sizing
+        d = N.DipConvDesc(None if sizing else _ptr(dy), Ho, Wo, round_up(r.Cout, 4), round_up(r.Cout, 4),
+                          N.DipTransform(None, None, 1.0), None if sizing else _ptr(self.packed, r.dgrad_off), None,
+                          None if sizing else _ptr(gbuf), Hg, Wg, Cg, r.Cin, 0, r.ks, 1, N.PAD_ZERO, off, r.stride, 0, None,
+                          ksplit, (None if sizing else _ptr(self.ws_scratch)) if ksplit > 1 else None)
+        variant = self.lib.dip_conv_variant(C.byref(d))
+        fused = None
+        if fuse_bn and x.bn is not None and self.lib.dip_conv_bnb_fusable(C.byref(d)):
+            bn = x.bn
+            rows = self.lib.dip_conv_ntiles(Hg, Wg)
+            c_lo = (r.Cin - 128) if variant == 3 else 0          # columns of the conv_thin4 launch (always 4 here: % 4)
+            rows_lo = self.lib.dip_conv_thin4_ntiles(Hg, Wg) if c_lo else 0
+            if c_lo % 4 == 0:
+                fused = (rows, rows_lo, c_lo)
+                self.bwdp_need = max(self.bwdp_need, rows * 2 * bn.Cs)
+                self.bwdp3_need = max(self.bwdp3_need, rows_lo * 2 * bn.Cs)
+        if sizing:
             self.ws_need = max(self.ws_need, wsf)
             return (gbuf, pad)
-        d = N.DipConvDesc(_ptr(dy), Ho, Wo, round_up(r.Cout, 4), round_up(r.Cout, 4),
-                          N.DipTransform(None, None, 1.0), _ptr(self.packed, r.dgrad_off), None,
-                          _ptr(gbuf), Hg, Wg, Cg, r.Cin, 0, r.ks, 1, N.PAD_ZERO, off, r.stride, 0, None,
-                          ksplit, _ptr(self.ws_scratch) if ksplit > 1 else None)
+        if fused is not None:
+            bn = x.bn
+            d.bnb_y, d.bnb_state = _ptr(x.buf), _ptr(bn.state)
+            d.bnb_partials = _ptr(self.bwd_scratch)
+            d.bnb_partials_thin = _ptr(self.bwd_scratch3) if fused[2] else None
+            d.bnb_Cy, d.bnb_Cs, d.bnb_pad, d.bnb_slope = x.Cs, bn.Cs, pad, float(x.slope)
+            self._fused_bnb[gbuf.data_ptr()] = fused
         self.keep.append(d)
-        if self.lib.dip_conv_variant(C.byref(d)) == 3 and self.two_streams:
+        if variant == 3 and self.two_streams:
             # 132-column data gradient = 4 thin columns on the vector ALU + 128 columns on the LDS-DMA kernel:
             # two launches that write disjoint columns, so the thin one goes to the side stream
             # (_run_backward_two_streams makes the BatchNorm backward of the concat wait for it)
@@ -514,12 +564,21 @@ class SkipEngine:
         lib = self.lib
         # phase 1 only reduces (dz = NULL); phase 3 recomputes the masked gradient from the source:
         # 5 tensor passes per BatchNorm instead of 6
-        ops.append((lib.dip_bn_bwd_stats, (C.byref(src), _ptr(a.buf), a.H, a.W, a.Cs, a.C, _ptr(bn.state), bn.Cs,
-                                           float(a.slope), None, a.Cs, _ptr(scratch), nblk),
-                    "bnb_stats:" + bn.name))
-        ops.append((lib.dip_bn_bwd_finalize, (_ptr(scratch), nblk, bn.Cs, bn.C, a.H * a.W,
-                                              _ptr(self.grads, bn.gamma_off), _ptr(self.grads, bn.beta_off),
-                                              _ptr(bn.coef)), "bnb_fin:" + bn.name))
+        fused = self._fused_bnb.get(g[0].data_ptr()) if (choff == 0 and not side) else None
+        if fused is not None:
+            # phase 1 already ran in the epilogue of the data-gradient launch(es) that produced g (_emit_dgrad)
+            rows, rows_lo, c_lo = fused
+            ops.append((lib.dip_bn_bwd_finalize2, (_ptr(self.bwd_scratch), rows, _ptr(self.bwd_scratch3) if c_lo else None,
+                                                   rows_lo, c_lo, bn.Cs, bn.C, a.H * a.W,
+                                                   _ptr(self.grads, bn.gamma_off), _ptr(self.grads, bn.beta_off),
+                                                   _ptr(bn.coef)), "bnb_fin:" + bn.name))
+        else:
+            ops.append((lib.dip_bn_bwd_stats, (C.byref(src), _ptr(a.buf), a.H, a.W, a.Cs, a.C, _ptr(bn.state), bn.Cs,
+                                               float(a.slope), None, a.Cs, _ptr(scratch), nblk),
+                        "bnb_stats:" + bn.name))
+            ops.append((lib.dip_bn_bwd_finalize, (_ptr(scratch), nblk, bn.Cs, bn.C, a.H * a.W,
+                                                  _ptr(self.grads, bn.gamma_off), _ptr(self.grads, bn.beta_off),
+                                                  _ptr(bn.coef)), "bnb_fin:" + bn.name))
         ops.append((lib.dip_bn_bwd_apply_src, (C.byref(src), _ptr(a.buf), a.H, a.W, a.Cs, a.C, _ptr(bn.state), bn.Cs,
                                                float(a.slope), _ptr(bn.coef), _ptr(dz), a.Cs), "bnb_apply:" + bn.name))
         return dz
@@ -550,31 +609,36 @@ class SkipEngine:
         s = self.sc[i]
         st = s.st
         ops = []
+        if i == self.defer_scale:
+            self._entered_defer_scale = True
+            ops += self._flush_deferred_wgrads()
         H, W, xin = st["H"], st["W"], st["xin"]
         if s.up1 is not None:
-            self._emit_wgrad(s.up1, st["u"], dy_last, ops)
-            g = self._emit_dgrad(s.up1, st["u"], dy_last, ops)
+            self._emit_wgrad(s.up1, st["u"], dy_last, ops, scale=i)
+            g = self._emit_dgrad(s.up1, st["u"], dy_last, ops, fuse_bn=True)
             dy_u = self._emit_bn_act_bwd(st["u"], g, ops)
         else:
             dy_u = dy_last
         cat = st["cat_act"]
-        self._emit_wgrad(s.up, cat, dy_u, ops)
-        g = self._emit_dgrad(s.up, cat, dy_u, ops)
+        self._emit_wgrad(s.up, cat, dy_u, ops, scale=i)
+        g = self._emit_dgrad(s.up, cat, dy_u, ops, fuse_bn=True)
         dcat = self._emit_bn_act_bwd(cat, g, ops)            # grad wrt the concat tensor [H,W,Cs_cat]
         dy_s = None
         if s.ns:
             dy_s = self._emit_bn_act_bwd(st["s_act"], (dcat, 0), ops, choff=0, Cg=cat.Cs, side=True)
-            self._emit_wgrad(s.skip_conv, xin, dy_s, ops)
+            self._emit_wgrad(s.skip_conv, xin, dy_s, ops, scale=i)
         deep = st["deep"]
         dy_deep = self._emit_up_bwd(deep, dcat, cat.Cs, s.ns, H, W, s.upsample_mode, ops)
+        if self._entered_defer_scale:
+            ops += self._flush_deferred_wgrads()          # this scale's decoder weight gradients, one fork
         if i < self.nscales - 1:
             ops += self._bwd_scale_ops(i + 1, dy_deep)
             gin = self.sc[i + 1].gin                         # gradient source wrt act d2
             dy_d2 = self._emit_bn_act_bwd(st["d2"], gin, ops)
         else:
             dy_d2 = dy_deep
-        self._emit_wgrad(s.down_b, st["d1"], dy_d2, ops)
-        g = self._emit_dgrad(s.down_b, st["d1"], dy_d2, ops)
+        self._emit_wgrad(s.down_b, st["d1"], dy_d2, ops, scale=i)
+        g = self._emit_dgrad(s.down_b, st["d1"], dy_d2, ops, fuse_bn=True)
         dy_d1 = self._emit_bn_act_bwd(st["d1"], g, ops)
         if s.pool in ('avg', 'max'):        # adjoint of the pooling: dy of the full-resolution conv output
             Cs1 = round_up(s.down_a.Cout, 4)
@@ -588,12 +652,14 @@ class SkipEngine:
                                                             s.down_a.Cout, _ptr(dy_full), Cs1),
                                 "poolb:" + s.down_a_bn.name))
             dy_d1 = dy_full
-        self._emit_wgrad(s.down_a, xin, dy_d1, ops)
+        self._emit_wgrad(s.down_a, xin, dy_d1, ops, scale=i)
         tgt = ops if i > 0 else self.bwd_input_ops
         g = self._emit_dgrad(s.down_a, xin, dy_d1, tgt)
         if s.ns:
             g = self._emit_dgrad(s.skip_conv, xin, dy_s, tgt, accumulate_into=g)
         s.gin = g
+        if self._entered_defer_scale:
+            ops += self._flush_deferred_wgrads()          # ... and its encoder ones
         s.dbg = {"dy_last": dy_last, "dy_u": dy_u, "dcat": dcat, "dy_s": dy_s, "dy_deep": dy_deep, "dy_d2": dy_d2,
                  "dy_d1": dy_d1}      # gradient buffers by role (tests/debug_grads.py)
         return ops
@@ -606,27 +672,31 @@ class SkipEngine:
             if rc:
                 check(rc, name)
 
-    def _run_two_streams(self, ops, main, on_side_fn, join_before_fn, key, deps=None):
-        """Launch list on two HIP streams.
+    def _run_two_streams(self, ops, main, cls_fn, join_before_fn, key, deps=None):
+        """Launch list on the main HIP stream + two auxiliary streams; cls_fn(name) -> 0 main, 1 side, 2 bulk.
         Backward: the weight-gradient kernels (+ their slab reductions) of a layer depend only on that
-        layer's dy and the stored activations, not on the data-gradient / BatchNorm-backward chain
-        that continues to the next layer; the BatchNorm backward of the 4-channel skip branch depends
-        only on the concat gradient.  Forward: the 1x1 skip-branch conv (+ its BatchNorm
-        finalisation) of a scale depends only on the scale's input and is needed again at the
-        scale's concat, so it runs next to the encoder convs (scratch of its own).
-        Fork: an event on the main stream in front of a run of side ops; join: main waits for the
-        side stream in front of every op `join_before_fn` selects and at the end.  `deps` =
-        {consumer op name: [producer op names]}: the consumer's stream waits for an event recorded right
-        after the producer (finer than a join: the main stream does not wait for the weight-gradient
-        kernels queued behind the producer).  The side work fills the partially occupied last round of
-        workgroups / the latency-bound low-resolution kernels of the main stream instead of idling CUs."""
-        if self._side is None or self._side.device != self.device:
-            self._side = torch.cuda.Stream(self.device)
-            self._events = {}
-        side = self._side
-        mptr, sptr = main.cuda_stream, side.cuda_stream
+        layer's dy and the stored activations, and nothing but the optimiser step waits for them: they form the
+        BULK stream.  Co-running a big weight gradient with the big data gradient of the same layer buys nothing
+        (both are MFMA-bound: 1430 us together = 700 + 780 alone, profiles/r03_timeline_*), whereas the main
+        chain's walk through the low-resolution scales leaves the chip ~85 % idle for 1.6 ms (latency-bound
+        launches) -- so the launch list holds the big weight gradients back (_flush_deferred_wgrads) and the bulk
+        stream runs them underneath that walk (+1.8 %; restricting them to part of the chip so that the walk keeps
+        moving -- smaller grids, a CU-masked stream -- was measured and does not pay).  SIDE stream: small work the main chain waits for again -- the BatchNorm backward of the 4-channel
+        skip branch, the thin columns of the 132-column data gradients; forward: the 1x1 skip-branch conv (+ its
+        BatchNorm finalisation) of a scale next to the encoder convs (scratch of its own).
+        Fork: before an auxiliary op, its stream waits for an event recorded on the main stream if the main stream
+        has advanced since that stream's last fork; join: main waits for the side stream in front of every op
+        `join_before_fn` selects, and for both at the end.  `deps` = {consumer op name: [producer op names]}: the
+        consumer's stream waits for an event recorded right after the producer (finer than a join)."""
+        capturing = torch.cuda.is_current_stream_capturing()
+        slot = "cap" if capturing else "eager"      # separate streams / events for captured and eager runs
+        st_ = self._aux.get((slot, self.device))
+        if st_ is None:
+            st_ = self._aux[(slot, self.device)] = ([torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)], {})
+        aux, events = st_
+        streams = [main, aux[0], aux[1]]
+        ptrs = [s_.cuda_stream for s_ in streams]
         check = N.check
-        events = self._events
         deps = deps or {}
         producers = {p for ps in deps.values() for p in ps}
 
@@ -636,38 +706,46 @@ class SkipEngine:
                 ev = events[tag] = torch.cuda.Event()
             return ev
 
-        prev_side = False
-        pending = False                       # side work the main stream has not joined yet
+        main_seq = 0                          # main-stream ops issued so far
+        forked = [0, -1, -1]                  # main_seq at the last fork of each auxiliary stream
+        pending = [False, False, False]       # auxiliary work the main stream has not joined yet
         for k, (fn, args, name) in enumerate(ops):
-            on_side = on_side_fn(name)
-            if on_side and not prev_side:
+            c = cls_fn(name)
+            if c and forked[c] != main_seq:
                 ev = event((key, "fork", k))
                 ev.record(main)
-                side.wait_event(ev)
-            if not on_side and pending and join_before_fn(name):
+                streams[c].wait_event(ev)
+                forked[c] = main_seq
+            if c == 0 and pending[1] and join_before_fn(name):
                 ev = event((key, "join", k))
-                ev.record(side)
+                ev.record(streams[1])
                 main.wait_event(ev)
-                pending = False
+                pending[1] = False
             for prod in deps.get(name, ()):
-                (side if on_side else main).wait_event(event((key, "dep", prod)))
-            rc = fn(*args, sptr if on_side else mptr)
+                streams[c].wait_event(event((key, "dep", prod)))
+            rc = fn(*args, ptrs[c])
             if rc:
                 check(rc, name)
             if name in producers:
-                event((key, "dep", name)).record(side if on_side else main)
-            pending = pending or on_side
-            prev_side = on_side
-        if pending:
-            ev = event((key, "join", -1))
-            ev.record(side)
-            main.wait_event(ev)
+                event((key, "dep", name)).record(streams[c])
+            if c:
+                pending[c] = True
+            else:
+                main_seq += 1
+        for c in (1, 2):
+            if pending[c]:
+                ev = event((key, "join", -c))
+                ev.record(streams[c])
+                main.wait_event(ev)
 
-    _BWD_SIDE = staticmethod(lambda n: n.startswith(("wgrad:", "wgred:", "dgthin:")) or n.endswith(".skip_bn"))
+    # stream class of a backward op: 2 = bulk (weight gradients), 1 = side, 0 = main
+    _BWD_SIDE = staticmethod(lambda n: 2 if n.startswith(("wgrad:", "wgred:")) else
+                             (1 if (n.startswith("dgthin:") or n.endswith(".skip_bn")) else 0))
 
     def _backward_deps(self, ops):
         """{consumer op: [producer ops]} of the backward list whose two ends run on different streams.
-        * dgrad+ of a skip conv (main stream) consumes dy of the skip BatchNorm backward (side stream);
+        * dgrad+ of a skip conv (main stream) and its weight gradient (bulk stream) consume dy of the skip BatchNorm
+          backward (side stream);
         * the thin columns of a 132-column data gradient ("dgthin:X", side stream) are written into the same
           gradient buffer as the 128 columns of "dgrad:X" (main): whatever main-stream op follows "dgrad:X" reads
           (or accumulates into) that buffer and must wait for them -- derived from the op list, for ANY conv X
@@ -678,6 +756,10 @@ class SkipEngine:
         for i, sc in enumerate(self.sc):
             c, p = f"dgrad+:s{i}.skip_conv", f"bnb_apply:s{i}.skip_bn"
             if sc.ns and c in present and p in present:        # (a wait on a never-recorded event is illegal under capture)
+                deps.setdefault(c, []).append(p)
+            # ... and so does the skip conv's weight gradient (bulk stream)
+            c = f"wgrad:s{i}.skip_conv"
+            if sc.ns and c in present and p in present:
                 deps.setdefault(c, []).append(p)
         for k, name in enumerate(names):
             if not name.startswith("dgthin:"):
@@ -698,8 +780,8 @@ class SkipEngine:
         self._run_two_streams(ops, main, self._BWD_SIDE, lambda n: False, "bwd", deps)
 
     def _run_forward_two_streams(self, ops, main):
-        self._run_two_streams(ops, main, lambda n: n.endswith((".skip_conv", ".skip_bn")),
-                              lambda n: n.startswith("upcat:"), "fwd")
+        side = self._fwd_side
+        self._run_two_streams(ops, main, lambda n: 1 if n in side else 0, lambda n: n.startswith("upcat:"), "fwd")
 
     def forward(self, x: torch.Tensor, head=None):
         """Runs the forward launch list.  head = None: returns the network output [1,C,H,W].

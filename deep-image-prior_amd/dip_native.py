@@ -35,7 +35,11 @@ class DipConvDesc(C.Structure):
                 ("y_pitch", C.c_int32),
                 ("ks", C.c_int32), ("stride", C.c_int32), ("pad_mode", C.c_int32), ("off", C.c_int32),
                 ("dil", C.c_int32), ("accumulate", C.c_int32), ("stats", C.c_void_p),
-                ("ksplit", C.c_int32), ("ws", C.c_void_p)]
+                ("ksplit", C.c_int32), ("ws", C.c_void_p),
+                # fused phase 1 of the BatchNorm backward of the conv's INPUT activation (data-gradient launches)
+                ("bnb_y", C.c_void_p), ("bnb_state", C.c_void_p), ("bnb_partials", C.c_void_p),
+                ("bnb_partials_thin", C.c_void_p), ("bnb_Cy", C.c_int32), ("bnb_Cs", C.c_int32),
+                ("bnb_pad", C.c_int32), ("bnb_slope", C.c_float)]
 
 
 class DipWgradDesc(C.Structure):
@@ -81,6 +85,8 @@ _SIGS = {
     "dip_conv_igemm": (C.c_int, [C.POINTER(DipConvDesc), C.c_void_p]),
     "dip_conv_ntiles": (C.c_int, [C.c_int, C.c_int]),
     "dip_conv_variant": (C.c_int, [C.POINTER(DipConvDesc)]),
+    "dip_conv_bnb_fusable": (C.c_int, [C.POINTER(DipConvDesc)]),
+    "dip_conv_thin4_ntiles": (C.c_int, [C.c_int, C.c_int]),
     "dip_conv_splitk_finish": (C.c_int, [C.POINTER(DipConvDesc), C.c_void_p]),
     "dip_conv_thin4": (C.c_int, [C.POINTER(DipConvDesc), C.c_int, C.c_void_p]),
     "dip_conv_igemm_dma_cols": (C.c_int, [C.POINTER(DipConvDesc), C.c_int, C.c_void_p]),
@@ -103,6 +109,8 @@ _SIGS = {
     "dip_bn_bwd_nblk": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "dip_bn_bwd_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p]),
+    "dip_bn_bwd_finalize2": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dip_bn_bwd_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                    C.c_void_p, C.c_void_p]),
     "dip_bn_bwd_apply_src": (C.c_int, [C.POINTER(DipGradSrc), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -40,6 +40,7 @@ extern "C" {
 int dip_abi_version(void);
 const char* dip_last_error(void);
 
+
 /* Per-channel input transform fused into a consumer's loader:
  *   u = act(t),  t = a[c]*x + b[c];  act = max(t, slope*t) for slope in (0, 1] (slope = 1 -> affine
  *   only), t*sigmoid(t) for slope == DIP_ACT_SWISH, ELU(alpha=1) for slope == DIP_ACT_ELU
@@ -107,10 +108,31 @@ typedef struct DipConvDesc {
                                     `ws`, then a fixed-order reduction (small images: too few tiles
                                     to fill 256 CUs otherwise); take the value from dip_conv_plan */
     float* ws;                   /* split-K workspace, ksplit*Hout*Wout*Cy floats, or NULL */
+    /* Optional (data-gradient launches): phase 1 of the backward of the BatchNorm(+activation) that PRODUCED this
+     * convolution's input in the forward pass, fused into the epilogue.  The launch's output is the gradient g wrt
+     * that BatchNorm's activated output on a domain padded by bnb_pad (reflection padding: the fold of the ring is
+     * linear, so every padded position contributes with the activation of its mirror pixel):
+     *   {sum g*act'(z), sum g*act'(z)*xhat},  z = a*y + b,  per output tile and channel
+     *   -> bnb_partials [dip_conv_ntiles(Hout, Wout)][2][bnb_Cs]   (8x16-pixel tiles; columns >= 128 of a
+     *      129..132-column gradient come from conv_thin4: bnb_partials_thin [dip_conv_thin4_ntiles()][2][bnb_Cs])
+     * i.e. what dip_bn_bwd_stats(dz = NULL) computes in a pass of its own over g and y (autograd
+     * NativeBatchNormBackward + LeakyReluBackward of models/common.py:82,96); dip_bn_bwd_finalize2 reduces the
+     * rows.  bnb_y == NULL: off.  Only one-pass launches (dip_conv_bnb_fusable). */
+    const float* bnb_y;          /* raw output y of the conv in front of that BatchNorm, [H][W][bnb_Cy], H = Hout - 2*bnb_pad */
+    const float* bnb_state;      /* its state block [4][bnb_Cs]: mean, rstd, a, b */
+    float* bnb_partials;
+    float* bnb_partials_thin;
+    int32_t bnb_Cy, bnb_Cs, bnb_pad;
+    float bnb_slope;
 } DipConvDesc;
 int dip_conv_igemm(const DipConvDesc* d, void* stream);
 /* number of 8x16 output tiles */
 int dip_conv_ntiles(int Hout, int Wout);
+/* number of 16x16 output tiles of dip_conv_thin4 (rows of bnb_partials_thin) */
+int dip_conv_thin4_ntiles(int Hout, int Wout);
+/* 1 when dip_conv_igemm runs `d` in one pass through a kernel whose epilogue can emit the fused BatchNorm-backward
+ * partials (bnb_* fields; evaluated with bnb_y ignored): no split-K, not the phase mode, not the N = 160 variant */
+int dip_conv_bnb_fusable(const DipConvDesc* d);
 /* launch plan of one convolution: split-K factor, rows of the statistics partial buffer and the
  * split-K workspace size in floats (0 when *ksplit == 1) */
 int dip_conv_plan(int Hout, int Wout, int Cin, int Cout, int ks, int stride, int* ksplit, int* stats_rows,
@@ -202,6 +224,10 @@ int dip_bn_bwd_nblk(int H, int W, int C);
 /* phase 2: reduce partials -> dgamma, dbeta (grad arena) and k1 = S1/N, k2 = S2/N in `coef` [2][Cs] */
 int dip_bn_bwd_finalize(const float* partials, int nblk, int Cs, int C, int npix, float* dgamma,
                         float* dbeta, float* coef, void* stream);
+/* phase 2 over two partial buffers: channels < c_lo from partials_lo [nblk_lo][2][Cs] (the conv_thin4 columns of a
+ * 129..132-column data gradient with fused statistics), the others from partials [nblk][2][Cs]; c_lo % 4 == 0 */
+int dip_bn_bwd_finalize2(const float* partials, int nblk, const float* partials_lo, int nblk_lo, int c_lo, int Cs,
+                         int C, int npix, float* dgamma, float* dbeta, float* coef, void* stream);
 /* phase 3 (in place): dy = a * (dz - k1 - xhat*k2) */
 int dip_bn_bwd_apply(float* dz, int Cdz, const float* y, int Cy, int npix, int C, const float* state,
                      int Cs, const float* coef, void* stream);

@@ -1,7 +1,12 @@
 """CPU arm of tests/test_net_gpu.py::test_end_quality_default_net_128: the denoising notebook's
 closure (denoising.ipynb:204-221 of the reference) on the CPU oracle with a given thread count.
 
-    python tests/end_quality_cpu.py <threads> <iters> <out.json>
+    python tests/end_quality_cpu.py <threads> <iters> <out.json> [<size> [<perturb>]]
+
+<perturb> = k > 0 multiplies ONE weight (element 0 of the k-th parameter tensor) by 1 + 2^-22 before the fit:
+trajectories are chaotic (a 1e-7 relative change of one weight decorrelates the outputs within 5
+iterations), so such arms sample the run-to-run spread of the end quality much better than thread counts do (which
+leave the convolutions' summation order untouched).
 
 Prints/writes {"psnr_gt": tail-averaged PSNR vs the clean image, "psnr_gt_sm": PSNR of the EMA
 output, "loss": final loss, "sec": wall time}.  Test infrastructure only."""
@@ -77,15 +82,26 @@ def run_fit(net_call, params_step, z, noisy, clean, iters, device, exp_weight=0.
             "loss": float(st["loss"].item()), "sec": time.time() - t0}
 
 
+def perturb_one_weight(params, k):
+    """k > 0: element 0 of the k-th parameter tensor *= 1 + 2^-22 (one or two ulps)."""
+    if k > 0:
+        with torch.no_grad():
+            p = list(params)[k]
+            p.view(-1)[0] *= 1.0 + 2.0 ** -22
+
+
 def main():
     threads, iters, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+    size = int(sys.argv[4]) if len(sys.argv) > 4 else SIZE
+    perturb = int(sys.argv[5]) if len(sys.argv) > 5 else 0
     torch.set_num_threads(threads)
-    clean, noisy = problem()
-    net, z = build()
+    clean, noisy = problem(size)
+    net, z = build(size)
+    perturb_one_weight(net.parameters(), perturb)
     sd = {k: v.detach().clone() for k, v in net.state_dict().items() if k in O.param_shapes(O.default_spec())}
     onet = O.OracleNet(O.default_spec(), sd)
     res = run_fit(onet, lambda c: O.optimize_adam(onet.params, c, 0.01, iters), z, noisy, clean, iters, "cpu")
-    res["threads"] = threads
+    res["threads"], res["perturb"] = threads, perturb
     with open(out, "w") as f:
         json.dump(res, f)
     print(json.dumps(res))

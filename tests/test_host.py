@@ -158,7 +158,7 @@ def test_backward_stream_dependencies_follow_the_op_list(built):
     waited = {p for ps in deps.values() for p in ps}
     assert set(thin) <= waited, (thin, deps)
     for consumer, prods in deps.items():
-        assert not eng._BWD_SIDE(consumer) or consumer.endswith(".skip_bn") or consumer.startswith("dgrad+"), consumer
+        assert not eng._BWD_SIDE(consumer) or consumer.endswith(".skip_bn") or consumer.startswith(("dgrad+", "wgrad:")), consumer
         for p in prods:
             assert names.index(p) < names.index(consumer), (p, consumer)
             if p.startswith("dgthin:"):
@@ -166,8 +166,14 @@ def test_backward_stream_dependencies_follow_the_op_list(built):
                 j = names.index("dgrad:" + p[len("dgthin:"):])
                 between = [n for n in names[j + 1:names.index(consumer)] if not eng._BWD_SIDE(n)]
                 assert between == [], (p, consumer, between)
-    assert deps["bnb_stats:s0.down_a_bn"] == ["dgthin:s0.down_b"]
+    # (the BatchNorm-backward statistics of down_a_bn ride in the data-gradient launches: the finalisation waits)
+    assert deps["bnb_fin:s0.down_a_bn"] == ["dgthin:s0.down_b"] and "bnb_stats:s0.down_a_bn" not in names
+    assert deps["bnb_fin:s0.cat_bn"] == ["dgthin:s0.up"]
     assert deps["dgrad+:s1.skip_conv"] == ["bnb_apply:s1.skip_bn"]      # (a stride-2 down_a has no thin launch)
+    # the weight gradients run on the bulk stream: the skip conv's waits for the side stream's BatchNorm backward
+    assert deps["wgrad:s0.skip_conv"] == ["bnb_apply:s0.skip_bn"] and deps["wgrad:s1.skip_conv"] == ["bnb_apply:s1.skip_bn"]
+    cls = [eng._BWD_SIDE(n) for n in names]
+    assert set(cls) == {0, 1, 2} and all(c == 2 for n, c in zip(names, cls) if n.startswith(("wgrad:", "wgred:")))
 
 
 def test_get_noise_get_params_semantics():

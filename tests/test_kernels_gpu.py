@@ -331,6 +331,90 @@ def test_bn_forward_backward_chain(dev, Cc, Hh, Ww, P, slope):
     _check("bn_bwd.dbeta", dbet, r64[2], r32[2], floor=5e-6)
 
 
+@pytest.mark.parametrize("Cin,Cout,ks,Hh,Ww,slope,mode", [
+    (128, 128, 3, 24, 40, 0.2, "reflect"),      # LDS-DMA kernel, padded domain with a reflected ring, ragged tiles
+    (132, 128, 3, 16, 32, 1.0, "reflect"),      # 132 columns: conv_thin4 (4 columns) + 128 columns, no activation (concat BN)
+    (128, 128, 1, 16, 48, 0.2, "reflect"),      # 1x1 (no padding)
+    (64, 96, 3, 19, 23, 0.2, "zero"),           # zero padding, 64-column block
+    (128, 8, 1, 16, 16, 0.2, "reflect"),        # data gradient of a thin conv (K = 8), like the RGB output conv
+    (32, 32, 5, 12, 20, 0.2, "reflect")])       # 5x5: the register-staged kernel's epilogue
+def test_bn_backward_statistics_fused_into_the_data_gradient(dev, Cin, Cout, ks, Hh, Ww, slope, mode):
+    """DipConvDesc.bnb_*: phase 1 of the BatchNorm(+LeakyReLU) backward of a conv's INPUT activation computed in the
+    epilogue of the data-gradient launch (per tile, ring positions weighted with the activation of their mirror
+    pixel) + dip_bn_bwd_finalize2, against the separate pass dip_bn_bwd_stats + dip_bn_bwd_finalize over the same
+    gradient buffer, and against autograd in fp64."""
+    lib = N.lib()
+    g = torch.Generator().manual_seed(Cin + ks)
+    P = (ks - 1) // 2
+    pad_mode = REFLECT if mode == "reflect" else N.PAD_ZERO
+    y = torch.randn(1, Cin, Hh, Ww, generator=g) * 1.5 + torch.randn(1, Cin, 1, 1, generator=g)
+    gamma, beta = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) / (ks * Cin ** 0.5)
+    dy = torch.randn(1, Cout, Hh, Ww, generator=g)
+
+    def ref(dt):
+        yy = y.to(dt).requires_grad_(True)
+        ga, be = gamma.to(dt).requires_grad_(True), beta.to(dt).requires_grad_(True)
+        u = F.batch_norm(yy, None, None, ga, be, True, 0.1, 1e-5)
+        u = torch.maximum(u, slope * u) if slope < 1.0 else u
+        o = _ref_conv(u, w.to(dt), None, 1, pad_mode, dt)
+        (o * dy.to(dt)).sum().backward()
+        return ga.grad, be.grad
+
+    r64, r32 = ref(torch.float64), ref(torch.float32)
+    st = H.stream(dev)
+    Cs = round_up(Cin, 4)
+    # forward state of the BatchNorm (mean, rstd, a, b) from the host (the finalisation kernel has its own test)
+    y64 = y.double()[0].reshape(Cin, -1)
+    mean, var = y64.mean(1), y64.var(1, unbiased=False)
+    rstd = 1 / torch.sqrt(var + 1e-5)
+    state = torch.zeros(4, Cs, dtype=torch.float64)
+    state[0, :Cin], state[1, :Cin] = mean, rstd
+    state[2, :Cin], state[3, :Cin] = gamma.double() * rstd, beta.double() - mean * gamma.double() * rstd
+    state = state.float().to(dev).contiguous()
+    yb = H.to_nhwc(y.to(dev))
+    reflect = pad_mode == REFLECT and P > 0
+    pad = P if reflect else 0
+    Hg, Wg = Hh + 2 * pad, Ww + 2 * pad
+    off = (ks - 1) if reflect else (ks - 1 - P)
+    packed, _, do = H.pack(w.to(dev))
+    dyb = H.to_nhwc(dy.to(dev))
+    gbuf = torch.full((Hg * Wg * Cs,), float("nan"), device=dev)
+    rows, rows_lo = lib.dip_conv_ntiles(Hg, Wg), lib.dip_conv_thin4_ntiles(Hg, Wg)
+    part = torch.full((rows * 2 * Cs,), float("nan"), device=dev)
+    part_lo = torch.full((rows_lo * 2 * Cs,), float("nan"), device=dev)
+    d = N.DipConvDesc(dyb.data_ptr(), Hh, Ww, round_up(Cout, 4), round_up(Cout, 4), N.DipTransform(None, None, 1.0),
+                      packed.data_ptr() + 4 * do, None, gbuf.data_ptr(), Hg, Wg, Cs, Cin, 0, ks, 1, N.PAD_ZERO, off,
+                      1, 0, None, 1, None)
+    assert lib.dip_conv_bnb_fusable(C.byref(d)) == 1
+    variant = lib.dip_conv_variant(C.byref(d))
+    c_lo = Cin - 128 if variant == 3 else 0
+    d.bnb_y, d.bnb_state, d.bnb_partials, d.bnb_partials_thin = yb.data_ptr(), state.data_ptr(), part.data_ptr(), part_lo.data_ptr()
+    d.bnb_Cy, d.bnb_Cs, d.bnb_pad, d.bnb_slope = Cs, Cs, pad, slope
+    N.check(lib.dip_conv_igemm(C.byref(d), st), "conv_igemm(dgrad + bnb)")
+    dgam, dbet, coef = (torch.full((n,), float("nan"), device=dev) for n in (Cin, Cin, 2 * Cs))
+    N.check(lib.dip_bn_bwd_finalize2(part.data_ptr(), rows, part_lo.data_ptr() if c_lo else None, rows_lo, c_lo, Cs, Cin,
+                                     Hh * Ww, dgam.data_ptr(), dbet.data_ptr(), coef.data_ptr(), st))
+    # the separate pass over the same gradient buffer
+    src = N.DipGradSrc(gbuf.data_ptr(), pad, 1 if pad else 0, Cs, 0)
+    nblk = lib.dip_bn_bwd_nblk(Hh, Ww, Cin)
+    part2 = torch.full((nblk * 2 * Cs,), float("nan"), device=dev)
+    N.check(lib.dip_bn_bwd_stats(C.byref(src), yb.data_ptr(), Hh, Ww, Cs, Cin, state.data_ptr(), Cs, slope, None, Cs,
+                                 part2.data_ptr(), nblk, st))
+    dgam2, dbet2, coef2 = (torch.full((n,), float("nan"), device=dev) for n in (Cin, Cin, 2 * Cs))
+    N.check(lib.dip_bn_bwd_finalize(part2.data_ptr(), nblk, Cs, Cin, Hh * Ww, dgam2.data_ptr(), dbet2.data_ptr(),
+                                    coef2.data_ptr(), st))
+    torch.cuda.synchronize()
+    assert variant == (3 if Cin == 132 else (0 if ks == 5 else 1)), variant
+    for a, b, name in ((dgam, dgam2, "dgamma"), (dbet, dbet2, "dbeta")):
+        scale = b.abs().max().item()
+        assert torch.allclose(a, b, rtol=0, atol=2e-6 * scale + 1e-9), (name, (a - b).abs().max().item(), scale)
+    cv, cv2 = coef.view(2, Cs)[:, :Cin], coef2.view(2, Cs)[:, :Cin]
+    assert torch.allclose(cv, cv2, rtol=0, atol=2e-6 * cv2.abs().max().item() + 1e-12)
+    _check("bnb_fused.dgamma", dgam, r64[0], r32[0], floor=5e-6)
+    _check("bnb_fused.dbeta", dbet, r64[1], r32[1], floor=5e-6)
+
+
 # ----------------------------------------------------------------------------- AvgPool2d(2, 2)
 @pytest.mark.parametrize("Cc,Hh,Ww", [(16, 8, 12), (128, 16, 32), (30, 10, 6)])
 def test_avgpool2_forward_stats_backward(dev, Cc, Hh, Ww):

@@ -145,19 +145,19 @@ def test_parity_mask_report_and_check_logic():
     m = z > 0
     m[0, 0, 0, 0], m[0, 3, 5, 7] = False, True                  # two flips inside the roundoff band
     rep = PT.mask_report({"bn": m}, {"bn": z})
-    assert rep["n"] == 2 and abs(rep["frac"] - 2 / z.numel()) < 1e-12 and rep["zrel"] < 1e-6
+    assert rep["n"] == 2 and rep["numel"] == z.numel() and abs(rep["frac"] - 2 / z.numel()) < 1e-12 and rep["zrel"] < 1e-6
     zr = torch.randn(1, 8, 512, 512)
     zr[0, 0, 0, 0] = 3e-7
     mr = zr > 0
     mr[0, 0, 0, 0] = False
     ok = {"worst": 0.5, "worst_zero": 0.1, "worst_rel": 2e-5, "worst_rel_key": "w", "worst_key": "w", "worst_unmasked": 1.0,
-          "worst_unmasked_key": "w", "n_zero": 0, "worst_rel_ref": 1e-5}
+          "worst_unmasked_key": "w", "n_zero": 0, "worst_rel_ref": 1e-5, "worst_rel_excess": 0.2}
     PT.check(ok, PT.mask_report({"bn": mr}, {"bn": zr}))
     mr[0, 1, 0, 0] = ~mr[0, 1, 0, 0]                            # a flip of an element that is NOT near zero
     with pytest.raises(AssertionError):
         PT.check(ok, PT.mask_report({"bn": mr}, {"bn": zr}))
     with pytest.raises(AssertionError):
-        PT.check(dict(ok, worst_rel=3e-4))
+        PT.check(dict(ok, worst_rel=3e-4, worst_rel_excess=3.0))
     # oracle_grads hands the pre-activations out
     spec = O.SkipSpec(4, 3, [8, 8], [8, 8], [4, 4], pad="reflection", upsample_mode="bilinear")
     sd = {k: torch.randn(s) * 0.2 for k, s in O.param_shapes(spec).items()}
