@@ -87,6 +87,51 @@ def gather_floats(v: float):
     return [float(x.item()) for x in xs]
 
 
+def parse_cpulist(text):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11] (the format of /sys/devices/system/node/node*/cpulist)."""
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def pin_to_gpu_numa(local_rank, world):
+    """N ranks on one host: keep each rank's Python thread (it enqueues ~160 launches per iteration, 2.4 ms of host
+    time) on the cores of its GPU's NUMA node and keep torch's intra-op pool at one thread, so that 8 ranks do not
+    migrate across sockets or oversubscribe each other.  Best effort (sysfs may be absent); returns a description."""
+    import glob
+    try:
+        import torch
+        if world > 1:
+            torch.set_num_threads(1)
+        cards = sorted(c for c in glob.glob("/sys/class/drm/card*/device")
+                       if os.path.exists(c + "/pp_dpm_sclk") or os.path.exists(c + "/numa_node"))
+        cards = [c for c in cards if open(c + "/vendor").read().strip() == "0x1002"] if cards else []
+        if local_rank >= len(cards):
+            return {"pinned": False, "why": "no sysfs entry for this GPU"}
+        node = int(open(cards[local_rank] + "/numa_node").read().strip())
+        if node < 0:
+            return {"pinned": False, "why": "numa_node = -1 (single-node host)"}
+        cpus = parse_cpulist(open(f"/sys/devices/system/node/node{node}/cpulist").read())
+        allowed = sorted(set(cpus) & set(os.sched_getaffinity(0)))
+        if not allowed:
+            return {"pinned": False, "why": "node's cores are outside this process' affinity mask"}
+        if world > 1:
+            # the ranks that share a node split its cores
+            same = [r for r in range(world) if r < len(cards) and
+                    open(cards[r] + "/numa_node").read().strip() == str(node)]
+            k, n = same.index(local_rank), len(same)
+            share = allowed[k * len(allowed) // n:(k + 1) * len(allowed) // n] or allowed
+            os.sched_setaffinity(0, share)
+            return {"pinned": True, "numa_node": node, "cores": len(share)}
+        return {"pinned": False, "numa_node": node, "why": "single rank: affinity left alone"}
+    except Exception as e:                   # never fail a benchmark over an affinity hint
+        return {"pinned": False, "why": f"{type(e).__name__}: {e}"}
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -202,7 +247,8 @@ class Fit:
 
         return closure
 
-    # the same arithmetic through the opt-in device helpers; replay-safe (in-place state only)
+    # the same arithmetic through the opt-in device helpers; replay-safe (in-place state only; the first call, which
+    # initialises the EMA, is an eager warm-up iteration, never the captured one)
     def _fused_closure(self, exp_weight=0.99):
         import torch
         from utils.reg_noise import RegNoise
@@ -214,6 +260,7 @@ class Fit:
         if ema:
             self.avg = torch.zeros_like(self.target)
         self.loss = torch.zeros((), device=self.dev)
+        first = [True]
 
         def closure():
             net_input = reg()
@@ -223,7 +270,11 @@ class Fit:
                 out = self.net(net_input)
                 total_loss = mse(self.down(out), self.target)
             if ema:
-                self.avg.mul_(exp_weight).add_(out.detach(), alpha=1 - exp_weight)
+                if first[0]:               # denoising.ipynb:214-215: out_avg = out on the first iteration
+                    self.avg.copy_(out.detach())
+                    first[0] = False
+                else:
+                    self.avg.mul_(exp_weight).add_(out.detach(), alpha=1 - exp_weight)
             total_loss.backward()
             self.loss.copy_(total_loss.detach())
             return total_loss
@@ -349,14 +400,165 @@ def dominant_ops(eng, fl):
     return out
 
 
+def hbm_ops(eng):
+    """Compulsory HBM bytes of every memory-bound launch of one iteration under THIS engine's fusion plan, as
+    {op name: bytes}: each operand tensor of the launch read once, each result written once (4 bytes per float,
+    channel strides as stored).  The MFMA convolutions are not in here (roofline / roofline_conv3x3_all); the thin
+    1x1 convs (<= 4 output channels) and the thin data-gradient columns are -- they stream a tensor for a few FLOP
+    per byte.  SURVEY.md 8(d) asks for this figure next to the 9.80 GB/iter of the unfused reference graph."""
+    from dip_native import round_up
+    B = {}
+    F4 = 4.0
+    n_arena = eng.n_arena
+    z = eng.H * eng.W
+    B["noise_axpy"] = F4 * 2 * z * eng.Cimg
+    B["nchw_to_nhwc"] = F4 * z * (eng.Cimg + round_up(eng.Cimg, 4))
+    B["pack_weights"] = F4 * (sum(r.Cout * r.Cin * r.ks * r.ks for r in eng.convs) + eng.packed.numel())
+    B["adam"] = F4 * 7 * n_arena
+    oc = eng.out_conv
+    B["loss_head_fwd"] = F4 * z * (eng.last_act.Cs + 2 * oc.Cout)
+    B["loss_head_bwd"] = F4 * z * (2 * oc.Cout + round_up(oc.Cout, 4))
+
+    def conv_io(r, x, pixels_out):
+        return F4 * (x.H * x.W * x.Cs + pixels_out * round_up(r.Cout, 4))
+
+    for i, s in enumerate(eng.sc):
+        st = s.st
+        H, W, xin = st["H"], st["W"], st["xin"]
+        acts = {"skip_bn": st.get("s_act"), "down_a_bn": st["d1"], "down_b_bn": st["d2"], "cat_bn": st["cat_act"],
+                "up_bn": st["u"], "up1_bn": st.get("u1")}
+        for key, a in acts.items():
+            if a is None:
+                continue
+            bn = a.bn
+            t = F4 * a.H * a.W * a.Cs
+            B[f"bnb_stats:{bn.name}"] = 2 * t                    # g (the ring of a padded g: < 2 %) + y
+            B[f"bnb_apply:{bn.name}"] = 3 * t                    # g + y -> dy  (in place after upb_stats: dz + y -> dz)
+        if s.ns:
+            B[f"conv_fwd:{s.skip_conv.name}"] = conv_io(s.skip_conv, xin, H * W)
+            B[f"dgrad+:{s.skip_conv.name}"] = F4 * H * W * (round_up(s.ns, 4) + 2 * xin.Cs)
+            B[f"wgrad:{s.skip_conv.name}"] = F4 * H * W * (xin.Cs + round_up(s.ns, 4))
+        deep, cat = st["deep"], st["cat_act"]
+        B[f"upcat:{s.cat_bn.name}"] = F4 * (H * W * (round_up(s.ns, 4) if s.ns else 0) + deep.H * deep.W * deep.Cs + H * W * cat.Cs)
+        B[f"upb_stats:{deep.bn.name}"] = F4 * (H * W * deep.C + 2 * deep.H * deep.W * deep.Cs)
+        if s.up.Cin > 128 and s.up.Cin <= 132:                   # thin columns of the 132-column data gradient
+            B[f"dgthin:{s.up.name}"] = F4 * H * W * (round_up(s.up.Cout, 4) + 4)
+    B[f"wgrad:{oc.name}"] = F4 * z * (eng.last_act.Cs + round_up(oc.Cout, 4))
+    return B
+
+
+def roofline_hbm(eng, per_op_ms):
+    """The memory-bound launches as a group: compulsory bytes of the fusion plan (hbm_ops) / their HIP-event time,
+    against 8 TB/s (spec) and the 6.29 TB/s copy ceiling (MI355X_MICROARCH.md), next to the traffic the PMC passes
+    measured for the same kernels (profiles/r03_pmc_traffic.json, taken on another box in another run)."""
+    B = hbm_ops(eng)
+    tot_b = tot_ms = 0.0
+    timed = {}
+    for k, b in B.items():
+        ms = per_op_ms.get(k)
+        if ms is None:                    # not a launch of this plan (statistics fused elsewhere), or issued outside the
+            continue                      # engine's op lists (noise, Adam, loss head, layout, weight packing)
+        timed[k] = (b, ms)
+        tot_b += b
+        tot_ms += ms
+    # launches that move data but have no compulsory count above (finalisations, slab / split-K reductions): their
+    # time counts against the group, their bytes are reported separately (they exist only because of the plan)
+    extra_ms = sum(ms for k, ms in per_op_ms.items() if k.startswith(("bn_fin:", "bnb_fin:", "wgred:")) or k.endswith("#finish"))
+    ach = tot_b / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+    untimed = sum(b for k, b in B.items() if k not in timed and ":" not in k)
+    pmc = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as f:
+            pmc = json.load(f).get("memory_bound_group")
+    except (OSError, ValueError):
+        pass
+    return {"bound": "hbm", "kernels": "BatchNorm backward, up-sample + concat and its adjoint, thin 1x1 convs / weight gradients, "
+                                       "thin data-gradient columns (per-launch HIP events, single stream)",
+            "achieved": round(ach, 3), "peak": 8.0, "unit": "TB/s", "frac": round(ach / 8.0, 4),
+            "frac_of_copy_ceiling_6.29": round(ach / 6.29, 4),
+            "compulsory_gb_per_step": round(tot_b / 1e9, 3), "ms_per_step": round(tot_ms, 3), "launches_per_step": len(timed),
+            "compulsory_gb_of_launches_outside_the_op_lists": round(untimed / 1e9, 3),
+            "finalise_and_reduction_launches_ms_per_step_not_included": round(extra_ms, 3),
+            "unfused_reference_graph_gb_per_step": 9.80 if (eng.H, eng.W) == (512, 512) else None,
+            "traffic": pmc["bytes_per_step"] if pmc else None,
+            "traffic_source": (pmc.get("source") if pmc else None)}
+
+
+def conv3x3_all(eng, per_op_ms, fl):
+    """roofline_conv3x3_all: EVERY launch that does 3x3-conv work -- forward, data and weight gradient, stride 1 and 2,
+    the thin columns, the N = 160 variant, and the split-K / slab reductions behind them -- against the algorithmic
+    FLOPs of the 3x3 layers (north_star: ">= 60 % of the fp32 MFMA roofline on the 3x3 conv layers")."""
+    f = ms = 0.0
+    n = 0
+    names3 = {r.name for r in eng.convs if r.ks == 3}
+    for k, t in per_op_ms.items():
+        base = k.split("#")[0]
+        kind, _, lname = base.partition(":")
+        if lname not in names3 or kind not in ("conv_fwd", "dgrad", "dgrad+", "dgthin", "wgrad", "wgred"):
+            continue
+        if "#" in k and k.split("#")[1] in ("thin4", "dma", "main", "finish"):
+            continue                      # the parts of a composite dispatch: `base` already carries the whole time
+        ms += t
+        n += 1
+        if kind in ("conv_fwd", "dgrad", "dgrad+", "wgrad"):
+            f += fl.get(base, 0.0)
+    ach = f / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    return {"bound": "mfma", "kernels": "every launch of the 3x3 layers: LDS-DMA / register-staged implicit GEMM (stride 1, "
+                                        "stride-2 modes), conv_thin4, conv_wgrad + slab reductions, split-K reductions",
+            "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "algorithmic_gflop_per_step": round(f / 1e9, 2),
+            "ms_per_step_serial": round(ms, 3), "launches_per_step": n, "traffic": None}
+
+
+def device_info(dev_index=0):
+    """Clocks / power cap / partition mode of the GPU this line was measured on (the pool has two speed classes of
+    boxes): sysfs + rocm-smi, best effort."""
+    import glob
+    info = {}
+
+    def rd(path):
+        try:
+            with open(path) as f:
+                return f.read().strip()
+        except OSError:
+            return None
+
+    cards = sorted(glob.glob("/sys/class/drm/card*/device"))
+    cards = [c for c in cards if rd(c + "/vendor") == "0x1002" and os.path.exists(c + "/pp_dpm_sclk")]
+    if dev_index < len(cards):
+        c = cards[dev_index]
+        for key, fn in (("sclk_levels", "pp_dpm_sclk"), ("mclk_levels", "pp_dpm_mclk"), ("fclk_levels", "pp_dpm_fclk"),
+                        ("perf_level", "power_dpm_force_performance_level"), ("compute_partition", "current_compute_partition"),
+                        ("memory_partition", "current_memory_partition"), ("vbios", "vbios_version"),
+                        ("numa_node", "numa_node")):
+            v = rd(f"{c}/{fn}")
+            if v is not None:
+                info[key] = " | ".join(v.split("\n")) if "\n" in v else v.replace("\n", " | ")
+        for hw in glob.glob(c + "/hwmon/hwmon*"):
+            cap, avg = rd(hw + "/power1_cap"), rd(hw + "/power1_average") or rd(hw + "/power1_input")
+            if cap:
+                info["power_cap_w"] = int(cap) / 1e6
+            if avg:
+                info["power_now_w"] = int(avg) / 1e6
+    try:
+        import torch
+        p = torch.cuda.get_device_properties(dev_index)
+        info["name"], info["cus"] = p.name, p.multi_processor_count
+        info["clock_rate_mhz"] = getattr(p, "clock_rate", 0) / 1e3 or None
+    except Exception:
+        pass
+    return info
+
+
 def pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
     (profiles/r0N_pmc_traffic.json, produced by tools/pmc_traffic.py); None when absent."""
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         try:
             with open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")) as f:
                 t = json.load(f)
             if t.get("kernel") == DOMINANT:
+                t["round"] = rnd
                 return t
         except (OSError, ValueError):
             pass
@@ -382,6 +584,8 @@ def roofline(eng, per_op_ms, with_pmc=True):
           "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
           "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
           "traffic": pmc["traffic_bytes_per_launch"] if pmc else None,
+          "traffic_source": (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes committed under profiles/ ({pmc.get('round', 'r02')}): "
+                             "another box, another run than this line") if pmc else None,
           "launches_per_step": n, "avg_launch_us": round(1e3 * tot_ms / max(n, 1), 1),
           "algorithmic_gflop_per_launch": round(tot_f / 1e9 / max(n, 1), 2),
           "algorithmic_bytes_per_launch": round(alg_bytes / max(n, 1)),
@@ -459,6 +663,8 @@ def cpu_baseline(seed=0, timed=5):
         times.append(time.time() - t0)
     tt = times[1:]
     return {"value": round(1.0 / float(np.median(tt)), 4), "unit": "it/s", "cores": cores, "kind": "port",
+            "note": "the unmodified reference (/root/reference) does not exist on the GPU box: this is oracle/dip_oracle.py, "
+                    "its restatement on torch.nn.functional, verified bitwise against the real reference in the build container",
             "host": f"{host_cpu_model()} ({os.cpu_count()} hardware threads)",
             "sample": f"default skip-net 512x512, 1 warm-up + {len(tt)} timed Adam iterations of the CPU oracle "
                       f"(torch {torch.__version__} CPU, {cores} threads), median; min/max "
@@ -554,6 +760,8 @@ def main():
             dist.barrier()
 
     if SELFTEST:
+        affinity = pin_to_gpu_numa(local, world)         # (exercised on CPU: no GPU sysfs entry -> left alone)
+        assert isinstance(affinity, dict) and "pinned" in affinity
         t = selftest_rank(args, rank, world, barrier)
         per_rank = gather_floats(args.steps / t)
         tmax = reduce_max_time(t)
@@ -571,6 +779,7 @@ def main():
         raise SystemExit(f"bench.py: rank {rank} wants GPU {local} but only {torch.cuda.device_count()} are visible")
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
+    affinity = pin_to_gpu_numa(local, world)
 
     # one independent image (x --instances) per rank; image index = global fit index = seed
     n_inst = max(args.instances, 1)
@@ -602,9 +811,11 @@ def main():
 
     if rank == 0:
         eng = fits[0].engine
-        rl = rw = None
+        rl = rw = rh = r3 = None
         if not args.no_roofline:
             rl, rw = roofline(eng, per_op, with_pmc=(args.config == "default"))
+            rh = roofline_hbm(eng, per_op)
+            r3 = conv3x3_all(eng, per_op, conv_flops(eng))
             if args.dump_ops:
                 fl = conv_flops(eng)
                 with open(args.dump_ops, "w") as f:
@@ -632,8 +843,11 @@ def main():
                        "images": world * n_inst, "closure": args.closure, "hipgraph": graphed,
                        "kernel_launches_per_iteration": n_launch, "final_loss": round(final_loss, 6)},
             "per_rank_it_s": [round(v, 3) for v in per_rank],
-            "roofline": rl, "roofline_wgrad": rw, "cpu_baseline": cb, "eager_notebook": eager,
+            "roofline": rl, "roofline_wgrad": rw, "roofline_conv3x3_all": r3, "roofline_hbm": rh,
+            "cpu_baseline": cb, "eager_notebook": eager, "device": device_info(local), "host_affinity_rank0": affinity,
         }
+        line["config"]["reported_mode"] = ("hipGraph replays" if graphed else "eager launches (main + side + bulk HIP stream)") + \
+            " of the iteration with the fused closure (RegNoise + MSEHead + in-place EMA)"
         if len(runs) > 1:
             o = runs[1]
             line["other_mode"] = {"hipgraph": o["graphed"], "it_s": round(world * len(fits) * args.steps / o["t"], 3),

@@ -1,10 +1,11 @@
 """CPU arms of the BASELINE.json configs[1] end-quality check, produced by the REAL reference.
 
-    python oracle/make_end_quality_golden.py <size> <iters> <threads>[:<perturb>] [<threads>[:<perturb>] ...]
+    python oracle/make_end_quality_golden.py <size> <iters> <threads>[:<perturb>[:<grad_noise>]] [...]
 
 For every arm -- a thread count (= another summation order inside ATen's reductions, nothing else) and an
-optional one-ulp perturbation of ONE weight (tests/end_quality_cpu.perturb_one_weight: a sample of the chaotic
-run-to-run spread) -- it runs the
+optional one-ulp perturbation of ONE weight (tests/end_quality_cpu.perturb_one_weight) and an optional relative
+perturbation of EVERY gradient element at every step (grad_noise = 1e-6: what another, equally correct fp32
+summation order does to a gradient; tests/end_quality_cpu.GRAD_NOISE) -- it runs the
 reference's own `get_net` (models/__init__.py:8) + `get_noise` (utils/common_utils.py:127) +
 `optimize('adam', ...)` (utils/common_utils.py:198-232) on the denoising notebook's closure
 (denoising.ipynb:204-221: reg-noise, forward, EMA of the output, MSE, backward) at <size>^2 for
@@ -30,15 +31,19 @@ import _refload  # noqa: E402
 
 def main():
     size, iters = int(sys.argv[1]), int(sys.argv[2])
-    specs = [tuple(int(v) for v in (t.split(":") + ["0"])[:2]) for t in sys.argv[3:]] or [(os.cpu_count(), 0)]
+    specs = []
+    for t in sys.argv[3:] or [str(os.cpu_count())]:
+        f = (t.split(":") + ["0", "0"])[:3]
+        specs.append((int(f[0]), int(f[1]), float(f[2])))
     assert _refload.available(), "needs the reference checkout"
     RM = _refload.load_ref_models()
     RU = _refload.load_ref_common_utils()
     import end_quality_cpu as E     # problem(), run_fit(): shared with the GPU arm
     path = os.path.join(ROOT, "tests", "golden", f"end_quality_{size}_{iters}.json")
     arms = json.load(open(path))["cpu_arms"] if os.path.exists(path) else []
-    for th, perturb in specs:
+    for th, perturb, gnoise in specs:
         torch.set_num_threads(th)
+        E.GRAD_NOISE = gnoise
         torch.manual_seed(0)
         net = RM.get_net(32, 'skip', 'reflection', skip_n33d=128, skip_n33u=128, skip_n11=4, num_scales=5,
                          upsample_mode='bilinear')
@@ -46,15 +51,16 @@ def main():
         z = RU.get_noise(32, 'noise', (size, size))
         clean, noisy = E.problem(size)
         res = E.run_fit(net, lambda c: RU.optimize('adam', RU.get_params('net', net, z), c, 0.01, iters),
-                        z, noisy, clean, iters, "cpu")
-        res["threads"], res["perturb"] = th, perturb
+                        z, noisy, clean, iters, "cpu", params=list(net.parameters()))
+        res["threads"], res["perturb"], res["grad_noise"] = th, perturb, gnoise
         print(json.dumps(res), flush=True)
         arms = json.load(open(path))["cpu_arms"] if os.path.exists(path) else arms     # (another generator may run)
-        arms = [a for a in arms if (a["threads"], a.get("perturb", 0)) != (th, perturb)] + [res]
+        arms = [a for a in arms if (a["threads"], a.get("perturb", 0), a.get("grad_noise", 0.0)) != (th, perturb, gnoise)] + [res]
         with open(path, "w") as f:
             json.dump({"size": size, "iters": iters, "sigma": E.SIGMA, "reg_noise_std": E.REG, "lr": 0.01,
                        "source": "real reference (/root/reference) on torch CPU fp32, oracle/make_end_quality_golden.py",
-                       "cpu_arms": sorted(arms, key=lambda a: (a.get("perturb", 0), a["threads"]))}, f, indent=1)
+                       "cpu_arms": sorted(arms, key=lambda a: (a.get("grad_noise", 0.0), a.get("perturb", 0), a["threads"]))},
+                      f, indent=1)
 
 
 if __name__ == "__main__":

@@ -55,10 +55,14 @@ def build(size=None):
     return net, z
 
 
-def run_fit(net_call, params_step, z, noisy, clean, iters, device, exp_weight=0.99):
+GRAD_NOISE = float(os.environ.get("EQ_GRAD_NOISE", "0"))     # relative gradient perturbation (tools: noise-floor experiment)
+
+
+def run_fit(net_call, params_step, z, noisy, clean, iters, device, exp_weight=0.99, params=None):
     """The notebook closure with the reg-noise drawn from a host generator (same perturbations in
     every arm).  net_call(x) -> out; params_step(closure) runs the optimisation loop."""
     gen = torch.Generator().manual_seed(77)
+    ngen = torch.Generator().manual_seed(78)
     zt = z.to(device)
     tgt = torch.from_numpy(noisy)[None].to(device)
     mse = torch.nn.MSELoss()
@@ -70,6 +74,10 @@ def run_fit(net_call, params_step, z, noisy, clean, iters, device, exp_weight=0.
         st["avg"] = out.detach() if st["avg"] is None else st["avg"] * exp_weight + out.detach() * (1 - exp_weight)
         loss = mse(out, tgt)
         loss.backward()
+        if GRAD_NOISE > 0 and params is not None:     # diagnostic: a multiplicative roundoff-like error on every gradient element
+            for p in params:
+                if p.grad is not None:
+                    p.grad.mul_(1.0 + GRAD_NOISE * torch.randn(p.grad.shape, generator=ngen).to(p.grad.device))
         st["i"] += 1
         st["loss"] = loss.detach()
         if st["i"] > iters - TAIL:              # single-iteration PSNR jitters by ~1 dB: average the tail
@@ -100,7 +108,9 @@ def main():
     perturb_one_weight(net.parameters(), perturb)
     sd = {k: v.detach().clone() for k, v in net.state_dict().items() if k in O.param_shapes(O.default_spec())}
     onet = O.OracleNet(O.default_spec(), sd)
-    res = run_fit(onet, lambda c: O.optimize_adam(onet.params, c, 0.01, iters), z, noisy, clean, iters, "cpu")
+    res = run_fit(onet, lambda c: O.optimize_adam(onet.params, c, 0.01, iters), z, noisy, clean, iters, "cpu",
+                  params=list(onet.params))
+    res["grad_noise"] = GRAD_NOISE
     res["threads"], res["perturb"] = threads, perturb
     with open(out, "w") as f:
         json.dump(res, f)

@@ -386,6 +386,34 @@ def test_lbfgs_on_the_arena(dev):
     assert len(hist) == len(ref_hist)
     for a, b in zip(hist[:4], ref_hist[:4]):
         assert abs(a - b) <= 2e-3 * abs(b), (hist, ref_hist)
+    # the optimiser's arithmetic in isolation: ArenaLBFGS and torch.optim.LBFGS driving the SAME (deterministic) HIP net
+    # from the same start -- the parameter vectors after max_iter = 8 steps agree to fp32 roundoff
+    finals = []
+    for kind in ("arena", "torch"):
+        n_ = _small_net(8)
+        n_.load_state_dict(sd, strict=False)
+        n_ = n_.to(dev)
+        ps = get_params("net", n_, zg)
+        o_ = ArenaLBFGS(ps, max_iter=8, lr=0.05, tolerance_grad=-1, tolerance_change=-1) if kind == "arena" else \
+            torch.optim.LBFGS(ps, max_iter=8, lr=0.05, tolerance_grad=-1, tolerance_change=-1)
+        losses = []
+
+        def c_():
+            o_.zero_grad()
+            l = F.mse_loss(n_(zg), ig)
+            l.backward()
+            losses.append(l.item())
+            return l
+
+        o_.step(c_)
+        torch.cuda.synchronize()
+        finals.append((torch.cat([p.detach().reshape(-1) for p in n_.parameters()]).cpu().double(), losses))
+    (pa, la), (pt, lt) = finals
+    assert len(la) == len(lt) == 8 and all(abs(a - b) <= 1e-5 * abs(b) for a, b in zip(la, lt)), (la, lt)
+    rel = (pa - pt).norm().item() / pt.norm().item()
+    moved = (pt - torch.cat([v.reshape(-1) for v in sd.values()]).double()).norm().item() / pt.norm().item()
+    print(f"ArenaLBFGS vs torch.optim.LBFGS on the HIP net: |dp|/|p| = {rel:.2e} after 8 steps (the steps moved p by {moved:.2e})")
+    assert rel <= 1e-5 and rel <= 1e-2 * moved, (rel, moved)
     # the full optimize('LBFGS') call
     net2 = _small_net(8).to(dev)
     rec = []

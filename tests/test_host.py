@@ -276,6 +276,16 @@ def _bench_selftest(cmd, extra_env=None):
     return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
 
 
+def test_bench_rank_affinity_helpers():
+    """bench.py's N-rank host hygiene: cpulist parsing and a pin attempt that must never raise."""
+    import bench
+    assert bench.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and bench.parse_cpulist("5") == [5]
+    before = os.sched_getaffinity(0)
+    r = bench.pin_to_gpu_numa(0, 1)
+    assert isinstance(r, dict) and r["pinned"] is False and os.sched_getaffinity(0) == before
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+
+
 def test_bench_gpus_2_starts_two_ranks():
     """`python bench.py --gpus 2` itself starts 2 worker processes (one per GPU), which meet over gloo
     (barrier, per-rank gather, max-over-ranks time) and print ONE JSON line with n_gpus == 2.

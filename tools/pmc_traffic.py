@@ -32,6 +32,30 @@ def calib(per, known_bytes):
     return ratios.most_common(1)[0][0], dict(ratios)
 
 
+# the launches bench.py's roofline_hbm object counts (hbm_ops): BatchNorm backward, up-sample + concat and its
+# adjoint, thin 1x1 convs / weight gradients, thin data-gradient columns
+MEM_GROUP = ("bn_bwd_stats_kernel", "bn_bwd_apply_src_kernel", "bn_bwd_apply_kernel", "upcat_fwd_kernel",
+             "upsample_bwd_stats_kernel", "thin1x1_wgrad_kernel", "conv_thin4_kernel", "conv_igemm_dma_kernel<1, 32")
+
+
+def group_bytes(fetch, write, ff, wf):
+    steps = sum(1 for k, _ in fetch.values() if "adam_kernel" in k)
+    per = collections.OrderedDict()
+    for tag, table, fac in (("fetch", fetch, ff), ("write", write, wf)):
+        for k, v in table.values():
+            for pat in MEM_GROUP:
+                if pat in k:
+                    e = per.setdefault(pat, {"fetch": 0.0, "write": 0.0, "launches": 0})
+                    e[tag] += v * 1024 * fac
+                    if tag == "fetch":
+                        e["launches"] += 1
+    tot = sum(e["fetch"] + e["write"] for e in per.values())
+    return {"bytes_per_step": round(tot / max(steps, 1)), "steps_in_pass": steps,
+            "per_kernel_bytes_per_step": {k: {"fetch": round(e["fetch"] / max(steps, 1)), "write": round(e["write"] / max(steps, 1)),
+                                              "launches_per_step": round(e["launches"] / max(steps, 1), 1)} for k, e in per.items()},
+            "source": "same passes; FETCH_SIZE x correction + WRITE_SIZE over the launches of the listed kernels"}
+
+
 def main():
     fetch, write = load(sys.argv[1]), load(sys.argv[2])
     T = 512 * 512 * 128 * 4
@@ -47,6 +71,7 @@ def main():
         "correction": {"FETCH_SIZE": ff, "WRITE_SIZE": wf,
                        "calibrated_on": "bn_bwd_apply_src_kernel, scale 0, C=128: reads 2 x 128 MiB, writes 128 MiB",
                        "observed_known_over_reported": {"FETCH_SIZE": fr, "WRITE_SIZE": wr}},
+        "memory_bound_group": group_bytes(fetch, write, ff, wf),
         "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python bench.py --steps 3 --warmup 2 "
                   "--no-cpu-baseline --no-roofline (tools/gpu_round.sh, DO_PMC=1); all launches of the kernel in the run",
     }
