@@ -139,11 +139,20 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d
             dreg[i] = v;
         }
     };
-    auto commit = [&]() __attribute__((always_inline)) {                  // registers -> LDS, producer BatchNorm+LeakyReLU on the way
+    // Compact halo of the packed tail phase of the SLIDE kernel: [pixel][4 channels] with a row pitch of PKP = 19
+    // pixels.  In the 32-channel layout the packed A operand (lane = (tap, channel)) reads addresses
+    // (ky*HTW + kx)*32 + ch: all 32 lanes of a half-wave in banks 0..3 (8-way conflict); with 4-float pixels and pitch
+    // 19 the eight taps land on banks 0, 4, ..., 28.  (Measured: the phase is bound by its per-tile staging latency, not
+    // by LDS -- 62 of the 780 us of the 132 -> 128 layer at 512^2 with either layout; another 70 us of that layer's
+    // excess over 128 -> 128 is the 528-byte pixel pitch of the 132-channel tensor, whose 128-byte channel slices
+    // straddle cache lines.)
+    constexpr int PKP = C::HTW + 1;
+    auto commit = [&](auto compactc) __attribute__((always_inline)) {     // registers -> LDS, producer BatchNorm+LeakyReLU on the way
+        constexpr bool COMPACT = decltype(compactc)::value;
 #pragma unroll
         for (int i = 0; i < C::U_SLOTS; ++i) {
             const int f = tid + i * 256;
-            if (f < C::NPIX * (C::CW / 4)) {
+            if (f < C::NPIX * (C::CW / 4) && (!COMPACT || c4 == 0)) {
                 f32x4 v = ureg[i];
                 if (has_tr) {
 #pragma unroll
@@ -152,7 +161,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = (v[e] == PADV) ? 0.f : v[e];
                 }
-                *reinterpret_cast<f32x4*>(Us + f * 4) = v;
+                if constexpr (COMPACT) {
+                    const int hp = f / (C::CW / 4);
+                    const int hr = hp / C::HTW, hc = hp - hr * C::HTW;
+                    *reinterpret_cast<f32x4*>(Us + (hr * PKP + hc) * 4) = v;
+                } else {
+                    *reinterpret_cast<f32x4*>(Us + f * 4) = v;
+                }
             }
         }
 #pragma unroll
@@ -202,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d
     if (PF && first < ntiles) fetch(first);
     for (int tile = first; tile < ntiles; tile += step) {
         __syncthreads();                   // every wave is done with the previous tile
-        if constexpr (PF) commit(); else stage_direct(tile);
+        if constexpr (PF) commit(std::integral_constant<bool, SLIDE && PACKED>{}); else stage_direct(tile);
         __syncthreads();
         if (PF && tile + step < ntiles) fetch(tile + step);
         if (wave_active) {
@@ -215,15 +230,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d
                 constexpr int NKY = NT / 3;
                 const int ky0 = tap0 / 3;
                 if constexpr (PACKED) {
+                    // (tap, channel)-packed rows on the compact halo (see commit): lane l31 = tap * 4 + channel
+                    const int ptap = l31 >> 2, pch = l31 & 3;
+                    const int po0 = ((ptap / 3) * PKP + (ptap % 3)) * 4 + pch, po1 = (2 * PKP + 2) * 4 + pch;
 #pragma unroll 2
                     for (int s = wk; s < C::NPX / 2; s += kw) {
                         const int px = 2 * s + half;
                         const int r = px >> 4, c = px & 15;
                         const float b = Ds[px * 128 + wcol * 32 + l31];
-                        bsum += b;
-                        const float* ub = Us + (r * C::HTW + c) * C::CW;
-                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ub[aoff0], b, acc[0], 0, 0, 0);
-                        acc[NT > 1 ? 1 : 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ub[aoff1], b, acc[NT > 1 ? 1 : 0], 0, 0, 0);
+                        const float* ub = Us + (r * PKP + c) * 4;
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ub[po0], b, acc[0], 0, 0, 0);
+                        acc[NT > 1 ? 1 : 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ub[po1], b, acc[NT > 1 ? 1 : 0], 0, 0, 0);
                     }
                 } else {
 #pragma unroll 1
