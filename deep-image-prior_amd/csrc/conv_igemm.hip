@@ -554,9 +554,12 @@ extern "C" int dip_conv_phase_eligible(const DipConvDesc* dp);
 extern "C" int dip_conv_igemm_dma(const DipConvDesc* dp, int ksplit, void* stream);
 extern "C" int dip_conv_igemm_dma_cols(const DipConvDesc* dp, int n_base, void* stream);
 extern "C" int dip_conv_thin4(const DipConvDesc* dp, int ncols, void* stream);
+extern "C" int dip_conv1x1_res_eligible(const DipConvDesc* dp);
+extern "C" int dip_conv1x1_res(const DipConvDesc* dp, void* stream);
 
 extern "C" int dip_conv_variant(const DipConvDesc* dp) {
     const DipConvDesc& d = *dp;
+    if (dip_conv1x1_res_eligible(dp)) return 6;
     static const bool no_dma = getenv("DIP_CONV_NO_DMA") != nullptr;      // A/B switches for profiling
     static const bool no_extra = getenv("DIP_CONV_NO_EXTRA") != nullptr;
     const int CoutP = dip_round_up(d.Cout, 32);
@@ -579,7 +582,7 @@ extern "C" int dip_conv_bnb_fusable(const DipConvDesc* dp) {
     static const bool off = getenv("DIP_NO_BNB_FUSE") != nullptr;
     if (off || dp->ksplit > 1) return 0;
     const int v = dip_conv_variant(dp);
-    return (v == 0 || v == 1 || v == 3) ? 1 : 0;
+    return (v == 0 || v == 1 || v == 3 || v == 6) ? 1 : 0;
 }
 
 // second half of a split-K dispatch: sums the d.ksplit workspace slices in a fixed order, adds the
@@ -622,6 +625,7 @@ extern "C" int dip_conv_igemm(const DipConvDesc* dp, void* stream) {
         if (rc) return rc;
         return dip_conv_igemm_dma_cols(dp, ncols, stream);
     }
+    if (variant == 6) return dip_conv1x1_res(dp, stream);
     if (variant == 1 || variant == 4 || variant == 5) rc = dip_conv_igemm_dma(dp, ksplit, stream);
     else if (d.ks == 1 && d.stride == 1) rc = launch_bn<1, 1, 32>(d, st, ksplit, d.ws);
     else if (d.ks == 3 && d.stride == 1) rc = launch_bn<3, 1, 32>(d, st, ksplit, d.ws);

@@ -149,7 +149,8 @@ int dip_conv_plan_dil2(int Hout, int Wout, int Cin, int Cout, int ks, int* kspli
  * (3x3, 129..160 output channels, split-K), 3 = conv_thin4_kernel (columns 0..Cout-129 on the vector ALU)
  * + conv_igemm_dma_kernel (the other 128 columns): 3x3 data gradients towards a 132-channel tensor,
  * 4 = conv_igemm_dma_kernel in phase mode (dil == 2: data gradient of a stride-2 3x3 convolution),
- * 5 = conv_igemm_dma_kernel in strided-forward mode (3x3, stride 2: the input split by pixel parity) */
+ * 5 = conv_igemm_dma_kernel in strided-forward mode (3x3, stride 2: the input split by pixel parity),
+ * 6 = conv1x1_res_kernel (1x1, 128 -> 97..128 channels, >= 256x256 pixels: persistent workgroups, weights in registers) */
 int dip_conv_variant(const DipConvDesc* d);
 /* The two launches behind variant 3, exported so that a caller can put them on DIFFERENT streams (they
  * write disjoint columns of the same output): columns [0, ncols) (ncols = Cout - 128 <= 4) of a 3x3

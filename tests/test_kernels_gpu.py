@@ -65,6 +65,9 @@ CONV_CASES = [
     (4, 32, 3, 1, REFLECT, 19, 27, True),
     (1, 128, 5, 2, ZERO, 40, 36, False),         # inpainting 'library': 1 input plane, 5x5 stride 2
     (3, 200, 3, 1, ZERO, 16, 16, True),          # 50 output groups: 5 pixel rows per block step (not a power of two)
+    # >= 65536 pixels, 128 input channels, 1x1: the weights-resident persistent kernel (conv1x1_res.hip)
+    (128, 128, 1, 1, REFLECT, 256, 256, True),
+    (128, 100, 1, 1, REFLECT, 128, 512, False),  # 100 output columns (CoutP = 128, 28 idle), no transform
 ]
 
 
@@ -335,6 +338,7 @@ def test_bn_forward_backward_chain(dev, Cc, Hh, Ww, P, slope):
     (128, 128, 3, 24, 40, 0.2, "reflect"),      # LDS-DMA kernel, padded domain with a reflected ring, ragged tiles
     (132, 128, 3, 16, 32, 1.0, "reflect"),      # 132 columns: conv_thin4 (4 columns) + 128 columns, no activation (concat BN)
     (128, 128, 1, 16, 48, 0.2, "reflect"),      # 1x1 (no padding)
+    (128, 128, 1, 256, 256, 0.2, "reflect"),    # 1x1 at >= 65536 pixels: the weights-resident kernel's epilogue
     (64, 96, 3, 19, 23, 0.2, "zero"),           # zero padding, 64-column block
     (128, 8, 1, 16, 16, 0.2, "reflect"),        # data gradient of a thin conv (K = 8), like the RGB output conv
     (32, 32, 5, 12, 20, 0.2, "reflect")])       # 5x5: the register-staged kernel's epilogue
@@ -405,7 +409,7 @@ def test_bn_backward_statistics_fused_into_the_data_gradient(dev, Cin, Cout, ks,
     N.check(lib.dip_bn_bwd_finalize(part2.data_ptr(), nblk, Cs, Cin, Hh * Ww, dgam2.data_ptr(), dbet2.data_ptr(),
                                     coef2.data_ptr(), st))
     torch.cuda.synchronize()
-    assert variant == (3 if Cin == 132 else (0 if ks == 5 else 1)), variant
+    assert variant == (3 if Cin == 132 else (0 if ks == 5 else (6 if Hh * Ww >= 65536 else 1))), variant
     for a, b, name in ((dgam, dgam2, "dgamma"), (dbet, dbet2, "dbeta")):
         scale = b.abs().max().item()
         assert torch.allclose(a, b, rtol=0, atol=2e-6 * scale + 1e-9), (name, (a - b).abs().max().item(), scale)
