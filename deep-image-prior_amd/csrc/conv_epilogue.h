@@ -127,28 +127,34 @@ __device__ __forceinline__ void dip_conv_epilogue_bnb(const DipConvDesc& d, f32x
         const float mean = d.bnb_state[nn], rstd = d.bnb_state[Cs + nn], sa = d.bnb_state[2 * Cs + nn],
                     sb = d.bnb_state[3 * Cs + nn];
         float s1 = 0.f, s2 = 0.f;
+        // all loads of this column block (MS accumulators x 16 pixels) are issued before the first use: the K loop's
+        // registers are dead by now, and one memory round trip per accumulator was measured at +100 us on the 256^2
+        // data gradients of a slow-class box (a tile's epilogue is on the critical path of its workgroup slot)
+        float yv[C::MS][16];
+        bool ok[C::MS][16];
 #pragma unroll
         for (int ms = 0; ms < C::MS; ++ms) {
             const int sub = wm * C::MS + ms;
-            float yv[16];
-            bool ok[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                ok[r] = nv && dip_epi_valid(e, sub, r, half);
+                ok[ms][r] = nv && dip_epi_valid(e, sub, r, half);
                 const int oy = e.oy0 + 2 * sub + (r >> 3), ox = e.ox0 + (r & 3) + 8 * ((r >> 2) & 1) + 4 * half;
-                const int iy = ok[r] ? dip_reflect(oy - pad, Hi) : 0, ix = ok[r] ? dip_reflect(ox - pad, Wi) : 0;
-                yv[r] = d.bnb_y[((size_t)iy * Wi + ix) * d.bnb_Cy + nn];
+                const int iy = ok[ms][r] ? dip_reflect(oy - pad, Hi) : 0, ix = ok[ms][r] ? dip_reflect(ox - pad, Wi) : 0;
+                yv[ms][r] = d.bnb_y[((size_t)iy * Wi + ix) * d.bnb_Cy + nn];
             }
+        }
+#pragma unroll
+        for (int ms = 0; ms < C::MS; ++ms) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float z = fmaf(sa, yv[r], sb);
-                const float gm = ok[r] ? dip_mul_rn(acc[ms][ns][r], dip_act_grad(z, d.bnb_slope)) : 0.f;
-                const float xh = (yv[r] - mean) * rstd;
+                const float z = fmaf(sa, yv[ms][r], sb);
+                const float gm = ok[ms][r] ? dip_mul_rn(acc[ms][ns][r], dip_act_grad(z, d.bnb_slope)) : 0.f;
+                const float xh = (yv[ms][r] - mean) * rstd;
                 s1 += gm;
                 s2 = fmaf(gm, xh, s2);
             }
-            __builtin_amdgcn_sched_barrier(0);      // one accumulator's 16 loads in flight at a time (register budget)
         }
+        __builtin_amdgcn_sched_barrier(0);          // one column block at a time (register budget)
         s1 += __shfl_xor(s1, 32);
         s2 += __shfl_xor(s2, 32);
         if (half == 0) {

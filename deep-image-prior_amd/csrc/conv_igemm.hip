@@ -579,8 +579,7 @@ extern "C" int dip_conv_variant(const DipConvDesc* dp) {
 // fused BatchNorm-backward partials (bnb_* fields) ride in the shared one-pass epilogue (conv_epilogue.h):
 // every one-pass variant except the phase mode (4 workgroups per tile, interleaved pixels) and the N = 160 variant
 extern "C" int dip_conv_bnb_fusable(const DipConvDesc* dp) {
-    static const bool off = getenv("DIP_NO_BNB_FUSE") != nullptr;
-    if (off || dp->ksplit > 1) return 0;
+    if (dp->ksplit > 1) return 0;
     const int v = dip_conv_variant(dp);
     return (v == 0 || v == 1 || v == 3 || v == 6) ? 1 : 0;
 }

@@ -117,6 +117,11 @@ class SkipEngine:
         # than the ~8 us launch it would overlap)
         self.side_min_pixels = int(os.environ.get("DIP_SIDE_MIN_PIXELS", "0"))
         self._fwd_side, self._deferred, self._entered_defer_scale, self._fused_bnb = set(), [], False, {}
+        # BatchNorm-backward statistics in the epilogue of the data-gradient launch (DipConvDesc.bnb_*) instead of a pass
+        # of their own: 18 launches and one pass over g fewer, but measured (round 3) as a wash -- the epilogue's
+        # per-lane reads of y cost the big launches 35..75 us each, as much as the streaming statistics kernels they
+        # replace (+0.5 % on a fast-class box, -1.5 % on a slow-class one) -- so it is opt-in
+        self.fuse_bnb = os.environ.get("DIP_BNB_FUSE", "0") == "1"
         self.device = None
         self.shape_key = None
         self.lib = None
@@ -509,7 +514,7 @@ class SkipEngine:
                           ksplit, (None if sizing else _ptr(self.ws_scratch)) if ksplit > 1 else None)
         variant = self.lib.dip_conv_variant(C.byref(d))
         fused = None
-        if fuse_bn and x.bn is not None and self.lib.dip_conv_bnb_fusable(C.byref(d)):
+        if fuse_bn and self.fuse_bnb and x.bn is not None and self.lib.dip_conv_bnb_fusable(C.byref(d)):
             bn = x.bn
             rows = self.lib.dip_conv_ntiles(Hg, Wg)
             c_lo = (r.Cin - 128) if variant == 3 else 0          # columns of the conv_thin4 launch (always 4 here: % 4)

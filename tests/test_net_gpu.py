@@ -223,6 +223,37 @@ def test_against_oracle_fresh_seed(dev, hw, mode, nskip):
     assert psnr >= 100.0 and rel <= 1e-5 and worst <= 1.0, (psnr, rel, worst, wk)
 
 
+def test_fused_batchnorm_backward_statistics_engine_path(dev):
+    """Opt-in engine path (DIP_BNB_FUSE=1 / SkipEngine.fuse_bnb): BatchNorm-backward statistics computed in the
+    epilogue of the data-gradient launches (DipConvDesc.bnb_*: LDS-DMA conv kernel, conv_thin4 for the 4 thin columns
+    of the 132-column gradients, the weights-resident 1x1 kernel) instead of dip_bn_bwd_stats -- same gradients as the
+    default path up to the summation order of the statistics."""
+    from models.skip import skip
+    torch.manual_seed(5)
+    hw = (256, 256)              # >= 65536 pixels: one-pass launches at the top scale, the 1x1 kernel included
+    kw = dict(num_channels_down=[128, 128], num_channels_up=[128, 128], num_channels_skip=[4, 4],
+              upsample_mode="bilinear", need_sigmoid=True, need_bias=True, pad="reflection")
+    z = (torch.rand(1, 16, *hw) * 0.1).to(dev)
+    target = torch.rand(1, 3, *hw).to(dev)
+    grads, counts = [], []
+    for fuse in (False, True):
+        torch.manual_seed(6)
+        net = skip(16, 3, **kw)
+        eng = net.__dict__["_dip_engine"]
+        eng.fuse_bnb = fuse
+        net = net.to(dev)
+        loss = torch.nn.functional.mse_loss(net(z), target)
+        loss.backward()
+        torch.cuda.synchronize()
+        grads.append({k: p.grad.detach().clone() for k, p in net.named_parameters()})
+        counts.append(sum(n.startswith("bnb_stats:") for _, _, n in eng.bwd_ops))
+    assert counts[1] < counts[0], counts
+    gmax = max(g.double().norm().item() for g in grads[0].values())
+    for k in grads[0]:
+        a, b = grads[0][k].double(), grads[1][k].double()
+        assert (a - b).norm().item() <= 2e-5 * a.norm().item() + 1e-7 * gmax, (k, (a - b).norm().item(), a.norm().item())
+
+
 def test_super_resolution_closure_against_oracle(dev):
     """The SR notebook's loss path (super-resolution.ipynb:169-186): net -> Downsampler(3, 4,
     'lanczos2', phase=0.5, preserve_size=True) -> MSE against the LR image, + tv_loss; iteration-1

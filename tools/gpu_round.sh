@@ -21,10 +21,12 @@ else
 TMO=600 run python __graft_entry__.py smoke
 TMO=1500 run python -m pytest tests/test_fullsize_gpu.py -q -m gpu --no-header -p no:cacheprovider -s
 TMO=900 run python -m pytest tests/test_closure_gpu.py tests/test_monitor_gpu.py -q -m gpu --no-header -p no:cacheprovider -s
-TMO=1500 run python -m pytest tests/test_net_gpu.py -q -m gpu --no-header -p no:cacheprovider -s
-for grp in "conv_forward" "conv_dgrad" "conv_wgrad" "mfma or bn_forward or upcat or avgpool or layout or adam or noise or lanczos"; do
-  TMO=900 run python -m pytest tests/test_kernels_gpu.py -q -m gpu -k "$grp" --no-header -p no:cacheprovider -s
-done
+if [ "${EQ:-1}" = "1" ]; then
+TMO=2400 run python -m pytest tests/test_net_gpu.py -q -m gpu --no-header -p no:cacheprovider -s
+else
+TMO=1500 run python -m pytest tests/test_net_gpu.py -q -m gpu -k "not end_quality" --no-header -p no:cacheprovider -s
+fi
+TMO=900 run python -m pytest tests/test_kernels_gpu.py -q -m gpu --no-header -p no:cacheprovider
 fi
 fi
 if [ "${SKIP_BENCH:-0}" != "1" ]; then
@@ -47,6 +49,7 @@ if [ "${DO_PROF:-0}" = "1" ]; then
   if [ "${DO_PROF2:-0}" = "1" ]; then
   ( cd /tmp && TMO=900 run rocprofv3 --kernel-trace --stats -d $ROOTD/gpurun_out/prof2 -o trace -- python $ROOTD/bench.py --steps 10 --warmup 3 --mode eager --no-cpu-baseline --no-roofline --no-eager-line )
   python tools/prof_summary.py gpurun_out/prof2 13 > gpurun_out/prof2_summary.txt 2>> $LOG
+  python tools/prof_timeline.py gpurun_out/prof2 3 > gpurun_out/prof2_timeline.txt 2>> $LOG
   fi
 fi
 if [ "${DO_PMC:-0}" = "1" ]; then
@@ -56,5 +59,9 @@ if [ "${DO_PMC:-0}" = "1" ]; then
     ( cd /tmp && TMO=600 run rocprofv3 --kernel-trace --pmc $ctr -d $ROOTD/gpurun_out/pmc_$ctr -o pmc -- env LD_PRELOAD=$ROOTD/deep-image-prior_amd/lib/libdip_hip.so python $ROOTD/bench.py --steps 3 --warmup 2 --mode eager --no-cpu-baseline --no-roofline --no-eager-line )
   done
   python tools/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE > gpurun_out/pmc_traffic.json 2>> $LOG
+  python tools/pmc_summary.py gpurun_out/pmc_FETCH_SIZE > gpurun_out/pmc_FETCH_SIZE_summary.txt 2>> $LOG
+  python tools/pmc_summary.py gpurun_out/pmc_WRITE_SIZE > gpurun_out/pmc_WRITE_SIZE_summary.txt 2>> $LOG
+  rm -rf gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE
 fi
+rm -f gpurun_out/prof1/*.db gpurun_out/prof2/*.db
 grep -E "passed|failed|error|rc=|^FAILED|^ERROR" $LOG | tail -60
