@@ -28,12 +28,17 @@ def _ref_conv(x, w, b, stride, pad_mode, dtype):
     return F.conv2d(x, w, b, stride=stride, padding=P)
 
 
+# per-op criterion: error vs the fp64 evaluation <= PER_OP_RATIO x the error of torch's own fp32 CPU kernel (+ a relative
+# floor): SURVEY 8c (1) asks for 2x; rounds 1-2 ran with 3x, all 216 cases pass with 2x (DIP_TEST_RATIO overrides it)
+PER_OP_RATIO = float(os.environ.get("DIP_TEST_RATIO", "2"))
+
+
 def _check(name, got, ref64, ref32, floor=2e-6):
     got = got.detach().cpu().double()
     e = (got - ref64).abs().max().item()
     e32 = (ref32.double() - ref64).abs().max().item()
     scale = ref64.abs().max().item() + 1e-30
-    tol = max(3 * e32, floor * scale)
+    tol = max(PER_OP_RATIO * e32, floor * scale)
     assert np.isfinite(e), f"{name}: non-finite output"
     assert e <= tol, f"{name}: max|err| {e:.3e} > tol {tol:.3e} (torch-fp32 err {e32:.3e}, scale {scale:.3e})"
 
