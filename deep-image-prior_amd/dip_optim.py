@@ -323,6 +323,12 @@ class ArenaLBFGS:
                 return torch.empty(0, dtype=torch.float32, device=g0.device).set_(st, off, (self._flat.numel(),),
                                                                                   (1,)).clone()
         views = [(p.grad.reshape(-1) if p.grad is not None else p.new_zeros(p.numel())) for p in self.params]
+        if self._flat is not None:
+            # same layout as the fast path (arena length, alignment gaps zero): history vectors of both paths mix
+            g = torch.zeros(self._flat.numel(), dtype=torch.float32, device=self._flat.device)
+            for v, o in zip(views, self._offsets):
+                g[o:o + v.numel()].copy_(v)
+            return g
         return torch.cat(views, 0)
 
     def _add_grad(self, t, d):

@@ -119,6 +119,11 @@ class Downsampler(nn.Module):
         kt = torch.from_numpy(self.kernel)
         for c in range(n_planes):
             holder.weight.data[c, c] = kt
+        # the HIP path applies FIXED taps and returns no weight gradient: say so on the parameters themselves, so that an
+        # optimiser handed `downsampler.parameters()` directly (not through get_params('down'), which makes forward()
+        # raise) sees tensors that do not require grad instead of silently training nothing
+        holder.weight.requires_grad_(False)
+        holder.bias.requires_grad_(False)
         self.downsampler_ = holder
         self.register_buffer('_taps', kt.to(torch.float32).contiguous(), persistent=False)
         self.register_load_state_dict_post_hook(Downsampler._taps_from_weight)
