@@ -305,8 +305,9 @@ def conv_flops(eng):
     for i, s in enumerate(eng.sc):
         st = s.st
         H, W = st["H"], st["W"]
-        for attr, (h, w) in (("skip_conv", (H, W)), ("down_a", (H, W)), ("down_b", (H // 2, W // 2)), ("up", (H, W)),
-                             ("up1", (H, W))):
+        Ho, Wo = st.get("Ho", H), st.get("Wo", W)
+        for attr, (h, w) in (("skip_conv", (H, W)), ("down_a", (H, W)), ("down_b", (st["d1"].H, st["d1"].W)), ("up", (Ho, Wo)),
+                             ("up1", (Ho, Wo))):
             r = getattr(s, attr)
             if r is not None:
                 f = dims(r, h, w, attr == "down_a" and s.pool is not None)
@@ -314,7 +315,7 @@ def conv_flops(eng):
                     fl[pre + r.name] = f
                 fl["dgthin:" + r.name] = 0.0       # thin columns of a 132-column data gradient: time counted, FLOPs are in "dgrad:"
     r = eng.out_conv
-    f = dims(r, eng.H, eng.W, False)
+    f = dims(r, eng.Hout, eng.Wout, False)
     fl["conv_fwd:out"] = fl["wgrad:out"] = fl["dgrad:out"] = f
     return fl
 

@@ -111,9 +111,23 @@ __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4
 // incoming gradient for pixel (r,c), channels [ch, ch+4): padded source with optional reflection fold
 __device__ __forceinline__ f32x4 grad_src4(const DipGradSrc& s, int r, int c, int H, int W, int ch) {
     const int P = s.pad;
-    const int Wg = W + 2 * P;
     const float* base = s.g + s.choff + ch;
+    if (s.win_h > 0) {                       // adjoint of a centre crop: zero outside the window
+        const int wr = r - s.win_y, wc = c - s.win_x;
+        if (wr < 0 || wr >= s.win_h || wc < 0 || wc >= s.win_w) return f32x4{0.f, 0.f, 0.f, 0.f};
+        return ld4(base + ((size_t)wr * s.win_w + wc) * s.Cg);
+    }
+    const int Wg = W + 2 * P;
     if (!s.fold || P == 0) return ld4(base + ((size_t)(r + P) * Wg + (c + P)) * s.Cg);
+    if (s.fold == 2) {
+        // adjoint of nn.ReplicationPad2d: a border pixel collects every ring position that clamps onto it
+        const int r0 = r == 0 ? 0 : r + P, r1 = r == H - 1 ? H - 1 + 2 * P : r + P;
+        const int c0 = c == 0 ? 0 : c + P, c1 = c == W - 1 ? W - 1 + 2 * P : c + P;
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = r0; i <= r1; ++i)
+            for (int j = c0; j <= c1; ++j) acc += ld4(base + ((size_t)i * Wg + j) * s.Cg);
+        return acc;
+    }
     // rows of the padded domain that reflect onto r: r+P itself, P-r (top), 2(H-1)-r+P (bottom)
     int rr[3], nr = 0, cc[3], ncn = 0;
     rr[nr++] = r + P;
@@ -310,6 +324,17 @@ __global__ __launch_bounds__(256) void fold_to_nchw_kernel(const DipGradSrc src,
     }
 }
 
+// fold a padded gradient onto the image, NHWC -> NHWC
+__global__ __launch_bounds__(256) void fold_to_nhwc_kernel(const DipGradSrc src, int H, int W, int C, float* dst, int Cd) {
+    const int nc4 = (C + 3) >> 2;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)H * W * nc4) return;
+    const int cg = (int)(i % nc4);
+    const long long p = i / nc4;
+    const int r = (int)(p / W), c = (int)(p - (long long)r * W);
+    st4(dst + (size_t)p * Cd + cg * 4, grad_src4(src, r, c, H, W, cg * 4));
+}
+
 __host__ int pixels_per_block(int npix, int C, int* nblk) {
     // ~1024 blocks for large tensors; small ones: two pixels per thread
     const int nc4 = (C + 3) / 4;
@@ -386,6 +411,15 @@ extern "C" int dip_bn_bwd_apply_src(const DipGradSrc* src, const float* y, int H
     const int ppb = pixels_per_block(H * W, C, &nb);
     hipLaunchKernelGGL(bn_bwd_apply_src_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *src, y, H, W, Cy, C,
                        state, Cs, slope, coef, dy, Cdy, ppb);
+    DIP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dip_fold_to_nhwc(const DipGradSrc* src, int H, int W, int C, float* dst, int Cd, void* stream) {
+    if ((Cd & 3) || (src->Cg & 3)) DIP_FAIL("fold_to_nhwc: channel strides must be multiples of 4");
+    const long long n = (long long)H * W * ((C + 3) / 4);
+    hipLaunchKernelGGL(fold_to_nhwc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *src, H,
+                       W, C, dst, Cd);
     DIP_CHECK_LAUNCH();
     return 0;
 }

@@ -62,9 +62,10 @@ struct Cfg {
     static constexpr bool PREFETCH_A = (KS == 1);
 };
 
-__device__ __forceinline__ int map_src(int v, int n_in, int dil, int reflect) {
+__device__ __forceinline__ int map_src(int v, int n_in, int dil, int pad_mode) {
     const int nv = (n_in - 1) * dil + 1;
-    if (reflect) v = dip_reflect(v, nv);
+    if (pad_mode == DIP_PAD_REFLECT) v = dip_reflect(v, nv);
+    else if (pad_mode == DIP_PAD_REPLICATE) v = min(max(v, 0), nv - 1);
     if (v < 0 || v >= nv) return -1;
     if (dil == 2) {
         if (v & 1) return -1;
@@ -465,6 +466,7 @@ int cch_of(int ks, int stride) {
     if (ks == 5 && stride == 2) return 8;
     if (ks == 7 && stride == 1) return 16;     // feature_inversion.ipynb: filter_size_down/up = [7, 7, 5, 5, 3, 3]
     if (ks == 7 && stride == 2) return 8;
+    if (ks == 8 || ks == 12) return 8;         // the dense Lanczos Downsampler conv inside conv() (stride 2) and its data gradient
     return 0;
 }
 
@@ -633,6 +635,10 @@ extern "C" int dip_conv_igemm(const DipConvDesc* dp, void* stream) {
     else if (d.ks == 5 && d.stride == 2) rc = launch_bn<5, 2, 8>(d, st, ksplit, d.ws);
     else if (d.ks == 7 && d.stride == 1) rc = launch_bn<7, 1, 16>(d, st, ksplit, d.ws);
     else if (d.ks == 7 && d.stride == 2) rc = launch_bn<7, 2, 8>(d, st, ksplit, d.ws);
+    else if (d.ks == 8 && d.stride == 2) rc = launch_bn<8, 2, 8>(d, st, ksplit, d.ws);
+    else if (d.ks == 8 && d.stride == 1) rc = launch_bn<8, 1, 8>(d, st, ksplit, d.ws);
+    else if (d.ks == 12 && d.stride == 2) rc = launch_bn<12, 2, 8>(d, st, ksplit, d.ws);
+    else if (d.ks == 12 && d.stride == 1) rc = launch_bn<12, 1, 8>(d, st, ksplit, d.ws);
     else DIP_FAIL("conv_igemm: unsupported kernel size / stride");
     if (rc || ksplit == 1) return rc;
     return dip_conv_splitk_finish(dp, stream);

@@ -720,6 +720,7 @@ extern "C" int dip_conv_dma_eligible(const DipConvDesc* dp) {
     } else if (d.stride != 1 || (d.ks != 1 && d.ks != 3)) {
         return 0;
     }
+    if (d.pad_mode == DIP_PAD_REPLICATE) return 0;      // (replication padding: the register-staged kernel)
     const bool has_tr = d.tr.a != nullptr;
     if (has_tr && d.Cin > TRN) return 0;
     if (has_tr && d.tr.slope <= 0.f) return 0;      // Swish / ELU: the register-staged kernel applies them at staging

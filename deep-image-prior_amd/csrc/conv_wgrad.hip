@@ -33,8 +33,9 @@ struct WCfg {
     static constexpr int NGROUPS = (KS * KS + NT - 1) / NT;
 };
 
-__device__ __forceinline__ int wmap_src(int v, int n_in, int reflect) {
-    if (reflect) v = dip_reflect(v, n_in);
+__device__ __forceinline__ int wmap_src(int v, int n_in, int pad_mode) {
+    if (pad_mode == DIP_PAD_REFLECT) v = dip_reflect(v, n_in);
+    else if (pad_mode == DIP_PAD_REPLICATE) v = min(max(v, 0), n_in - 1);
     return (v < 0 || v >= n_in) ? -1 : v;
 }
 
@@ -753,7 +754,7 @@ extern "C" int dip_wgrad_plan(int Hout, int Wout, int Cin, int Cout, int ks, int
     const int CinP = dip_round_up(Cin, 32), CoutP = dip_round_up(Cout, 32);
     const int nt = dip_conv_wgrad_ntiles(Hout, Wout);
     const int cw = (ks == 1) ? 128 : 32;
-    const int groups = (ks == 5) ? 5 : (ks == 7 ? 7 : 1);
+    const int groups = (ks == 5) ? 5 : (ks == 7 ? 7 : (ks == 8 ? 8 : (ks == 12 ? 24 : 1)));
     int chunks = dip_cdiv(CinP, cw);
     // a ragged <= 4-channel tail of a 3x3 conv runs the packed variant (2 of 9 MFMAs): its
     // workgroups are light, so fill the chip with the full chunks' workgroups
@@ -871,6 +872,8 @@ extern "C" int dip_conv_wgrad(const DipWgradDesc* dp, void* stream) {
     if (d.ks == 5 && d.stride == 2) return launch<5, 2, 5, 1>(d, st);
     if (d.ks == 7 && d.stride == 1) return launch<7, 1, 7, 1>(d, st);
     if (d.ks == 7 && d.stride == 2) return launch<7, 2, 7, 1>(d, st);
+    if (d.ks == 8 && d.stride == 2) return launch<8, 2, 8, 1>(d, st);        // Lanczos2 Downsampler conv: one filter row per workgroup
+    if (d.ks == 12 && d.stride == 2) return launch<12, 2, 6, 1>(d, st);      // Lanczos3: half a filter row
     DIP_FAIL("conv_wgrad: unsupported kernel size / stride");
 }
 

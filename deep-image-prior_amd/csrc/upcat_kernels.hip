@@ -158,16 +158,92 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const DipUpcatDesc d, in
     }
 }
 
-// low-res pixel (i,j): du = sum over the <=4x4 high-res pixels whose interpolation touches it
+// General centre crop (models/common.py:29-37): one thread = 4 channels of ONE output pixel (r, c); the skip branch is
+// read at (r + os_y, c + os_x) of its [Hs][Ws] tensor, the deeper branch at the up-sampled coordinate (r + od_y, c + od_x)
+// of its [2*Hd][2*Wd] image (upsample_bilinear2d's own source-index rule, bil_src, or nearest).  Used only for the
+// geometries the 2x2-block kernel above does not cover (pooling nets / skip-less scales at non-divisible sizes).
+__global__ __launch_bounds__(256) void upcat_fwd_crop_kernel(const DipUpcatDesc d, int ppb) {
+    __shared__ __attribute__((aligned(16))) float sh[256 * 12];
+    const int C = d.ns + d.nd;
+    const RowLayout L = row_layout(C);
+    f32x4 K = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = K, s2 = K;
+    float n = 0.f;
+    if (L.active) {
+        const int ch = L.cg * 4;
+        const bool skip_side = ch < d.ns;
+        const DipTransform& tt = skip_side ? d.ts : d.td;
+        const int tch = skip_side ? ch : ch - d.ns;
+        const bool has_t = tt.a != nullptr;
+        const f32x4 tA = has_t ? ld4(tt.a + tch) : f32x4{1.f, 1.f, 1.f, 1.f};
+        const f32x4 tB = has_t ? ld4(tt.b + tch) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const float tS = has_t ? tt.slope : 1.f;
+        auto trr = [&](f32x4 x) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = dip_act(fmaf(tA[e], x[e], tB[e]), tS);
+            return o;
+        };
+        const int npix = d.H * d.W;
+        const int p0 = blockIdx.x * ppb, p1 = min(p0 + ppb, npix);
+        for (int p = p0 + L.prow; p < p1; p += L.rpi) {
+            const int r = p / d.W, c = p - r * d.W;
+            f32x4 v;
+            if (skip_side) {
+                v = trr(ld4(d.s + ((size_t)(r + d.os_y) * d.Ws + (c + d.os_x)) * d.Cs_s + ch));
+            } else if (d.mode == DIP_UP_NEAREST) {
+                v = trr(ld4(d.d + ((size_t)((r + d.od_y) >> 1) * d.Wd + ((c + d.od_x) >> 1)) * d.Cs_d + (ch - d.ns)));
+            } else {
+                int i0, i1, j0, j1;
+                float li0, li1, lj0, lj1;
+                bil_src(r + d.od_y, d.Hd, i0, i1, li0, li1);
+                bil_src(c + d.od_x, d.Wd, j0, j1, lj0, lj1);
+                const float* base = d.d + (ch - d.ns);
+                const f32x4 t00 = trr(ld4(base + ((size_t)i0 * d.Wd + j0) * d.Cs_d)), t01 = trr(ld4(base + ((size_t)i0 * d.Wd + j1) * d.Cs_d)),
+                            t10 = trr(ld4(base + ((size_t)i1 * d.Wd + j0) * d.Cs_d)), t11 = trr(ld4(base + ((size_t)i1 * d.Wd + j1) * d.Cs_d));
+#pragma unroll
+                for (int e = 0; e < 4; ++e)      // ATen's order: rows blended from column blends
+                    v[e] = li0 * (lj0 * t00[e] + lj1 * t01[e]) + li1 * (lj0 * t10[e] + lj1 * t11[e]);
+            }
+            st4(d.cat + (size_t)p * d.Cs_cat + ch, v);
+            if (n == 0.f) K = v;
+            n += 1.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float dv = v[e] - K[e];
+                s1[e] += dv;
+                s2[e] += dv * dv;
+            }
+        }
+    }
+    f32x4 mean = f32x4{0.f, 0.f, 0.f, 0.f}, M2 = mean;
+    if (n > 0.f) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            mean[e] = K[e] + s1[e] / n;
+            M2[e] = s2[e] - s1[e] * s1[e] / n;
+        }
+    }
+    dip_tree_chan4(sh, L.nc4, L.rpi, L.prow, L.cg, L.active, n, mean, M2);
+    if (L.active && L.prow == 0) {
+        float* o = d.stats + (size_t)blockIdx.x * 3 * d.Cs_cat + L.cg * 4;
+        st4(o, f32x4{n, n, n, n});
+        st4(o + d.Cs_cat, mean);
+        st4(o + 2 * d.Cs_cat, M2);
+    }
+}
+
+// low-res pixel (i,j): du = sum over the <=4x4 high-res pixels whose interpolation touches it.  The deeper branch is
+// [Hl][Wl]; the gradient dcat is [H][W] and covers rows ody..ody+H-1, columns odx..odx+W-1 of the [2*Hl][2*Wl] up-sampled
+// image (Concat's centre crop; default geometry: Hl = (H+1)/2, offsets 0).
 __global__ __launch_bounds__(256) void upsample_bwd_stats_kernel(const float* __restrict__ dcat, int Cs_cat, int choff,
-                                                                 int H, int W, int mode, const float* __restrict__ y,
+                                                                 int H, int W, int Hl, int Wl, int ody, int odx, int mode,
+                                                                 const float* __restrict__ y,
                                                                  int Cy, int C, const float* __restrict__ state, int Cs,
                                                                  float slope, float* dz, int Cdz, float* partials,
                                                                  int ppb) {
     __shared__ __attribute__((aligned(16))) float sh[256 * 8];
     const RowLayout L = row_layout(C);
     f32x4 s1 = f32x4{0.f, 0.f, 0.f, 0.f}, s2 = s1;
-    const int Hl = (H + 1) >> 1, Wl = (W + 1) >> 1;      // (odd sizes: the last up-sampled row / column was cropped away)
     if (L.active) {
         const int ch = L.cg * 4;
         const f32x4 mean = ld4(state + ch), rstd = ld4(state + Cs + ch), a = ld4(state + 2 * Cs + ch),
@@ -182,9 +258,9 @@ __global__ __launch_bounds__(256) void upsample_bwd_stats_kernel(const float* __
                 for (int dr = 0; dr < 2; ++dr)
 #pragma unroll
                     for (int dc = 0; dc < 2; ++dc) {
-                        const int hr = 2 * i + dr, hc = 2 * j + dc;
-                        const f32x4 gq = ld4(dcat + ((size_t)min(hr, H - 1) * W + min(hc, W - 1)) * Cs_cat + choff + ch);
-                        const float wq = (hr < H && hc < W) ? 1.f : 0.f;
+                        const int hr = 2 * i + dr - ody, hc = 2 * j + dc - odx;          // position inside the crop window
+                        const f32x4 gq = ld4(dcat + ((size_t)min(max(hr, 0), H - 1) * W + min(max(hc, 0), W - 1)) * Cs_cat + choff + ch);
+                        const float wq = (hr >= 0 && hr < H && hc >= 0 && hc < W) ? 1.f : 0.f;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) du[e] = fmaf(wq, gq[e], du[e]);
                     }
@@ -192,19 +268,23 @@ __global__ __launch_bounds__(256) void upsample_bwd_stats_kernel(const float* __
                 // adjoint weights of the scale-2 bilinear up-sampling (align_corners = False) in closed form: high-res
                 // rows 2i-1 .. 2i+2 touch low-res row i with (0.25, 0.75, 0.75, 0.25); row 0 gives all of itself to
                 // i = 0, the last low-res row also collects the clamped upper neighbour, rows outside [0, H) nothing
-                const float wr[4] = {i >= 1 ? 0.25f : 0.f, i == 0 ? 1.f : 0.75f,
-                                     2 * i + 1 < H ? (i == Hl - 1 ? 1.f : 0.75f) : 0.f, 2 * i + 2 < H ? 0.25f : 0.f};
-                const float wc[4] = {j >= 1 ? 0.25f : 0.f, j == 0 ? 1.f : 0.75f,
-                                     2 * j + 1 < W ? (j == Wl - 1 ? 1.f : 0.75f) : 0.f, 2 * j + 2 < W ? 0.25f : 0.f};
+                // (weights of the FULL up-sampled image x "is the row inside the crop window")
+                auto inw = [](int u, int o, int nwin) { return (u - o >= 0 && u - o < nwin) ? 1.f : 0.f; };
+                const float wr[4] = {(i >= 1 ? 0.25f : 0.f) * inw(2 * i - 1, ody, H), (i == 0 ? 1.f : 0.75f) * inw(2 * i, ody, H),
+                                     (i == Hl - 1 ? 1.f : 0.75f) * inw(2 * i + 1, ody, H),
+                                     (i + 1 <= Hl - 1 ? 0.25f : 0.f) * inw(2 * i + 2, ody, H)};
+                const float wc[4] = {(j >= 1 ? 0.25f : 0.f) * inw(2 * j - 1, odx, W), (j == 0 ? 1.f : 0.75f) * inw(2 * j, odx, W),
+                                     (j == Wl - 1 ? 1.f : 0.75f) * inw(2 * j + 1, odx, W),
+                                     (j + 1 <= Wl - 1 ? 0.25f : 0.f) * inw(2 * j + 2, odx, W)};
                 // all 16 loads of the 4x4 window are issued unconditionally (clamped address, zero
                 // weight outside the image): branching on the weights serialised them
                 f32x4 gw[16];
 #pragma unroll
                 for (int tr = 0; tr < 4; ++tr) {
-                    const int hr = min(max(2 * i - 1 + tr, 0), H - 1);
+                    const int hr = min(max(2 * i - 1 + tr - ody, 0), H - 1);
 #pragma unroll
                     for (int tc = 0; tc < 4; ++tc) {
-                        const int hc = min(max(2 * j - 1 + tc, 0), W - 1);
+                        const int hc = min(max(2 * j - 1 + tc - odx, 0), W - 1);
                         gw[tr * 4 + tc] = ld4(dcat + ((size_t)hr * W + hc) * Cs_cat + choff + ch);
                     }
                 }
@@ -378,8 +458,24 @@ extern "C" int dip_upcat_fwd(const DipUpcatDesc* d, void* stream) {
     if ((d->ns & 3) || (d->nd & 3)) DIP_FAIL("upcat_fwd: channel counts must be multiples of 4");
     if (C > 1024) DIP_FAIL("upcat_fwd: C > 1024 unsupported");
     int nb;
-    pixels_per_block(d->H * d->W, C, &nb);
+    const int ppb = pixels_per_block(d->H * d->W, C, &nb);
     if (nb != d->nblk) DIP_FAIL("upcat_fwd: nblk mismatch (use dip_upcat_nblk)");
+    const bool general = d->Hs > 0 || d->Hd > 0;
+    if (general) {
+        DipUpcatDesc g = *d;
+        if (g.Hs == 0) { g.Hs = g.H; g.Ws = g.W; g.os_y = g.os_x = 0; }
+        if (g.Hd == 0) { g.Hd = (g.H + 1) / 2; g.Wd = (g.W + 1) / 2; g.od_y = g.od_x = 0; }
+        if (g.os_y < 0 || g.os_x < 0 || g.os_y + g.H > g.Hs || g.os_x + g.W > g.Ws || g.od_y < 0 || g.od_x < 0 ||
+            g.od_y + g.H > 2 * g.Hd || g.od_x + g.W > 2 * g.Wd)
+            DIP_FAIL("upcat_fwd: crop window outside a branch");
+        const bool dflt = g.Hs == g.H && g.Ws == g.W && g.os_y == 0 && g.os_x == 0 && g.Hd == (g.H + 1) / 2 &&
+                          g.Wd == (g.W + 1) / 2 && g.od_y == 0 && g.od_x == 0;
+        if (!dflt) {
+            hipLaunchKernelGGL(upcat_fwd_crop_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, g, ppb);
+            DIP_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     const int qpb = dip_cdiv(((d->H + 1) / 2) * ((d->W + 1) / 2), nb);       // 2x2 output blocks per workgroup
     hipLaunchKernelGGL(upcat_fwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *d, qpb);
     DIP_CHECK_LAUNCH();
@@ -441,7 +537,22 @@ extern "C" int dip_upsample_bwd_stats(const float* dcat, int Cs_cat, int choff, 
     const int ppb = pixels_per_block(((H + 1) / 2) * ((W + 1) / 2), C, &nb);
     if (nb != nblk) DIP_FAIL("upsample_bwd_stats: nblk mismatch (use dip_bn_bwd_nblk((H+1)/2, (W+1)/2, C))");
     hipLaunchKernelGGL(upsample_bwd_stats_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dcat, Cs_cat, choff, H,
-                       W, mode, y, Cy, C, state, Cs, slope, dz, Cdz, partials, ppb);
+                       W, (H + 1) / 2, (W + 1) / 2, 0, 0, mode, y, Cy, C, state, Cs, slope, dz, Cdz, partials, ppb);
+    DIP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dip_upsample_bwd_stats_crop(const float* dcat, int Cs_cat, int choff, int H, int W, int Hd, int Wd,
+                                           int od_y, int od_x, int mode, const float* y, int Cy, int C,
+                                           const float* state, int Cs, float slope, float* dz, int Cdz, float* partials,
+                                           int nblk, void* stream) {
+    if (C > 1024) DIP_FAIL("upsample_bwd_stats_crop: C > 1024 unsupported");
+    if (od_y < 0 || od_x < 0 || od_y + H > 2 * Hd || od_x + W > 2 * Wd) DIP_FAIL("upsample_bwd_stats_crop: crop window outside the up-sampled image");
+    int nb;
+    const int ppb = pixels_per_block(Hd * Wd, C, &nb);
+    if (nb != nblk) DIP_FAIL("upsample_bwd_stats_crop: nblk mismatch (use dip_bn_bwd_nblk(Hd, Wd, C))");
+    hipLaunchKernelGGL(upsample_bwd_stats_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dcat, Cs_cat, choff, H,
+                       W, Hd, Wd, od_y, od_x, mode, y, Cy, C, state, Cs, slope, dz, Cdz, partials, ppb);
     DIP_CHECK_LAUNCH();
     return 0;
 }

@@ -255,20 +255,6 @@ class SkipEngine:
         self.bwdp3_need = 4                            # fused BatchNorm-backward partials of the thin data-gradient columns
 
     def _build_plan(self, H, W, Cin_img):
-        div = 2 ** self.nscales
-        if (H % div or W % div) and any(sc.pool is not None for sc in self.sc):
-            # pooling floors the size, so the x2 up-sampled tensor is SMALLER than the skip branch, the concat (and
-            # the net's output) shrinks and crop offsets appear: not built (the reference's own loss then fails on
-            # the shape mismatch with the target image)
-            raise NotImplementedError(
-                f"dip-amd: input {H}x{W} must be divisible by 2^{self.nscales} with avg / max down-sampling "
-                "(size-changing Concat crop, models/common.py:29-37)")
-        if (H % div or W % div) and any(sc.ns == 0 for sc in self.sc):
-            # a scale without skip branch has no Concat: its x2 up-sampled tensor keeps the larger size and the crop
-            # further up gets a non-zero offset
-            raise NotImplementedError(
-                f"dip-amd: input {H}x{W} must be divisible by 2^{self.nscales} when a scale has no skip branch "
-                "(Concat crop with offsets, models/common.py:29-37)")
         if min(H, W) < 2 ** self.nscales:
             raise NotImplementedError(f"dip-amd: input {H}x{W} is too small for {self.nscales} scales")
         self.H, self.W, self.Cimg = H, W, Cin_img
@@ -299,10 +285,13 @@ class SkipEngine:
             xin = Act(self.x_nhwc, H, W, Cin_img)
             last = self._plan_scale(0, xin, H, W)
             # output conv (no BatchNorm) + sigmoid head
-            self.y_out = self._buf(H * W * round_up(oc.Cout, 4))
+            # (the net's output is the size of the top scale's concat: smaller than the input when pooling floors an odd
+            # size and Concat crops the skip branch, models/common.py:29-37)
+            self.Hout, self.Wout = last.H, last.W
+            self.y_out = self._buf(last.H * last.W * round_up(oc.Cout, 4))
             self._emit_conv_fwd(oc, last, self.y_out, None)
             # backward: head, out conv, then the scales from the top
-            self.dy_out = self._buf(H * W * round_up(oc.Cout, 4))
+            self.dy_out = self._buf(last.H * last.W * round_up(oc.Cout, 4))
             pre = []
             self._emit_wgrad(oc, last, self.dy_out, pre, scale=0)
             du_last = self._emit_dgrad(oc, last, self.dy_out, pre, fuse_bn=True)
@@ -343,21 +332,34 @@ class SkipEngine:
         st["deep"] = deep
         ccat = s.ns + deep.C
         assert ccat == s.cat_bn.C == s.up.Cin, (ccat, s.cat_bn.C, s.up.Cin)
-        st["cat"] = self._buf(H * W * round_up(ccat, 4))
-        self._emit_upcat(s, st.get("s_act"), deep, st["cat"], H, W)
-        cat = Act(st["cat"], H, W, ccat, s.cat_bn, 1.0)
+        # Concat (models/common.py:19-39): [skip branch H x W | x2 up-sampled deeper branch Hu x Wu], both centre-cropped
+        # to the smaller size; without a skip branch there is no Concat and the up-sampled size goes on as it is.
+        Hu, Wu = 2 * deep.H, 2 * deep.W
+        if s.ns:
+            Ho, Wo = min(H, Hu), min(W, Wu)
+        else:
+            Ho, Wo = Hu, Wu
+        geom = dict(Hs=H, Ws=W, os_y=(H - Ho) // 2 if s.ns else 0, os_x=(W - Wo) // 2 if s.ns else 0,
+                    Hd=deep.H, Wd=deep.W, od_y=(Hu - Ho) // 2, od_x=(Wu - Wo) // 2)
+        # the geometry of the 2x2-block kernels: nothing cropped but (for an odd size) the last up-sampled row / column
+        default = (not s.ns or (Ho, Wo) == (H, W)) and deep.H == (Ho + 1) // 2 and deep.W == (Wo + 1) // 2 \
+            and geom["od_y"] == 0 and geom["od_x"] == 0
+        st["geom"] = None if default else geom
+        st["cat"] = self._buf(Ho * Wo * round_up(ccat, 4))
+        self._emit_upcat(s, st.get("s_act"), deep, st["cat"], Ho, Wo, st["geom"])
+        cat = Act(st["cat"], Ho, Wo, ccat, s.cat_bn, 1.0)
         st["cat_act"] = cat
-        st["u_y"] = self._buf(H * W * round_up(s.up.Cout, 4))
+        st["u_y"] = self._buf(Ho * Wo * round_up(s.up.Cout, 4))
         self._emit_conv_fwd(s.up, cat, st["u_y"], s.up_bn)
-        u = Act(st["u_y"], H, W, s.up.Cout, s.up_bn, self.slope)
+        u = Act(st["u_y"], Ho, Wo, s.up.Cout, s.up_bn, self.slope)
         st["u"] = u
         res = u
         if s.up1 is not None:
-            st["u1_y"] = self._buf(H * W * round_up(s.up1.Cout, 4))
+            st["u1_y"] = self._buf(Ho * Wo * round_up(s.up1.Cout, 4))
             self._emit_conv_fwd(s.up1, u, st["u1_y"], s.up1_bn)
-            res = Act(st["u1_y"], H, W, s.up1.Cout, s.up1_bn, self.slope)
+            res = Act(st["u1_y"], Ho, Wo, s.up1.Cout, s.up1_bn, self.slope)
             st["u1"] = res
-        st["xin"], st["H"], st["W"] = xin, H, W
+        st["xin"], st["H"], st["W"], st["Ho"], st["Wo"] = xin, H, W, Ho, Wo
         s.st = st
         return res
 
@@ -421,7 +423,7 @@ class SkipEngine:
         self.fwd_ops.append((fn, (_ptr(x), H, W, Cs, Cc, _ptr(y), Cs, _ptr(self.stats_scratch), nblk), "pool:" + bn.name))
         self._emit_bn_finalize(bn, self.stats_scratch, nblk, Cs)
 
-    def _emit_upcat(self, s, s_act: Optional[Act], deep: Act, cat, H, W):
+    def _emit_upcat(self, s, s_act: Optional[Act], deep: Act, cat, H, W, geom=None):
         Ccat = s.ns + deep.C
         Cs_cat = round_up(Ccat, 4)
         nblk = self.lib.dip_upcat_nblk(H, W, Ccat)
@@ -433,6 +435,9 @@ class SkipEngine:
                            s_act.transform() if s_act else N.DipTransform(None, None, 1.0),
                            _ptr(deep.buf), deep.Cs, deep.C, deep.transform(), H, W, mode, _ptr(cat), Cs_cat,
                            _ptr(self.stats_scratch), nblk)
+        if geom is not None:                      # general centre crop (DipUpcatDesc: Hs / Hd geometry)
+            for k, v in geom.items():
+                setattr(d, k, v)
         self.keep.append(d)
         self.fwd_ops.append((self.lib.dip_upcat_fwd, (C.byref(d),), "upcat:" + s.cat_bn.name))
         self._emit_bn_finalize(s.cat_bn, self.stats_scratch, nblk, Cs_cat)
@@ -545,13 +550,15 @@ class SkipEngine:
             ops.append((self.lib.dip_conv_igemm, (C.byref(d),), "dgrad:" + r.name))
         return (gbuf, pad)
 
-    def _gradsrc(self, g, Cg, choff=0):
+    def _gradsrc(self, g, Cg, choff=0, window=None):
         buf, pad = g
         d = N.DipGradSrc(_ptr(buf), pad, 1 if pad > 0 else 0, Cg, choff)
+        if window is not None:                    # (win_y, win_x, win_h, win_w): adjoint of Concat's crop of this branch
+            d.win_y, d.win_x, d.win_h, d.win_w = window
         self.keep.append(d)
         return d
 
-    def _emit_bn_act_bwd(self, a: Act, g, ops, choff=0, Cg=None, side=False):
+    def _emit_bn_act_bwd(self, a: Act, g, ops, choff=0, Cg=None, side=False, window=None):
         """BatchNorm(+LeakyReLU) backward of activation `a` given the gradient source g=(buf,pad)
         wrt the activated value.  Returns the dy buffer (grad wrt a.buf, the conv's raw output).
         side=True: the op runs on the side stream (skip branch) and gets partial-sum scratch of its own."""
@@ -565,7 +572,7 @@ class SkipEngine:
             return None
         scratch = self.bwd_scratch2 if side else self.bwd_scratch
         dz = self._new(a.H * a.W * a.Cs)
-        src = self._gradsrc(g, Cg if Cg is not None else a.Cs, choff)
+        src = self._gradsrc(g, Cg if Cg is not None else a.Cs, choff, window)
         lib = self.lib
         # phase 1 only reduces (dz = NULL); phase 3 recomputes the masked gradient from the source:
         # 5 tensor passes per BatchNorm instead of 6
@@ -588,7 +595,7 @@ class SkipEngine:
                                                float(a.slope), _ptr(bn.coef), _ptr(dz), a.Cs), "bnb_apply:" + bn.name))
         return dz
 
-    def _emit_up_bwd(self, deep: Act, dcat, Cs_cat, choff, H, W, mode, ops):
+    def _emit_up_bwd(self, deep: Act, dcat, Cs_cat, choff, H, W, mode, ops, geom=None):
         bn = deep.bn
         nblk = self.lib.dip_bn_bwd_nblk(deep.H, deep.W, deep.C)
         if self._sizing:
@@ -597,9 +604,15 @@ class SkipEngine:
         dz = self._new(deep.H * deep.W * deep.Cs)
         lib = self.lib
         m = N.UP_BILINEAR if mode == "bilinear" else N.UP_NEAREST
-        ops.append((lib.dip_upsample_bwd_stats, (_ptr(dcat), Cs_cat, choff, H, W, m, _ptr(deep.buf), deep.Cs, deep.C,
-                                                 _ptr(bn.state), bn.Cs, float(deep.slope), _ptr(dz), deep.Cs,
-                                                 _ptr(self.bwd_scratch), nblk), "upb_stats:" + bn.name))
+        if geom is None:
+            ops.append((lib.dip_upsample_bwd_stats, (_ptr(dcat), Cs_cat, choff, H, W, m, _ptr(deep.buf), deep.Cs, deep.C,
+                                                     _ptr(bn.state), bn.Cs, float(deep.slope), _ptr(dz), deep.Cs,
+                                                     _ptr(self.bwd_scratch), nblk), "upb_stats:" + bn.name))
+        else:
+            ops.append((lib.dip_upsample_bwd_stats_crop,
+                        (_ptr(dcat), Cs_cat, choff, H, W, geom["Hd"], geom["Wd"], geom["od_y"], geom["od_x"], m,
+                         _ptr(deep.buf), deep.Cs, deep.C, _ptr(bn.state), bn.Cs, float(deep.slope), _ptr(dz), deep.Cs,
+                         _ptr(self.bwd_scratch), nblk), "upb_stats:" + bn.name))
         ops.append((lib.dip_bn_bwd_finalize, (_ptr(self.bwd_scratch), nblk, bn.Cs, bn.C, deep.H * deep.W,
                                               _ptr(self.grads, bn.gamma_off), _ptr(self.grads, bn.beta_off),
                                               _ptr(bn.coef)), "bnb_fin:" + bn.name))
@@ -618,6 +631,7 @@ class SkipEngine:
             self._entered_defer_scale = True
             ops += self._flush_deferred_wgrads()
         H, W, xin = st["H"], st["W"], st["xin"]
+        Ho, Wo, geom = st["Ho"], st["Wo"], st["geom"]
         if s.up1 is not None:
             self._emit_wgrad(s.up1, st["u"], dy_last, ops, scale=i)
             g = self._emit_dgrad(s.up1, st["u"], dy_last, ops, fuse_bn=True)
@@ -630,10 +644,11 @@ class SkipEngine:
         dcat = self._emit_bn_act_bwd(cat, g, ops)            # grad wrt the concat tensor [H,W,Cs_cat]
         dy_s = None
         if s.ns:
-            dy_s = self._emit_bn_act_bwd(st["s_act"], (dcat, 0), ops, choff=0, Cg=cat.Cs, side=True)
+            win = (geom["os_y"], geom["os_x"], Ho, Wo) if (geom is not None and (Ho, Wo) != (H, W)) else None
+            dy_s = self._emit_bn_act_bwd(st["s_act"], (dcat, 0), ops, choff=0, Cg=cat.Cs, side=True, window=win)
             self._emit_wgrad(s.skip_conv, xin, dy_s, ops, scale=i)
         deep = st["deep"]
-        dy_deep = self._emit_up_bwd(deep, dcat, cat.Cs, s.ns, H, W, s.upsample_mode, ops)
+        dy_deep = self._emit_up_bwd(deep, dcat, cat.Cs, s.ns, Ho, Wo, s.upsample_mode, ops, geom)
         if self._entered_defer_scale:
             ops += self._flush_deferred_wgrads()          # this scale's decoder weight gradients, one fork
         if i < self.nscales - 1:
@@ -824,10 +839,11 @@ class SkipEngine:
                 self._run_forward_two_streams(ops, main)
             else:
                 self._run(ops, stream)
-            out = torch.empty((1, self.n_out, H, W), dtype=torch.float32, device=dev)
+            Ho_, Wo_ = self.Hout, self.Wout
+            out = torch.empty((1, self.n_out, Ho_, Wo_), dtype=torch.float32, device=dev)
             loss = None
             if head is None:
-                N.check(lib.dip_head_fwd(_ptr(self.y_out), out.data_ptr(), self.n_out, H * W, round_up(self.n_out, 4),
+                N.check(lib.dip_head_fwd(_ptr(self.y_out), out.data_ptr(), self.n_out, Ho_ * Wo_, round_up(self.n_out, 4),
                                          1 if self.need_sigmoid else 0, stream), "head_fwd")
             else:
                 loss = torch.empty((), dtype=torch.float32, device=dev)
@@ -877,7 +893,8 @@ class SkipEngine:
                 if g.dtype != torch.float32:
                     g = g.float()
                 g = g.contiguous()
-                N.check(lib.dip_head_bwd(g.data_ptr(), self.last_out.data_ptr(), _ptr(self.dy_out), self.n_out, H * W,
+                N.check(lib.dip_head_bwd(g.data_ptr(), self.last_out.data_ptr(), _ptr(self.dy_out), self.n_out,
+                                         self.Hout * self.Wout,
                                          round_up(self.n_out, 4), 1 if self.need_sigmoid else 0, stream), "head_bwd")
             else:
                 gl = gloss.detach().reshape(1)

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdip_hip.so")
 ABI_VERSION = 3
 
-PAD_ZERO, PAD_REFLECT = 0, 1
+PAD_ZERO, PAD_REFLECT, PAD_REPLICATE = 0, 1, 2
 UP_NEAREST, UP_BILINEAR = 0, 1
 
 c_float_p = C.c_void_p  # device pointers travel as raw addresses
@@ -52,7 +52,8 @@ class DipWgradDesc(C.Structure):
 
 
 class DipGradSrc(C.Structure):
-    _fields_ = [("g", C.c_void_p), ("pad", C.c_int32), ("fold", C.c_int32), ("Cg", C.c_int32), ("choff", C.c_int32)]
+    _fields_ = [("g", C.c_void_p), ("pad", C.c_int32), ("fold", C.c_int32), ("Cg", C.c_int32), ("choff", C.c_int32),
+                ("win_y", C.c_int32), ("win_x", C.c_int32), ("win_h", C.c_int32), ("win_w", C.c_int32)]
 
 
 class DipUpcatDesc(C.Structure):
@@ -60,7 +61,9 @@ class DipUpcatDesc(C.Structure):
                 ("d", C.c_void_p), ("Cs_d", C.c_int32), ("nd", C.c_int32), ("td", DipTransform),
                 ("H", C.c_int32), ("W", C.c_int32), ("mode", C.c_int32),
                 ("cat", C.c_void_p), ("Cs_cat", C.c_int32),
-                ("stats", C.c_void_p), ("nblk", C.c_int32)]
+                ("stats", C.c_void_p), ("nblk", C.c_int32),
+                ("Hs", C.c_int32), ("Ws", C.c_int32), ("os_y", C.c_int32), ("os_x", C.c_int32),
+                ("Hd", C.c_int32), ("Wd", C.c_int32), ("od_y", C.c_int32), ("od_x", C.c_int32)]
 
 
 class DipIterState(C.Structure):
@@ -116,6 +119,7 @@ _SIGS = {
     "dip_bn_bwd_apply_src": (C.c_int, [C.POINTER(DipGradSrc), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "dip_fold_to_nchw": (C.c_int, [C.POINTER(DipGradSrc), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "dip_fold_to_nhwc": (C.c_int, [C.POINTER(DipGradSrc), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "dip_upcat_fwd": (C.c_int, [C.POINTER(DipUpcatDesc), C.c_void_p]),
     "dip_upcat_nblk": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "dip_avgpool2_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
@@ -128,6 +132,9 @@ _SIGS = {
     "dip_upsample_bwd_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                          C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int,
                                          C.c_void_p, C.c_int, C.c_void_p]),
+    "dip_upsample_bwd_stats_crop": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                              C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                              C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "dip_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double,
                                 C.c_double, C.c_double, C.c_int, C.c_void_p]),
     "dip_noise_axpy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_uint64, C.c_uint64, C.c_void_p]),

@@ -51,7 +51,7 @@ class MSEHead:
 
     def _descriptor(self, eng, out, loss):
         """DipLossHeadDesc for the engine's current plan (called by SkipEngine.forward)."""
-        H, W = eng.H, eng.W
+        H, W = eng.Hout, eng.Wout
         if tuple(self.target.shape[2:]) != (H, W):
             raise ValueError(f"MSEHead: target is {tuple(self.target.shape[2:])}, the net output is {(H, W)}")
         a = eng.last_act

@@ -29,6 +29,7 @@ extern "C" {
 
 #define DIP_PAD_ZERO 0
 #define DIP_PAD_REFLECT 1
+#define DIP_PAD_REPLICATE 2   /* nn.ReplicationPad2d: the Downsampler inside conv(), models/downsampler.py:56-61 */
 
 /* DipTransform.slope codes for activations other than LeakyReLU (act_fun='Swish' | 'ELU') */
 #define DIP_ACT_SWISH (-1.0f)
@@ -208,10 +209,15 @@ int dip_bn_finalize(const float* partials, int ntiles, int Cstride, int C, const
 /* Source of an incoming activation gradient `du` for pixel (r,c), channel ch:
  *   du = sum over folded positions of  g[((r+pad)*Wg + (c+pad)) * Cg + choff + ch]
  * fold == 1 adds the mirror images of the reflection-padded border (adjoint of
- * nn.ReflectionPad2d, models/common.py:116-118); Hg = H + 2*pad, Wg = W + 2*pad. */
+ * nn.ReflectionPad2d, models/common.py:116-118), fold == 2 the ring positions that nn.ReplicationPad2d clamps onto a
+ * border pixel (models/downsampler.py:56-61); Hg = H + 2*pad, Wg = W + 2*pad. */
 typedef struct DipGradSrc {
     const float* g;
     int32_t pad, fold, Cg, choff;
+    /* Optional crop window (win_h > 0, then pad == 0): g is a [win_h][win_w] tensor that covers rows win_y..win_y+win_h-1,
+     * columns win_x..win_x+win_w-1 of the [H][W] activation; du = 0 outside (adjoint of Concat's centre crop,
+     * models/common.py:29-37, for the branch that was cropped). */
+    int32_t win_y, win_x, win_h, win_w;
 } DipGradSrc;
 
 /* BatchNorm+LeakyReLU backward, phase 1:  dz = du * (a*y+b > 0 ? 1 : slope); writes dz (unless
@@ -240,18 +246,26 @@ int dip_bn_bwd_apply_src(const DipGradSrc* src, const float* y, int H, int W, in
 /* Fold a (reflection-)padded gradient back onto the image and emit it NCHW: gradient wrt
  * `net_input` for get_params('net,input') (utils/common_utils.py:47-49). */
 int dip_fold_to_nchw(const DipGradSrc* src, int H, int W, int C, float* dst, void* stream);
+/* The same, NHWC out ([H][W][Cd]): dy of a conv whose output feeds a padded consumer directly, without a BatchNorm in
+ * between (the stride-1 conv in front of the Lanczos Downsampler of conv(..., downsample_mode='lanczos2')). */
+int dip_fold_to_nhwc(const DipGradSrc* src, int H, int W, int C, float* dst, int Cd, void* stream);
 
 /* ---------------------------------------------------------------- upsample + concat ------- */
 /* cat[p][0:ns]      = T_s(s[p])                      (skip branch, Concat child "0")
  * cat[p][ns:ns+nd]  = upsample2x(T_d(d))[p]          (deeper branch, nn.Upsample models/skip.py:81)
  * and the {count, mean, M2} partials of the BatchNorm2d(ns+nd) that follows (models/skip.py:55).
- * Concat: models/common.py:11-42 (no crop: H, W divisible by 2^scales). */
+ * Concat: models/common.py:11-42.  Default geometry (Hs == 0): s is [H][W], d is [(H+1)/2][(W+1)/2] (an odd size drops
+ * the last up-sampled row / column: the centre crop with offset 0).  General centre crop (models/common.py:29-37; pooling
+ * nets or skip-less scales at sizes that 2^scales does not divide): Hs, Ws = size of s, (os_y, os_x) = its crop offset;
+ * Hd, Wd = size of d, (od_y, od_x) = crop offset inside its [2*Hd][2*Wd] up-sampled image; H, W = the common (min) size. */
 typedef struct DipUpcatDesc {
     const float* s; int32_t Cs_s, ns; DipTransform ts;      /* ns may be 0 (s == NULL) */
     const float* d; int32_t Cs_d, nd; DipTransform td;      /* low-res [H/2][W/2][Cs_d] */
     int32_t H, W, mode;                                      /* output (high-res) size */
     float* cat; int32_t Cs_cat;
     float* stats; int32_t nblk;                              /* [nblk][3][Cs_cat] */
+    int32_t Hs, Ws, os_y, os_x;                              /* 0: default geometry */
+    int32_t Hd, Wd, od_y, od_x;
 } DipUpcatDesc;
 int dip_upcat_fwd(const DipUpcatDesc* d, void* stream);
 int dip_upcat_nblk(int H, int W, int C);
@@ -277,6 +291,11 @@ int dip_maxpool2_bwd(const float* dy, const float* x, int H, int W, int Cdy, int
 int dip_upsample_bwd_stats(const float* dcat, int Cs_cat, int choff, int H, int W, int mode,
                            const float* y, int Cy, int C, const float* state, int Cs, float slope,
                            float* dz, int Cdz, float* partials, int nblk, void* stream);
+/* the same with the general crop geometry of DipUpcatDesc: dcat is [H][W], the deeper branch [Hd][Wd] (y, dz), cropped at
+ * (od_y, od_x) of its up-sampled image; nblk = dip_bn_bwd_nblk(Hd, Wd, C) */
+int dip_upsample_bwd_stats_crop(const float* dcat, int Cs_cat, int choff, int H, int W, int Hd, int Wd, int od_y,
+                                int od_x, int mode, const float* y, int Cy, int C, const float* state, int Cs,
+                                float slope, float* dz, int Cdz, float* partials, int nblk, void* stream);
 
 /* ---------------------------------------------------------------- optimiser --------------- */
 /* torch.optim.Adam(lr) defaults, one fused launch over a flat arena

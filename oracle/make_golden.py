@@ -82,6 +82,18 @@ NETS = {
                            kw=dict(num_channels_down=[16, 16], num_channels_up=[16, 16],
                                    num_channels_skip=[4, 4], upsample_mode="nearest",
                                    need_sigmoid=True, need_bias=True, pad="zero")),
+    # Concat's centre crop with OFFSETS (models/common.py:29-37): avg pooling floors the odd sizes 45x38 -> 22x19 -> 11x9, so
+    # the x2 up-sampled tensors are smaller than the skip branches (cropped at offsets (2,3) / (1,1) / 0) and the net's
+    # output is 40x32; two skip-less scales up-sample 8x10 -> 16x20 -> 32x40 against a 29x37 skip branch (deep branch
+    # cropped at offset (1,1))
+    "tiny_poolcrop": dict(args=(8, 3), hw=(45, 38), seed=14,
+                          kw=dict(num_channels_down=[16, 16, 16], num_channels_up=[16, 16, 16],
+                                  num_channels_skip=[4, 4, 4], upsample_mode="bilinear", downsample_mode="avg",
+                                  need_sigmoid=True, need_bias=True, pad="reflection")),
+    "tiny_noskipcrop": dict(args=(8, 3), hw=(29, 37), seed=15,
+                            kw=dict(num_channels_down=[16, 16, 16], num_channels_up=[16, 16, 16],
+                                    num_channels_skip=[4, 0, 0], upsample_mode="bilinear",
+                                    need_sigmoid=True, need_bias=True, pad="reflection")),
     # feature_inversion.ipynb:169-174: per-scale filter sizes 7 / 5 / 3, zero padding, avg-pool
     # down-sampling, nearest up-sampling, meshgrid input
     "tiny_feat7": dict(args=(2, 3), hw=(32, 48), seed=7,
@@ -109,8 +121,9 @@ def gen_net(name, cfg):
     H, W = cfg["hw"]
     cin, cout = cfg["args"]
     z = cu.get_noise(cin, "meshgrid" if cin == 2 else "noise", (H, W)).float()
-    target = torch.rand(1, cout, H, W)
-    mask = (torch.rand(1, 1, H, W) > 0.3).float()
+    Ho, Wo = copy.deepcopy(net)(z).shape[2:]        # (the output is smaller than the input when Concat crops a skip branch)
+    target = torch.rand(1, cout, Ho, Wo)
+    mask = (torch.rand(1, 1, Ho, Wo) > 0.3).float()
     rec = {"z": z.numpy(), "target": target.numpy(), "mask": mask.numpy()}
     for k, v in net.state_dict().items():
         rec["sd/" + k] = v.detach().numpy().copy()

@@ -25,7 +25,7 @@ def test_cabi_exports_every_declared_symbol(built):
     assert built.dip_abi_version() == dip_native.ABI_VERSION == 3
     # struct layouts agree with the header's field order (sizes on LP64)
     assert ctypes.sizeof(dip_native.DipTransform) == 24
-    assert ctypes.sizeof(dip_native.DipGradSrc) == 24
+    assert ctypes.sizeof(dip_native.DipGradSrc) == 40     # + the crop window of round 3
     assert ctypes.sizeof(dip_native.DipPackRec) == 56
 
 
@@ -127,14 +127,16 @@ def test_planner_builds_launch_lists_for_every_option(built):
     pooled = skip(8, 3, [16, 16], [16, 16], [4, 4], downsample_mode="avg", pad="reflection")
     e3 = pooled.__dict__["_dip_engine"]
     e3._build_arenas(torch.device("cpu"))
-    with pytest.raises(NotImplementedError, match="divisible"):
-        e3._build_plan(30, 32, 8)              # pooling floors: the concat would shrink (size-changing crop)
+    e3._build_plan(30, 33, 8)                  # pooling floors 15x16 -> 7x8: the concats shrink (centre crops with offsets)
+    assert (e3.Hout, e3.Wout) == (28, 32) and e3.sc[0].st["geom"]["os_y"] == 1 and e3.sc[1].st["geom"]["os_y"] == 0
+    assert [n for _, _, n in e3.fwd_ops if n.startswith("upcat:")] == ["upcat:s1.cat_bn", "upcat:s0.cat_bn"]
     noskip = skip(8, 3, [16, 16], [16, 16], [4, 0], pad="reflection")
     e4 = noskip.__dict__["_dip_engine"]
     e4._build_arenas(torch.device("cpu"))
     e4._build_plan(32, 48, 8)
-    with pytest.raises(NotImplementedError, match="no skip branch"):
-        e4._build_plan(30, 47, 8)              # the crop further up would need an offset
+    e4._build_plan(30, 47, 8)                  # 15x24 -> 8x12 -> (no Concat at scale 1) 16x24 -> x2 = 32x48 against 30x47
+    assert (e4.Hout, e4.Wout) == (30, 47) and e4.sc[0].st["geom"]["od_y"] == 1 and e4.sc[0].st["geom"]["od_x"] == 0
+    assert (e4.sc[1].st["Ho"], e4.sc[1].st["Wo"]) == (16, 24) and e4.sc[1].st["geom"] is None
     big = skip(8, 3, [16, 16], [16, 16], [4, 4], filter_skip_size=5, filter_size_down=3, pad="reflection")
     e2 = big.__dict__["_dip_engine"]
     e2._build_arenas(torch.device("cpu"))

@@ -58,6 +58,13 @@ NETS = {
     "tiny_ragged_nn": dict(args=(8, 3), kw=dict(num_channels_down=[16, 16], num_channels_up=[16, 16],
                                                 num_channels_skip=[4, 4], upsample_mode="nearest",
                                                 need_sigmoid=True, need_bias=True, pad="zero")),
+    # Concat's centre crop with offsets (models/common.py:29-37): pooling at odd sizes / skip-less scales (oracle/make_golden.py)
+    "tiny_poolcrop": dict(args=(8, 3), kw=dict(num_channels_down=[16, 16, 16], num_channels_up=[16, 16, 16],
+                                               num_channels_skip=[4, 4, 4], upsample_mode="bilinear", downsample_mode="avg",
+                                               need_sigmoid=True, need_bias=True, pad="reflection")),
+    "tiny_noskipcrop": dict(args=(8, 3), kw=dict(num_channels_down=[16, 16, 16], num_channels_up=[16, 16, 16],
+                                                 num_channels_skip=[4, 0, 0], upsample_mode="bilinear",
+                                                 need_sigmoid=True, need_bias=True, pad="reflection")),
     "tiny_feat7": dict(args=(2, 3), kw=dict(num_channels_down=[8, 16, 16], num_channels_up=[8, 16, 16],
                                             num_channels_skip=[4, 4, 4], filter_size_down=[7, 5, 3],
                                             filter_size_up=[7, 5, 3], upsample_mode="nearest", downsample_mode="avg",
