@@ -503,6 +503,15 @@ extern "C" int dip_conv_plan(int Hout, int Wout, int Cin, int Cout, int ks, int 
         if (k > 24) k = 24;
         if (k < 1) k = 1;
     }
+    // accuracy rule: one fp32 accumulator never sums more than ~2300 products (2x the 3x3 x 128-channel layers the
+    // per-op tolerance is calibrated on).  Only the dense 8x8 / 12x12 Lanczos convs of conv(..., 'lanczos*') at >= 72
+    // channels get here (K = 8192 at 128 channels: 4 slices, summed in fixed order by splitk_finish_kernel)
+    const int Kred = ks * ks * dip_round_up(Cin, 4);
+    if (Kred > 4608) {
+        int kmin = dip_cdiv(Kred, 2304);
+        if (kmin > units / 2) kmin = units / 2;
+        if (k < kmin) k = kmin;
+    }
     const int Cy = dip_round_up(Cout, 4);
     *ksplit = k;
     if (k > 1) {

@@ -95,7 +95,8 @@ class ScalePlan:
         self.cat_bn = self.up = self.up_bn = self.up1 = self.up1_bn = None
         self.ns = 0
         self.upsample_mode = "nearest"
-        self.pool = None                    # 'avg': down_a is a stride-1 conv followed by AvgPool2d(2, 2)
+        self.pool = None                    # 'avg' | 'max': down_a is a stride-1 conv followed by Avg/MaxPool2d(2, 2);
+        self.down_ds = None                 # 'lanczos': ... followed by the Downsampler's dense stride-2 conv (down_ds)
 
 
 class SkipEngine:
@@ -117,6 +118,7 @@ class SkipEngine:
         # than the ~8 us launch it would overlap)
         self.side_min_pixels = int(os.environ.get("DIP_SIDE_MIN_PIXELS", "0"))
         self._fwd_side, self._deferred, self._entered_defer_scale, self._fused_bnb = set(), [], False, {}
+        self._replicate_bufs = set()
         # BatchNorm-backward statistics in the epilogue of the data-gradient launch (DipConvDesc.bnb_*) instead of a pass
         # of their own: 18 launches and one pass over g fewer, but measured (round 3) as a wash -- the epilogue's
         # per-lane reads of y cost the big launches 35..75 us each, as much as the streaming statistics kernels they
@@ -134,10 +136,13 @@ class SkipEngine:
             rec = ScalePlan()
             rec.ns, rec.upsample_mode = s.ns, s.upsample_mode
             rec.pool = getattr(s, 'pool', None)
-            for attr in ("skip_conv", "down_a", "down_b", "up", "up1"):
-                m = getattr(s, attr)
+            for attr in ("skip_conv", "down_a", "down_ds", "down_b", "up", "up1"):
+                m = getattr(s, attr, None)
                 if m is not None:
                     r = ConvRec(m, self.pad_mode, f"s{i}.{attr}")
+                    if attr == "down_ds":       # Downsampler(preserve_size=True): nn.ReplicationPad2d((k - factor) / 2)
+                        r.P = (r.ks - r.stride) // 2
+                        r.pad_mode = N.PAD_REPLICATE
                     self.convs.append(r)
                     setattr(rec, attr, r)
             for attr in ("skip_bn", "down_a_bn", "down_b_bn", "cat_bn", "up_bn", "up1_bn"):
@@ -156,7 +161,8 @@ class SkipEngine:
     # ------------------------------------------------------------------ support matrix
     def _check_supported(self):
         for r in self.convs:
-            if r.ks not in (1, 3, 5, 7) or r.stride not in (1, 2) or (r.ks == 1 and r.stride != 1):
+            lanczos_ds = r.name.endswith(".down_ds") and r.ks in (8, 12) and r.stride == 2
+            if not lanczos_ds and (r.ks not in (1, 3, 5, 7) or r.stride not in (1, 2) or (r.ks == 1 and r.stride != 1)):
                 raise NotImplementedError(f"dip-amd: conv {r.name} k={r.ks} s={r.stride} has no gfx950 kernel")
             m = r.module
             if m.dilation != (1, 1) or m.groups != 1 or m.kernel_size[0] != m.kernel_size[1]:
@@ -279,6 +285,7 @@ class SkipEngine:
                 self.bwd_scratch3 = self._new(self.bwdp3_need)
             self._fused_bnb = {}
             self._deferred = []
+            self._replicate_bufs = set()
             self._fwd_side = set()
             self._entered_defer_scale = False
             self.x_nhwc = self._buf(H * W * round_up(Cin_img, 4))
@@ -319,6 +326,13 @@ class SkipEngine:
             st["d1_full"] = self._buf(H * W * round_up(s.down_a.Cout, 4))
             self._emit_conv_fwd(s.down_a, xin, st["d1_full"], None)
             self._emit_avgpool(st["d1_full"], H, W, s.down_a.Cout, st["d1_y"], s.down_a_bn, s.pool)
+        elif s.pool == 'lanczos':
+            # conv(..., downsample_mode='lanczos2' | 'lanczos3'), models/common.py:107-108: full-resolution conv (raw: no
+            # BatchNorm in between), then the Downsampler's dense k x k stride-2 conv behind nn.ReplicationPad2d
+            st["d1_full"] = self._buf(H * W * round_up(s.down_a.Cout, 4))
+            self._emit_conv_fwd(s.down_a, xin, st["d1_full"], None)
+            st["d1_raw"] = Act(st["d1_full"], H, W, s.down_a.Cout)
+            self._emit_conv_fwd(s.down_ds, st["d1_raw"], st["d1_y"], s.down_a_bn)
         else:
             self._emit_conv_fwd(s.down_a, xin, st["d1_y"], s.down_a_bn)
         d1 = Act(st["d1_y"], Hl, Wl, s.down_a.Cout, s.down_a_bn, self.slope)
@@ -483,7 +497,7 @@ class SkipEngine:
         when the launch is a one-pass one, and _emit_bn_act_bwd skips its statistics pass (self._fused_bnb)."""
         Ho = (x.H + 2 * r.P - r.ks) // r.stride + 1
         Wo = (x.W + 2 * r.P - r.ks) // r.stride + 1
-        reflect = r.pad_mode == N.PAD_REFLECT and r.P > 0
+        reflect = r.pad_mode in (N.PAD_REFLECT, N.PAD_REPLICATE) and r.P > 0      # gradient on the PADDED domain, folded later
         pad = r.P if reflect else 0
         Hg, Wg = x.H + 2 * pad, x.W + 2 * pad
         off = (r.ks - 1) if reflect else (r.ks - 1 - r.P)
@@ -531,6 +545,8 @@ class SkipEngine:
         if sizing:
             self.ws_need = max(self.ws_need, wsf)
             return (gbuf, pad)
+        if r.pad_mode == N.PAD_REPLICATE:
+            self._replicate_bufs.add(gbuf.data_ptr())       # _gradsrc: fold = 2 (adjoint of nn.ReplicationPad2d)
         if fused is not None:
             bn = x.bn
             d.bnb_y, d.bnb_state = _ptr(x.buf), _ptr(bn.state)
@@ -552,7 +568,8 @@ class SkipEngine:
 
     def _gradsrc(self, g, Cg, choff=0, window=None):
         buf, pad = g
-        d = N.DipGradSrc(_ptr(buf), pad, 1 if pad > 0 else 0, Cg, choff)
+        fold = 0 if pad == 0 else (2 if buf.data_ptr() in self._replicate_bufs else 1)
+        d = N.DipGradSrc(_ptr(buf), pad, fold, Cg, choff)
         if window is not None:                    # (win_y, win_x, win_h, win_w): adjoint of Concat's crop of this branch
             d.win_y, d.win_x, d.win_h, d.win_w = window
         self.keep.append(d)
@@ -660,6 +677,18 @@ class SkipEngine:
         self._emit_wgrad(s.down_b, st["d1"], dy_d2, ops, scale=i)
         g = self._emit_dgrad(s.down_b, st["d1"], dy_d2, ops, fuse_bn=True)
         dy_d1 = self._emit_bn_act_bwd(st["d1"], g, ops)
+        if s.pool == 'lanczos':             # backward of the Downsampler's dense conv: its weight gradient, then the data
+            # gradient on the replication-padded domain folded into dy of the full-resolution conv's (raw) output
+            Cs1 = round_up(s.down_a.Cout, 4)
+            raw = st["d1_raw"]
+            self._emit_wgrad(s.down_ds, raw, dy_d1, ops, scale=i)
+            g2 = self._emit_dgrad(s.down_ds, raw, dy_d1, ops)
+            dy_full = self._buf(H * W * Cs1)
+            if not self._sizing:
+                src = self._gradsrc(g2, Cs1)
+                ops.append((self.lib.dip_fold_to_nhwc, (C.byref(src), H, W, s.down_a.Cout, _ptr(dy_full), Cs1),
+                            "fold:" + s.down_ds.name))
+            dy_d1 = dy_full
         if s.pool in ('avg', 'max'):        # adjoint of the pooling: dy of the full-resolution conv output
             Cs1 = round_up(s.down_a.Cout, 4)
             dy_full = self._buf(H * W * Cs1)

@@ -103,7 +103,7 @@ def conv(in_f, out_f, kernel_size, stride=1, bias=True, pad='zero', downsample_m
             pool = nn.MaxPool2d(stride, stride)
         elif downsample_mode in ('lanczos2', 'lanczos3'):
             pool = Downsampler(n_planes=out_f, factor=stride, kernel_type=downsample_mode, phase=0.5,
-                               preserve_size=True)
+                               preserve_size=True, _dense=True)
         else:
             raise AssertionError(downsample_mode)
         stride = 1

@@ -98,8 +98,13 @@ class _LanczosFn(torch.autograd.Function):
 
 class Downsampler(nn.Module):
     def __init__(self, n_planes, factor, kernel_type, phase=0, kernel_width=None, support=None, sigma=None,
-                 preserve_size=False):
+                 preserve_size=False, _dense=False):
         super().__init__()
+        # _dense (models.common.conv only): the module sits INSIDE a skip() net (conv(..., downsample_mode='lanczos2')),
+        # where the reference trains its dense n_planes x n_planes x k x k weight with the rest of net.parameters()
+        # (models/common.py:107-108): dip_engine runs it as a stride-`factor` convolution with replication padding and
+        # returns its weight gradient; the parameters stay trainable and the fixed-taps check does not apply
+        self._dense = _dense
         assert phase in [0, 0.5], 'phase should be 0 or 0.5'
         if kernel_type in _PRESETS:
             p = _PRESETS[kernel_type]
@@ -122,8 +127,9 @@ class Downsampler(nn.Module):
         # the HIP path applies FIXED taps and returns no weight gradient: say so on the parameters themselves, so that an
         # optimiser handed `downsampler.parameters()` directly (not through get_params('down'), which makes forward()
         # raise) sees tensors that do not require grad instead of silently training nothing
-        holder.weight.requires_grad_(False)
-        holder.bias.requires_grad_(False)
+        if not _dense:
+            holder.weight.requires_grad_(False)
+            holder.bias.requires_grad_(False)
         self.downsampler_ = holder
         self.register_buffer('_taps', kt.to(torch.float32).contiguous(), persistent=False)
         self.register_load_state_dict_post_hook(Downsampler._taps_from_weight)
@@ -136,6 +142,8 @@ class Downsampler(nn.Module):
     def _taps_from_weight(self, *_):
         """load_state_dict post-hook: the native path applies `_taps`, so re-derive them from the loaded
         dense weight and refuse anything that is not one 2-D kernel on the channel diagonal."""
+        if getattr(self, "_dense", False):        # inside a skip() net: the engine convolves with the dense weight itself
+            return
         w = self.downsampler_.weight.detach()
         b = self.downsampler_.bias.detach()
         n = w.shape[0]
@@ -149,6 +157,9 @@ class Downsampler(nn.Module):
         self._taps = diag[0].to(torch.float32).contiguous().to(self._taps.device)
 
     def forward(self, input):
+        if getattr(self, "_dense", False):
+            raise RuntimeError("dip-amd: this Downsampler belongs to a skip() net (conv(..., downsample_mode='lanczos*')); "
+                               "it runs as part of the net's launch list, not on its own")
         if getattr(self, "_dip_optimised", False):
             raise NotImplementedError("dip-amd: optimising the down-sampler kernel (opt_over='down') is not "
                                       "implemented: the HIP path applies the fixed taps and returns no weight gradient")

@@ -61,7 +61,7 @@ def _attach_engine(model, scale_paths, out_path, need_sigmoid, pad, act_fun):
         s.ns, s.upsample_mode = sp['ns'], sp['upsample_mode']
         s.pool = sp.get('pool')
         for k in ('skip_conv', 'skip_bn', 'down_a', 'down_a_bn', 'down_b', 'down_b_bn', 'cat_bn', 'up', 'up_bn',
-                  'up1', 'up1_bn'):
+                  'up1', 'up1_bn', 'down_ds'):
             setattr(s, k, at(sp[k]) if sp.get(k) is not None else None)
         scales.append(s)
     model.__dict__['_dip_spec'] = (scale_paths, out_path, need_sigmoid, pad, act_fun)
@@ -146,11 +146,13 @@ def skip(
         sp['pool'] = None
         if downsample_mode[i] in ('avg', 'max'):
             sp['pool'] = downsample_mode[i]     # stride-1 conv + AvgPool2d / MaxPool2d(2, 2): dip_{avg,max}pool2_fwd/bwd
+        elif downsample_mode[i] in ('lanczos2', 'lanczos3'):
+            # the reference puts a Downsampler with a TRAINABLE dense nd x nd x 8 x 8 (12 x 12) stride-2 conv weight
+            # behind the stride-1 conv (models/common.py:107-110): the engine runs it as a convolution of its own
+            # (replication padding, ScalePlan.down_ds); the BatchNorm that follows normalises ITS output
+            sp['pool'] = 'lanczos'
         elif downsample_mode[i] != 'stride':
-            # 'lanczos2' / 'lanczos3': the reference puts a Downsampler with a TRAINABLE dense nf x nf x 8 x 8
-            # (12 x 12) conv weight behind the stride-1 conv (models/common.py:107-110): no kernel for that
-            sp['unsupported'] = (f"downsample_mode={downsample_mode[i]!r} (a trainable dense Lanczos Downsampler "
-                                 "after a stride-1 conv) has no gfx950 kernel")
+            sp['unsupported'] = f"downsample_mode={downsample_mode[i]!r} has no gfx950 kernel"
 
         inner = nn.Sequential()
         if i != n - 1:
@@ -191,6 +193,12 @@ def skip(
         raise AssertionError(p)
 
     for sp in scale_paths:
+        if sp.get('pool') == 'lanczos':       # conv() = Sequential([pad], Conv2d, Downsampler): its dense holder conv
+            blk = model
+            for name in sp['down_a']:
+                blk = blk._modules[name]
+            ds = [name for name, m in blk._modules.items() if type(m).__name__ == 'Downsampler']
+            sp['down_ds'] = sp['down_a'] + [ds[0], 'downsampler_']
         for k in ('skip_conv', 'down_a', 'down_b', 'up', 'up1'):
             if sp.get(k) is not None:
                 sp[k] = conv_path(sp[k])

@@ -63,7 +63,7 @@ class SkipSpec:
     pad: str = "zero"
     upsample_mode: Sequence[str] | str = "nearest"
     need1x1_up: bool = True
-    downsample_mode: Sequence[str] | str = "stride"      # 'stride' | 'avg' | 'max' (models/common.py:99-112)
+    downsample_mode: Sequence[str] | str = "stride"      # 'stride' | 'avg' | 'max' | 'lanczos2' | 'lanczos3' (models/common.py:99-112)
     act_fun: str = "LeakyReLU"                           # 'LeakyReLU' | 'Swish' | 'ELU' | 'none' (models/common.py:76-92)
 
     def __post_init__(self):
@@ -105,6 +105,7 @@ class ScaleKeys:
     skip_conv: Optional[str]
     skip_bn: Optional[str]
     down_a: str
+    down_a_ds: Optional[str]          # the Downsampler's dense Conv2d behind down_a (downsample_mode 'lanczos2' | 'lanczos3')
     down_a_bn: str
     down_b: str
     down_b_bn: str
@@ -128,7 +129,11 @@ def scale_keys(spec: SkipSpec) -> (List[ScaleKeys], str):
         k = ScaleKeys(
             skip_conv=_conv_key(sk, 1, spec.pad) if has_skip else None,
             skip_bn=(sk + "2") if has_skip else None,
-            down_a=_conv_key(dp, 1, spec.pad), down_a_bn=dp + "2",
+            down_a=_conv_key(dp, 1, spec.pad),
+            # conv() = Sequential([padder], Conv2d, Downsampler): the Downsampler follows the Conv2d (models/common.py:122-123)
+            down_a_ds=(f"{dp}1.{2 if spec.pad == 'reflection' else 1}.downsampler_"
+                       if spec.downsample_mode[i] in ("lanczos2", "lanczos3") else None),
+            down_a_bn=dp + "2",
             down_b=_conv_key(dp, 4, spec.pad), down_b_bn=dp + "5",
             cat_bn=P + "2",
             up=_conv_key(P, 3, spec.pad), up_bn=P + "4",
@@ -140,6 +145,12 @@ def scale_keys(spec: SkipSpec) -> (List[ScaleKeys], str):
     n_top = 2 + 3 + (3 if spec.need1x1_up else 0)        # children "1".."n_top" of the top Sequential
     out_key = _conv_key("", n_top + 1, spec.pad)
     return keys, out_key
+
+
+def lanczos_ds_width(mode: str, factor: int = 2) -> int:
+    """Filter width of Downsampler(factor, 'lanczos2' | 'lanczos3', phase=0.5): kernel_width = 4*factor+1 | 6*factor+1
+    (models/downsampler.py:14-22), one less for phase 0.5 (get_kernel, :77-78)."""
+    return (4 if mode == "lanczos2" else 6) * factor
 
 
 def param_shapes(spec: SkipSpec) -> Dict[str, tuple]:
@@ -165,6 +176,10 @@ def param_shapes(spec: SkipSpec) -> Dict[str, tuple]:
             conv(k.skip_conv, cin, ns, spec.filter_skip_size)
             bn(k.skip_bn, ns)
         conv(k.down_a, cin, nd, spec.filter_size_down[i]); bn(k.down_a_bn, nd)
+        if k.down_a_ds is not None:          # Downsampler(n_planes=nd, factor=2, ...): dense nd x nd conv, bias always present
+            kw = lanczos_ds_width(spec.downsample_mode[i])
+            shapes[k.down_a_ds + ".weight"] = (nd, nd, kw, kw)
+            shapes[k.down_a_ds + ".bias"] = (nd,)
         conv(k.down_b, nd, nd, spec.filter_size_down[i]); bn(k.down_b_bn, nd)
         bn(k.cat_bn, ns + kdeep)
         conv(k.up, ns + kdeep, nu, spec.filter_size_up[i]); bn(k.up_bn, nu)
@@ -245,6 +260,13 @@ def skip_forward(spec: SkipSpec, sd: Dict[str, torch.Tensor], x: torch.Tensor,
             d = _conv(x, sd, k.down_a, fd, 2, spec.pad)
         elif spec.downsample_mode[i] == "avg":   # conv(): stride-1 conv followed by nn.AvgPool2d(2, 2), common.py:101-104
             d = F.avg_pool2d(_conv(x, sd, k.down_a, fd, 1, spec.pad), 2, 2)
+        elif spec.downsample_mode[i] in ("lanczos2", "lanczos3"):
+            # ... or Downsampler(n_planes=out_f, factor=2, kernel_type, phase=0.5, preserve_size=True), common.py:107-108:
+            # ReplicationPad2d((k - factor) / 2) + a dense (trainable) Conv2d(out_f, out_f, k, stride=2), downsampler.py:44-71
+            d = _conv(x, sd, k.down_a, fd, 1, spec.pad)
+            wds = sd[k.down_a_ds + ".weight"]
+            p = (wds.shape[-1] - 2) // 2
+            d = F.conv2d(F.pad(d, (p,) * 4, mode="replicate"), wds, sd[k.down_a_ds + ".bias"], stride=2)
         else:                               # ... or nn.MaxPool2d(2, 2), common.py:105-106
             assert spec.downsample_mode[i] == "max", spec.downsample_mode[i]
             d = F.max_pool2d(_conv(x, sd, k.down_a, fd, 1, spec.pad), 2, 2)

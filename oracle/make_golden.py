@@ -94,6 +94,16 @@ NETS = {
                             kw=dict(num_channels_down=[16, 16, 16], num_channels_up=[16, 16, 16],
                                     num_channels_skip=[4, 0, 0], upsample_mode="bilinear",
                                     need_sigmoid=True, need_bias=True, pad="reflection")),
+    # conv(..., downsample_mode='lanczos2' | 'lanczos3') (models/common.py:107-108): a stride-1 conv followed by a
+    # Downsampler whose dense 8x8 / 12x12 stride-2 Conv2d is part of net.parameters() and is trained
+    "tiny_lanczos2": dict(args=(8, 3), hw=(32, 48), seed=16,
+                          kw=dict(num_channels_down=[16, 16], num_channels_up=[16, 16], num_channels_skip=[4, 4],
+                                  upsample_mode="bilinear", downsample_mode="lanczos2",
+                                  need_sigmoid=True, need_bias=True, pad="reflection")),
+    "tiny_lanczos3": dict(args=(8, 3), hw=(32, 32), seed=17,
+                          kw=dict(num_channels_down=[8, 16], num_channels_up=[8, 16], num_channels_skip=[4, 4],
+                                  upsample_mode="nearest", downsample_mode=["lanczos3", "lanczos2"],
+                                  need_sigmoid=True, need_bias=True, pad="zero")),
     # feature_inversion.ipynb:169-174: per-scale filter sizes 7 / 5 / 3, zero padding, avg-pool
     # down-sampling, nearest up-sampling, meshgrid input
     "tiny_feat7": dict(args=(2, 3), hw=(32, 48), seed=7,
@@ -141,6 +151,9 @@ def gen_net(name, cfg):
     # optimize('adam') trajectory, utils/common_utils.py:223-230, closure in the notebook style
     mse = torch.nn.MSELoss()
     # optimize() creates a fresh Adam every call, so run it once for 1 step on a clone and once for 3
+    for m in net.modules():               # Downsampler.forward keeps its padded input on self.x (models/downsampler.py:70):
+        if hasattr(m, "x") and torch.is_tensor(m.x):      # a non-leaf tensor that deepcopy refuses
+            m.x = None
     for nsteps in (1, 3):
         net2 = copy.deepcopy(net)
 

@@ -93,7 +93,7 @@ def conv_dgrad(dy, w, stride, pad_mode, Hin, Win, split=False):
     Cout, Cin, ks, _ = w.shape
     P = (ks - 1) // 2
     _, _, Ho, Wo = dy.shape
-    reflect = pad_mode == N.PAD_REFLECT and P > 0
+    reflect = pad_mode in (N.PAD_REFLECT, N.PAD_REPLICATE) and P > 0
     pad = P if reflect else 0
     Hg, Wg = Hin + 2 * pad, Win + 2 * pad
     off = (ks - 1) if reflect else (ks - 1 - P)
@@ -114,7 +114,7 @@ def conv_dgrad(dy, w, stride, pad_mode, Hin, Win, split=False):
                       packed.data_ptr() + 4 * do, None, g.data_ptr(), Hg, Wg, Cg, Cin, 0, ks, 1, N.PAD_ZERO, off,
                       stride, 0, None, ksplit, ws.data_ptr() if ksplit > 1 else None)
     N.check(lib.dip_conv_igemm(C.byref(d), stream(dev)), "conv_igemm(dgrad)")
-    src = N.DipGradSrc(g.data_ptr(), pad, 1 if pad else 0, Cg, 0)
+    src = N.DipGradSrc(g.data_ptr(), pad, (2 if pad_mode == N.PAD_REPLICATE else 1) if pad else 0, Cg, 0)
     gx = torch.empty(1, Cin, Hin, Win, dtype=torch.float32, device=dev)
     N.check(lib.dip_fold_to_nchw(C.byref(src), Hin, Win, Cin, gx.data_ptr(), stream(dev)), "fold")
     torch.cuda.synchronize()

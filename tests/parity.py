@@ -62,6 +62,8 @@ def zero_grad_keys(spec, sd=None):
             for c in (k.skip_conv, k.down_a, k.down_b, k.up, k.up1):
                 if c is not None:
                     out.add(c + ".bias")
+        if getattr(k, "down_a_ds", None):       # the Downsampler's conv (always biased) feeds the BatchNorm directly
+            out.add(k.down_a_ds + ".bias")
         # beta of the BatchNorm over the concat: it feeds (without an activation) the reflection-padded
         # decoder conv, whose output BatchNorm removes the per-channel constant a constant input shift
         # produces (with zero padding the border breaks this, so only for pad == 'reflection')

@@ -223,9 +223,11 @@ def test_no_silent_fallback():
     bad = skip(4, 3, [8, 8], [8, 8], [4, 4], act_fun=torch.nn.Tanh)          # (LeakyReLU / Swish / ELU / none have kernels)
     with pytest.raises(NotImplementedError):
         bad(torch.zeros(1, 4, 16, 16))
-    mx = skip(4, 3, [8, 8], [8, 8], [4, 4], downsample_mode="lanczos2")     # ('avg' / 'max' have kernels, Lanczos does not)
-    with pytest.raises(NotImplementedError):
+    mx = skip(4, 3, [8, 8], [8, 8], [4, 4], downsample_mode="lanczos2")     # has kernels since round 3: same loud CPU error
+    with pytest.raises(RuntimeError, match="MI355X"):
         mx(torch.zeros(1, 4, 16, 16))
+    with pytest.raises(RuntimeError, match="launch list"):                  # its Downsampler is not a stand-alone module
+        [m for m in mx.modules() if type(m).__name__ == "Downsampler"][0](torch.zeros(1, 8, 16, 16))
     with pytest.raises(NotImplementedError):
         get_net(3, "UNet", "zero", "nearest")
     # missing shared library -> loud error

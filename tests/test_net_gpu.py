@@ -65,6 +65,13 @@ NETS = {
     "tiny_noskipcrop": dict(args=(8, 3), kw=dict(num_channels_down=[16, 16, 16], num_channels_up=[16, 16, 16],
                                                  num_channels_skip=[4, 0, 0], upsample_mode="bilinear",
                                                  need_sigmoid=True, need_bias=True, pad="reflection")),
+    # Lanczos down-sampling inside conv(): trainable dense 8x8 / 12x12 stride-2 convs (models/common.py:107-108)
+    "tiny_lanczos2": dict(args=(8, 3), kw=dict(num_channels_down=[16, 16], num_channels_up=[16, 16], num_channels_skip=[4, 4],
+                                               upsample_mode="bilinear", downsample_mode="lanczos2",
+                                               need_sigmoid=True, need_bias=True, pad="reflection")),
+    "tiny_lanczos3": dict(args=(8, 3), kw=dict(num_channels_down=[8, 16], num_channels_up=[8, 16], num_channels_skip=[4, 4],
+                                               upsample_mode="nearest", downsample_mode=["lanczos3", "lanczos2"],
+                                               need_sigmoid=True, need_bias=True, pad="zero")),
     "tiny_feat7": dict(args=(2, 3), kw=dict(num_channels_down=[8, 16, 16], num_channels_up=[8, 16, 16],
                                             num_channels_skip=[4, 4, 4], filter_size_down=[7, 5, 3],
                                             filter_size_up=[7, 5, 3], upsample_mode="nearest", downsample_mode="avg",
