@@ -233,6 +233,105 @@ __global__ __launch_bounds__(256) void lanczos_bwd_kernel(const float* __restric
     gx[id] = acc;
 }
 
+// ---------------------------------------------------------------- dense down-sampler (NCHW): opt_over='down'
+// The reference's Downsampler IS a dense Conv2d(n, n, k, stride=f) behind ReplicationPad2d; get_params('down', ...)
+// hands its weight to the optimiser (utils/common_utils.py:44-46).  n is 3 (or 1) image planes, k = 4f or 6f: a few
+// MFLOP per call, so these are plain gather kernels -- one thread per output element, fixed summation order.
+__global__ __launch_bounds__(256) void down_dense_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ y,
+                                                             int C, int H, int W, int k, int f, int pad, int Ho, int Wo) {
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= C * Ho * Wo) return;
+    const int ox = id % Wo, oy = (id / Wo) % Ho, o = id / (Wo * Ho);
+    float acc = bias != nullptr ? bias[o] : 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float* xc = x + (size_t)c * H * W;
+        const float* wc = w + ((size_t)o * C + c) * k * k;
+        for (int i = 0; i < k; ++i) {
+            const int sy = min(max(oy * f + i - pad, 0), H - 1);
+            for (int j = 0; j < k; ++j) {
+                const int sx = min(max(ox * f + j - pad, 0), W - 1);
+                acc = fmaf(wc[i * k + j], xc[(size_t)sy * W + sx], acc);
+            }
+        }
+    }
+    y[id] = acc;
+}
+
+// gradient wrt the input: the gather form of lanczos_bwd_kernel with the sum over output planes added
+__global__ __launch_bounds__(256) void down_dense_bwd_data_kernel(const float* __restrict__ gy, const float* __restrict__ w,
+                                                                  float* __restrict__ gx, int C, int H, int W, int k,
+                                                                  int f, int pad, int Ho, int Wo) {
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= C * H * W) return;
+    const int sx = id % W, sy = (id / W) % H, c = id / (W * H);
+    const int ylo = (sy == 0) ? -pad : sy, yhi = (sy == H - 1) ? H - 1 + pad : sy;
+    const int xlo = (sx == 0) ? -pad : sx, xhi = (sx == W - 1) ? W - 1 + pad : sx;
+    float acc = 0.f;
+    for (int o = 0; o < C; ++o) {
+        const float* g = gy + (size_t)o * Ho * Wo;
+        const float* wc = w + ((size_t)o * C + c) * k * k;
+        for (int py = ylo; py <= yhi; ++py) {
+            const int t = py + pad;
+            const int oy_hi = min(t / f, Ho - 1);
+            const int oy_lo = max((t - k + 1 + f - 1) / f, 0);
+            for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+                const int i = t - oy * f;
+                if (i < 0 || i >= k) continue;
+                for (int px = xlo; px <= xhi; ++px) {
+                    const int u = px + pad;
+                    const int ox_hi = min(u / f, Wo - 1);
+                    const int ox_lo = max((u - k + 1 + f - 1) / f, 0);
+                    for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                        const int j = u - ox * f;
+                        if (j < 0 || j >= k) continue;
+                        acc = fmaf(wc[i * k + j], g[(size_t)oy * Wo + ox], acc);
+                    }
+                }
+            }
+        }
+    }
+    gx[id] = acc;
+}
+
+// gradient wrt weight and bias: block (o, c, i, j) sums gy[o][p] * xpad[c][p*f + (i, j)] over the output pixels p
+// (thread t takes p = t, t + 256, ...; fixed-order tree over the 256 partial sums); blocks >= C*C*k*k sum gy[o] alone
+__global__ __launch_bounds__(256) void down_dense_bwd_weight_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                                    float* __restrict__ dw, float* __restrict__ db, int C,
+                                                                    int H, int W, int k, int f, int pad, int Ho, int Wo) {
+    __shared__ float sh[256];
+    const int nw = C * C * k * k;
+    const int b = blockIdx.x;
+    const bool is_bias = b >= nw;
+    int o, c = 0, i = 0, j = 0;
+    if (is_bias) {
+        o = b - nw;
+    } else {
+        j = b % k; i = (b / k) % k; c = (b / (k * k)) % C; o = b / (k * k * C);
+    }
+    const float* g = gy + (size_t)o * Ho * Wo;
+    const float* xc = x + (size_t)c * H * W;
+    float acc = 0.f;
+    for (int p = threadIdx.x; p < Ho * Wo; p += 256) {
+        const int oy = p / Wo, ox = p - oy * Wo;
+        float xv = 1.f;
+        if (!is_bias) {
+            const int sy = min(max(oy * f + i - pad, 0), H - 1), sx = min(max(ox * f + j - pad, 0), W - 1);
+            xv = xc[(size_t)sy * W + sx];
+        }
+        acc = fmaf(g[p], xv, acc);
+    }
+    sh[threadIdx.x] = acc;
+    for (int s = 128; s >= 1; s >>= 1) {
+        __syncthreads();
+        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    }
+    if (threadIdx.x == 0) {
+        if (is_bias) { if (db != nullptr) db[o] = sh[0]; }
+        else dw[b] = sh[0];
+    }
+}
+
 }  // namespace
 
 extern "C" int dip_nchw_to_nhwc(const float* src, float* dst, int C, int HW, int Cs, void* stream) {
@@ -339,6 +438,32 @@ extern "C" int dip_lanczos_down_bwd(const float* gy, const float* taps, float* g
     const int Ho = (H + 2 * pad - k) / factor + 1, Wo = (W + 2 * pad - k) / factor + 1;
     hipLaunchKernelGGL(lanczos_bwd_kernel, dim3(dip_cdiv(C * H * W, 256)), dim3(256), 0, (hipStream_t)stream, gy,
                        taps, gx, C, H, W, k, factor, pad, Ho, Wo);
+    DIP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dip_down_dense_fwd(const float* x, const float* w, const float* bias, float* y, int C, int H, int W, int k,
+                                  int factor, int pad, void* stream) {
+    const int Ho = (H + 2 * pad - k) / factor + 1, Wo = (W + 2 * pad - k) / factor + 1;
+    if (Ho < 1 || Wo < 1) DIP_FAIL("down_dense_fwd: empty output");
+    hipLaunchKernelGGL(down_dense_fwd_kernel, dim3(dip_cdiv(C * Ho * Wo, 256)), dim3(256), 0, (hipStream_t)stream, x, w,
+                       bias, y, C, H, W, k, factor, pad, Ho, Wo);
+    DIP_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int dip_down_dense_bwd_data(const float* gy, const float* w, float* gx, int C, int H, int W, int k, int factor,
+                                       int pad, void* stream) {
+    const int Ho = (H + 2 * pad - k) / factor + 1, Wo = (W + 2 * pad - k) / factor + 1;
+    hipLaunchKernelGGL(down_dense_bwd_data_kernel, dim3(dip_cdiv(C * H * W, 256)), dim3(256), 0, (hipStream_t)stream, gy,
+                       w, gx, C, H, W, k, factor, pad, Ho, Wo);
+    DIP_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int dip_down_dense_bwd_weight(const float* gy, const float* x, float* dw, float* db, int C, int H, int W, int k,
+                                         int factor, int pad, void* stream) {
+    const int Ho = (H + 2 * pad - k) / factor + 1, Wo = (W + 2 * pad - k) / factor + 1;
+    hipLaunchKernelGGL(down_dense_bwd_weight_kernel, dim3(C * C * k * k + C), dim3(256), 0, (hipStream_t)stream, gy, x, dw,
+                       db, C, H, W, k, factor, pad, Ho, Wo);
     DIP_CHECK_LAUNCH();
     return 0;
 }

@@ -154,6 +154,12 @@ _SIGS = {
                                        C.c_int, C.c_int, C.c_void_p]),
     "dip_lanczos_down_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_int, C.c_int, C.c_void_p]),
+    "dip_down_dense_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_int, C.c_void_p]),
+    "dip_down_dense_bwd_data": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.c_int, C.c_void_p]),
+    "dip_down_dense_bwd_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                            C.c_int, C.c_int, C.c_int, C.c_void_p]),
 }
 
 EXPORTS = tuple(_SIGS.keys())

@@ -6,13 +6,14 @@ weight is the 2-D tap table on the channel diagonal (2/3 of the MACs multiply ze
 registers the fixed taps as trainable parameters.  Here the same taps (float64 numpy, then fp32)
 drive `dip_lanczos_down_fwd/bwd`: one depth-wise stencil with clamped (replicated) borders.
 `downsampler_.weight/bias` are kept as parameters so `state_dict()`, `get_params('down', ...)` and
-`.type(dtype)` have the reference's shape; the native path reads the taps, not the dense weight:
-  * `load_state_dict()` re-derives the taps from the loaded weight and refuses a weight that is not
-    "one 2-D kernel on the channel diagonal, zero bias" (what every reference constructor builds);
-  * OPTIMISING the down-sampler (opt_over containing 'down', utils/common_utils.py:44-46 of the
-    reference -- no notebook does) would train the dense 3x3xkxk weight; there is no kernel for that,
-    so `get_params('down', ...)` marks the module and forward() raises instead of silently
-    optimising nothing.
+`.type(dtype)` have the reference's shape.  The depth-wise path reads the taps, not the dense weight, so:
+  * the parameters do not require grad by default (the fixed-taps kernels return no weight gradient);
+  * OPTIMISING the down-sampler (opt_over containing 'down', utils/common_utils.py:44-46 of the reference -- no
+    notebook does): `get_params('down', ...)` turns requires_grad on, and forward() then runs the module as what the
+    reference's is -- a dense Conv2d(n, n, k, stride=factor) behind the replication padding -- through
+    `dip_down_dense_fwd / _bwd_data / _bwd_weight`, with gradients for weight and bias;
+  * `load_state_dict()` re-derives the taps from the loaded weight; a weight that is not "one 2-D kernel on the channel
+    diagonal, zero bias" any more (a trained down-sampler) switches the module to the dense path as well.
 """
 import numpy as np
 import torch
@@ -96,6 +97,50 @@ class _LanczosFn(torch.autograd.Function):
         return gx, None, None, None, None
 
 
+class _DenseFn(torch.autograd.Function):
+    """ReplicationPad2d(pad) + Conv2d(n, n, k, stride=factor) with trainable weight / bias (models/downsampler.py:88-101
+    of the reference when its parameters are optimised)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, k, factor, pad):
+        import dip_native as N
+        lib = N.lib()
+        _, C, H, W = x.shape
+        Ho, Wo = (H + 2 * pad - k) // factor + 1, (W + 2 * pad - k) // factor + 1
+        xs = x.detach().contiguous().float()
+        w = weight.detach().contiguous().float()
+        b = bias.detach().contiguous().float()
+        y = torch.empty((1, C, Ho, Wo), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            st = torch.cuda.current_stream(x.device).cuda_stream
+            N.check(lib.dip_down_dense_fwd(xs.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), C, H, W, k, factor, pad,
+                                           st), "down_dense_fwd")
+        ctx.save_for_backward(xs, w)
+        ctx.meta = (k, factor, pad, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        import dip_native as N
+        lib = N.lib()
+        xs, w = ctx.saved_tensors
+        k, factor, pad, C, H, W = ctx.meta
+        g = gy.detach().contiguous().float()
+        gx = dw = db = None
+        with torch.cuda.device(gy.device):
+            st = torch.cuda.current_stream(gy.device).cuda_stream
+            if ctx.needs_input_grad[0]:
+                gx = torch.empty((1, C, H, W), dtype=torch.float32, device=gy.device)
+                N.check(lib.dip_down_dense_bwd_data(g.data_ptr(), w.data_ptr(), gx.data_ptr(), C, H, W, k, factor, pad, st),
+                        "down_dense_bwd_data")
+            if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+                dw = torch.empty_like(w)
+                db = torch.empty((C,), dtype=torch.float32, device=gy.device)
+                N.check(lib.dip_down_dense_bwd_weight(g.data_ptr(), xs.data_ptr(), dw.data_ptr(), db.data_ptr(), C, H, W, k,
+                                                      factor, pad, st), "down_dense_bwd_weight")
+        return gx, dw, db, None, None, None
+
+
 class Downsampler(nn.Module):
     def __init__(self, n_planes, factor, kernel_type, phase=0, kernel_width=None, support=None, sigma=None,
                  preserve_size=False, _dense=False):
@@ -124,9 +169,9 @@ class Downsampler(nn.Module):
         kt = torch.from_numpy(self.kernel)
         for c in range(n_planes):
             holder.weight.data[c, c] = kt
-        # the HIP path applies FIXED taps and returns no weight gradient: say so on the parameters themselves, so that an
-        # optimiser handed `downsampler.parameters()` directly (not through get_params('down'), which makes forward()
-        # raise) sees tensors that do not require grad instead of silently training nothing
+        # the depth-wise path applies FIXED taps and returns no weight gradient: say so on the parameters themselves.
+        # get_params('down', ...) -- or the user -- turns requires_grad on, and forward() then takes the dense path
+        self._nondiag = False
         if not _dense:
             holder.weight.requires_grad_(False)
             holder.bias.requires_grad_(False)
@@ -151,20 +196,22 @@ class Downsampler(nn.Module):
         off = w.clone()
         for c in range(n):
             off[c, c] = 0
-        if float(off.abs().max()) != 0 or float(b.abs().max()) != 0 or float((diag - diag[0]).abs().max()) != 0:
-            raise NotImplementedError("dip-amd: Downsampler weights other than one 2-D kernel on the channel "
-                                      "diagonal with zero bias have no gfx950 kernel")
-        self._taps = diag[0].to(torch.float32).contiguous().to(self._taps.device)
+        # a trained down-sampler (anything but one 2-D kernel on the channel diagonal, zero bias): dense path from now on
+        self._nondiag = bool(float(off.abs().max()) != 0 or float(b.abs().max()) != 0
+                             or float((diag - diag[0]).abs().max()) != 0)
+        if not self._nondiag:
+            self._taps = diag[0].to(torch.float32).contiguous().to(self._taps.device)
 
     def forward(self, input):
         if getattr(self, "_dense", False):
             raise RuntimeError("dip-amd: this Downsampler belongs to a skip() net (conv(..., downsample_mode='lanczos*')); "
                                "it runs as part of the net's launch list, not on its own")
-        if getattr(self, "_dip_optimised", False):
-            raise NotImplementedError("dip-amd: optimising the down-sampler kernel (opt_over='down') is not "
-                                      "implemented: the HIP path applies the fixed taps and returns no weight gradient")
         if not input.is_cuda:
             raise RuntimeError("dip-amd: Downsampler runs on an MI355X only (no CPU fallback in this backend)")
         if input.dim() != 4 or input.shape[0] != 1:
             raise NotImplementedError("dip-amd: Downsampler expects a [1,C,H,W] tensor")
+        w, b = self.downsampler_.weight, self.downsampler_.bias
+        if w.requires_grad or b.requires_grad or getattr(self, "_nondiag", False):
+            self._nondiag = True        # once handed to an optimiser the weight is no longer known to equal the taps
+            return _DenseFn.apply(input, w, b, self.kernel.shape[0], self.factor, self._pad)
         return _LanczosFn.apply(input, self._taps.to(input.device), self.kernel.shape[0], self.factor, self._pad)

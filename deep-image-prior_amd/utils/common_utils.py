@@ -131,8 +131,8 @@ def get_params(opt_over, net, net_input, downsampler=None):
         elif opt == 'down':
             assert downsampler is not None
             params = [x for x in downsampler.parameters()]
-            if hasattr(downsampler, "downsampler_"):      # dip-amd Downsampler: fixed taps, see models/downsampler.py
-                downsampler._dip_optimised = True
+            for x in params:        # dip-amd Downsampler: fixed taps unless its parameters require grad (models/downsampler.py)
+                x.requires_grad_(True)
         elif opt == 'input':
             net_input.requires_grad = True
             params += [net_input]

@@ -390,6 +390,16 @@ int dip_lanczos_down_fwd(const float* x, const float* taps, float* y, int C, int
                          int factor, int pad, void* stream);
 int dip_lanczos_down_bwd(const float* gy, const float* taps, float* gx, int C, int H, int W, int k,
                          int factor, int pad, void* stream);
+/* The same module with its dense weight being optimised -- get_params('down', ...), utils/common_utils.py:44-46:
+ * ReplicationPad2d(pad) + Conv2d(C, C, k, stride=factor) with weight w [C][C][k][k] (OIHW) and bias [C] (may be NULL),
+ * models/downsampler.py:88-101; NCHW.  _bwd_data: autograd's gradient wrt the input, _bwd_weight: wrt weight (dw, same
+ * layout as w) and bias (db, may be NULL); x is the UNPADDED input of the forward. */
+int dip_down_dense_fwd(const float* x, const float* w, const float* bias, float* y, int C, int H, int W, int k,
+                       int factor, int pad, void* stream);
+int dip_down_dense_bwd_data(const float* gy, const float* w, float* gx, int C, int H, int W, int k, int factor,
+                            int pad, void* stream);
+int dip_down_dense_bwd_weight(const float* gy, const float* x, float* dw, float* db, int C, int H, int W, int k,
+                              int factor, int pad, void* stream);
 
 #ifdef __cplusplus
 }

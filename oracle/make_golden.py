@@ -7,6 +7,7 @@ Outputs (all float32 unless noted, produced by /root/reference code on torch CPU
                                 out, loss, every gradient, parameters after 1 and after 3
                                 optimize('adam') iterations (utils/common_utils.py:223-230)
   tests/golden/downsampler.npz  Downsampler(3,4,'lanczos2',0.5,preserve_size) taps, fwd, bwd
+  tests/golden/downsampler_dense.npz  the same module as a trainable dense conv (opt_over='down')
   tests/golden/get_noise.npz    get_noise() draws for fixed seeds
   tests/golden/default64_digest.json  digests of the FULL default net (2 217 831 params,
                                 torch.manual_seed(0) construction) at 64x64: pins parameter
@@ -193,6 +194,51 @@ def gen_downsampler():
     print("downsampler.npz")
 
 
+def gen_downsampler_dense():
+    """opt_over='down' (utils/common_utils.py:44-46): the Downsampler's dense Conv2d weight is what gets optimised.
+    Vectors: forward / input gradient / weight and bias gradients at a weight that is NOT on the channel diagonal any
+    more, and the parameters after 3 optimize('adam') steps over get_params('down', ...)."""
+    rm = _refload.load_ref_models()
+    cu = _refload.load_ref_common_utils()
+    rec = {}
+    for factor, hw in ((4, (64, 96)), (2, (36, 44)), (8, (64, 64))):
+        d = rm.downsampler.Downsampler(n_planes=3, factor=factor, kernel_type="lanczos2", phase=0.5, preserve_size=True)
+        torch.manual_seed(10 + factor)
+        with torch.no_grad():
+            d.downsampler_.weight += 0.01 * torch.randn_like(d.downsampler_.weight)
+            d.downsampler_.bias += 0.1 * torch.randn_like(d.downsampler_.bias)
+        x = torch.rand(1, 3, *hw, requires_grad=True)
+        y = d(x)
+        g = torch.rand_like(y)
+        (y * g).sum().backward()
+        tag = f"f{factor}"
+        rec[tag + "/w"] = d.downsampler_.weight.detach().numpy().copy()
+        rec[tag + "/b"] = d.downsampler_.bias.detach().numpy().copy()
+        rec[tag + "/x"] = x.detach().numpy()
+        rec[tag + "/y"] = y.detach().numpy()
+        rec[tag + "/gy"] = g.numpy()
+        rec[tag + "/gx"] = x.grad.numpy().copy()
+        rec[tag + "/dw"] = d.downsampler_.weight.grad.numpy().copy()
+        rec[tag + "/db"] = d.downsampler_.bias.grad.numpy().copy()
+        d.x = None
+        d2 = copy.deepcopy(d)
+        xin = x.detach().clone()
+        target = torch.rand_like(y)
+        mse = torch.nn.MSELoss()
+
+        def closure():
+            l = mse(d2(xin), target)
+            l.backward()
+            return l
+
+        cu.optimize("adam", cu.get_params("down", None, xin, d2), closure, 0.01, 3)
+        rec[tag + "/target"] = target.numpy()
+        rec[tag + "/adam3_w"] = d2.downsampler_.weight.detach().numpy().copy()
+        rec[tag + "/adam3_b"] = d2.downsampler_.bias.detach().numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "downsampler_dense.npz"), **rec)
+    print("downsampler_dense.npz")
+
+
 def gen_get_noise():
     cu = _refload.load_ref_common_utils()
     rec = {}
@@ -243,8 +289,11 @@ if __name__ == "__main__":
     for n, c in NETS.items():
         if not only or n in only:
             gen_net(n, c)
+    if only == ["downsampler_dense"]:
+        gen_downsampler_dense()
     if only:
         sys.exit(0)
     gen_downsampler()
+    gen_downsampler_dense()
     gen_get_noise()
     gen_default_digest()

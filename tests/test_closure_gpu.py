@@ -3,6 +3,7 @@ Philox reg-noise (utils.reg_noise.RegNoise), hipGraph capture of one iteration a
 independent fits (dip_optim.GraphedIteration), the device-side Adam step count, torch's
 accumulate-on-second-backward semantics at the autograd boundary, and optimize('LBFGS')."""
 import copy
+import os
 
 import numpy as np
 import pytest
@@ -431,19 +432,55 @@ def test_lbfgs_on_the_arena(dev):
     assert len(vals) >= 100 + 2 and np.isfinite(vals).all() and vals[-1] < vals[0]
 
 
-def test_downsampler_refuses_to_be_optimised(dev):
+def test_downsampler_optimised_as_dense_conv_golden(dev):
+    """opt_over='down' (utils/common_utils.py:44-46 of the reference): the Downsampler's dense Conv2d weight and bias
+    get gradients and are trained; vectors from the real reference (oracle/make_golden.py: gen_downsampler_dense)."""
+    from conftest import GOLDEN
     from models.downsampler import Downsampler
-    from utils.common_utils import get_params
+    from utils.common_utils import get_params, optimize
+    gold = np.load(os.path.join(GOLDEN, "downsampler_dense.npz"))
+    for factor in (4, 2, 8):
+        t = f"f{factor}/"
+        d = Downsampler(n_planes=3, factor=factor, kernel_type="lanczos2", phase=0.5, preserve_size=True).to(dev)
+        assert not d.downsampler_.weight.requires_grad                 # fixed taps until someone asks to optimise them
+        sd = d.state_dict()
+        sd["downsampler_.weight"] = torch.from_numpy(gold[t + "w"]).to(dev)
+        sd["downsampler_.bias"] = torch.from_numpy(gold[t + "b"]).to(dev)
+        d.load_state_dict(sd)                                          # not on the channel diagonal any more -> dense path
+        x = torch.from_numpy(gold[t + "x"]).to(dev).requires_grad_(True)
+        y = d(x)
+        assert torch.allclose(y.detach().cpu(), torch.from_numpy(gold[t + "y"]), rtol=1e-5, atol=5e-6)
+        params = get_params("down", None, x, d)
+        assert all(p.requires_grad for p in params) and len(params) == 2
+        y = d(x)
+        (y * torch.from_numpy(gold[t + "gy"]).to(dev)).sum().backward()
+        for got, key in ((x.grad, "gx"), (d.downsampler_.weight.grad, "dw"), (d.downsampler_.bias.grad, "db")):
+            ref = torch.from_numpy(gold[t + key])
+            assert torch.allclose(got.cpu(), ref, rtol=2e-5, atol=2e-6 * float(ref.abs().max())), (factor, key)
+        # three optimize('adam') steps over the down-sampler alone
+        xin = torch.from_numpy(gold[t + "x"]).to(dev)
+        target = torch.from_numpy(gold[t + "target"]).to(dev)
+        mse = torch.nn.MSELoss()
+
+        def closure():
+            l = mse(d(xin), target)
+            l.backward()
+            return l
+
+        optimize("adam", params, closure, 0.01, 3)
+        for p_, key in ((d.downsampler_.weight, "adam3_w"), (d.downsampler_.bias, "adam3_b")):
+            ref = torch.from_numpy(gold[t + key])
+            err = float((p_.detach().cpu() - ref).abs().max())
+            assert err <= 2e-5, (factor, key, err)                     # steps are 1e-2 each
+
+
+def test_downsampler_fixed_taps_state_dict_roundtrip(dev):
+    from models.downsampler import Downsampler
     d = Downsampler(n_planes=3, factor=4, kernel_type="lanczos2", phase=0.5, preserve_size=True).to(dev)
     x = torch.rand(1, 3, 64, 64, device=dev)
     y = d(x)
-    sd = copy.deepcopy(d.state_dict())
-    d.load_state_dict(sd)
-    assert torch.equal(d(x), y)
-    sd["downsampler_.weight"][0, 1] = 1.0
-    with pytest.raises(NotImplementedError):
-        d.load_state_dict(sd)
-    d2 = Downsampler(n_planes=3, factor=4, kernel_type="lanczos2", phase=0.5, preserve_size=True).to(dev)
-    get_params("down", torch.nn.Conv2d(1, 1, 1), x, d2)
-    with pytest.raises(NotImplementedError, match="opt_over"):
-        d2(x)
+    d.load_state_dict(copy.deepcopy(d.state_dict()))
+    assert not d._nondiag and torch.equal(d(x), y)
+    # the dense evaluation of the same taps agrees with the depth-wise kernel to rounding
+    d._nondiag = True
+    assert torch.allclose(d(x), y, rtol=1e-5, atol=2e-6)

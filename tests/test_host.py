@@ -2,6 +2,7 @@
 naming, planner, reference-compatible helper semantics, loud failure without the HIP path, and
 the multi-process sharding used by `bench.py --gpus N` (world_size-2 gloo)."""
 import ctypes
+import copy
 import os
 import re
 import subprocess
@@ -211,6 +212,28 @@ def test_downsampler_taps_match_reference_vectors():
         assert list(d.state_dict().keys()) == ["downsampler_.weight", "downsampler_.bias"]
         assert d.downsampler_.weight.shape == (3, 3, 4 * factor, 4 * factor)
     assert get_kernel(2, "box", 0.5, 4).shape == (4, 4)
+
+
+def test_downsampler_switches_to_the_dense_path_when_optimised():
+    """Fixed taps (depth-wise kernel, parameters without grad) until get_params('down', ...) asks for the reference's
+    behaviour -- the dense Conv2d weight is optimised, utils/common_utils.py:44-46 -- or a trained weight is loaded."""
+    from models.downsampler import Downsampler
+    from utils.common_utils import get_params
+    d = Downsampler(n_planes=3, factor=4, kernel_type="lanczos2", phase=0.5, preserve_size=True)
+    assert not any(p.requires_grad for p in d.parameters()) and not d._nondiag
+    d.load_state_dict(copy.deepcopy(d.state_dict()))
+    assert not d._nondiag
+    ps = get_params("down", None, torch.zeros(1, 3, 8, 8), d)
+    assert [tuple(p.shape) for p in ps] == [(3, 3, 16, 16), (3,)] and all(p.requires_grad for p in ps)
+    gold = np.load(os.path.join(GOLDEN, "downsampler_dense.npz"))
+    d2 = Downsampler(n_planes=3, factor=4, kernel_type="lanczos2", phase=0.5, preserve_size=True)
+    sd = d2.state_dict()
+    sd["downsampler_.weight"] = torch.from_numpy(gold["f4/w"])
+    sd["downsampler_.bias"] = torch.from_numpy(gold["f4/b"])
+    d2.load_state_dict(sd)
+    assert d2._nondiag
+    with pytest.raises(RuntimeError, match="MI355X"):
+        d2(torch.zeros(1, 3, 16, 16))
 
 
 def test_no_silent_fallback():
