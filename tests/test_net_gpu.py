@@ -8,6 +8,7 @@ end quality only."""
 import copy
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -15,7 +16,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from conftest import GOLDEN  # noqa: E402
+from conftest import GOLDEN, ROOT  # noqa: E402
 import dip_oracle as O  # noqa: E402
 import parity as PT  # noqa: E402
 from parity import oracle_grads as _oracle_grads  # noqa: E402
@@ -268,6 +269,75 @@ def test_fused_batchnorm_backward_statistics_engine_path(dev):
         # (+ an absolute floor for the analytically-zero tensors -- conv biases in front of a BatchNorm hold 1e-8-level
         # roundoff in both paths, tests/parity.py)
         assert (a - b).norm().item() <= 2e-5 * a.norm().item() + 1e-6 * gmax, (k, (a - b).norm().item(), a.norm().item())
+
+
+# every A/B switch of the library and the engine that the end-quality arms below do not already run with
+AB_SWITCH_SETS = [
+    # fall-backs of the convolution dispatcher / loss head (each replaces one specialised kernel by the generic one)
+    dict(DIP_CONV_NO_EXTRA="1", DIP_CONV_NO_RES1X1="1", DIP_CONV_NO_S2DMA="1", DIP_LOSS_HEAD_NO_COAL="1"),
+    dict(DIP_CONV_NO_THIN4="1", DIP_CONV_PHASE_KSPLIT="2", DIP_CONV_NO_DMA="1"),
+    dict(DIP_CONV_NO_PHASE="1"),
+    # weight-gradient planner / kernels
+    dict(DIP_WGRAD_NO_KW="1", DIP_WGRAD_NO_RAGGED_PARTS="1", DIP_WGRAD_NO_THIN_CIN="1", DIP_WGRAD_NO_SMALL_PLAN="1"),
+    dict(DIP_WGRAD_NO_SLIDE="1", DIP_CONV_PLAN_WGS="256"),
+    # schedule: single stream; three streams without deferral; side stream only for big launches; fused BN-backward stats
+    dict(DIP_TWO_STREAMS="0"),
+    dict(DIP_DEFER_WGRAD="-1", DIP_SIDE_MIN_PIXELS="16384"),
+    dict(DIP_BNB_FUSE="1", DIP_DEFER_WGRAD="0"),
+]
+
+
+def test_ab_switch_branches_compute_the_same_gradients(dev, tmp_path):
+    """The A/B switches (DIP_* variables, read once per process) select other kernels / launch plans / schedules for the
+    same arithmetic.  None of them is set in a default run, so each set is run here in a process of its own
+    (tests/switch_probe.py: 256x256 two-scale 128-channel net, plain loss and fused loss head) and compared with the
+    default run: same output and loss, every gradient equal up to the summation order."""
+    import subprocess
+    probe = os.path.join(ROOT, "tests", "switch_probe.py")
+
+    def run(env_extra, tag):
+        env = {k: v for k, v in os.environ.items() if not k.startswith("DIP_")}
+        env.update(env_extra)
+        out = str(tmp_path / f"{tag}.npz")
+        r = subprocess.run([sys.executable, probe, out], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (env_extra, r.stdout[-2000:], r.stderr[-4000:])
+        return np.load(out)
+
+    base = run({}, "default")
+    keys = [k for k in base.files if k.startswith(("g/", "gh/"))]
+    mkeys = [k for k in base.files if k.startswith("m/")]
+    assert len(mkeys) == 10                      # 2 scales x (skip, down_a, down_b, up, up1)
+    nact = 8 * sum(base[k].size for k in mkeys)
+    gmax = max(float(np.linalg.norm(base[k].astype(np.float64))) for k in keys)
+    # the fused head against the plain spelling inside the default run
+    assert abs(float(base["loss_head"]) - float(base["loss"])) <= 1e-6 * abs(float(base["loss"]))
+    for i, sw in enumerate(AB_SWITCH_SETS):
+        got = run(sw, f"set{i}")
+        assert abs(float(got["loss"]) - float(base["loss"])) <= 1e-6 * abs(float(base["loss"])), sw
+        assert abs(float(got["loss_head"]) - float(base["loss"])) <= 1e-6 * abs(float(base["loss"])), sw
+        d = got["out"].astype(np.float64) - base["out"].astype(np.float64)
+        assert float(np.abs(d).max()) <= 2e-5, (sw, float(np.abs(d).max()))
+        # LeakyReLU's derivative jumps at 0: when the forward's summation order changes, an element with |z| ~ 1e-7 may
+        # take the other branch, and ONE such element moves the weight gradients upstream of it by ~1/sqrt(pixels x
+        # channels) ~ 5e-4 relative at this size (DESIGN 4).  So: identical branch pattern => the gradients agree to
+        # rounding; otherwise the flips are counted (< 1e-5 of the activated elements, as tests/parity.py demands of the
+        # HIP-vs-oracle comparison) and the bound is the kink's.  Analytically-zero tensors (conv biases in front of a
+        # BatchNorm) hold roundoff only: absolute floor as in tests/parity.py
+        flips = sum(int(np.unpackbits(np.bitwise_xor(base[k], got[k])).sum()) for k in mkeys)
+        assert flips <= 1e-5 * nact, (sw, flips, nact)
+        tol, tol_med = (1e-4, 2e-5) if flips == 0 else (5e-3, 2e-3)
+        worst, rels = (0.0, None), []
+        for k in keys:
+            a, b = base[k].astype(np.float64), got[k].astype(np.float64)
+            na, e = float(np.linalg.norm(a)), float(np.linalg.norm(a - b))
+            assert e <= tol * na + 1e-6 * gmax, (sw, flips, k, e, na)
+            if na > 1e-4 * gmax:
+                if worst[1] is None or e / na > worst[0]:
+                    worst = (e / na, k)
+                rels.append(e / na)
+        assert float(np.median(rels)) <= tol_med, (sw, flips, float(np.median(rels)))
+        print(f"  switches {sw}: {flips} of {nact} LeakyReLU branches differ; rel-L2 vs default: median "
+              f"{np.median(rels):.2e}, worst {worst[0]:.2e} ({worst[1]})")
 
 
 def test_super_resolution_closure_against_oracle(dev):
