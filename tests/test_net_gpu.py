@@ -205,20 +205,24 @@ def test_default_net_64_against_oracle_and_digest(dev):
     assert worst <= 1.0, (worst, wk)
 
 
-@pytest.mark.parametrize("hw,mode,nskip", [((96, 64), "bilinear", 4), ((64, 64), "nearest", 128),
-                                           # not divisible by 2^5: ceil sizes 81x103 -> 41x52 -> 21x26 -> 11x13 -> 6x7 -> 3x4
-                                           ((81, 103), "bilinear", 4), ((70, 57), "nearest", 4)])
-def test_against_oracle_fresh_seed(dev, hw, mode, nskip):
+@pytest.mark.parametrize("hw,mode,nskip,down", [
+    ((96, 64), "bilinear", 4, "stride"), ((64, 64), "nearest", 128, "stride"),
+    # not divisible by 2^5: ceil sizes 81x103 -> 41x52 -> 21x26 -> 11x13 -> 6x7 -> 3x4
+    ((81, 103), "bilinear", 4, "stride"), ((70, 57), "nearest", 4, "stride"),
+    # Lanczos down-sampling inside conv at 128 planes: dense 128x128x8x8 convs, K = 8192 (dip_conv_plan's slices)
+    ((96, 64), "bilinear", 4, "lanczos2")])
+def test_against_oracle_fresh_seed(dev, hw, mode, nskip, down):
     from models.skip import skip
     torch.manual_seed(123)
     kw = dict(num_channels_down=[128] * 5, num_channels_up=[128] * 5, num_channels_skip=[nskip] * 5,
-              upsample_mode=mode, need_sigmoid=True, need_bias=True, pad="reflection")
+              upsample_mode=mode, downsample_mode=down, need_sigmoid=True, need_bias=True, pad="reflection")
     net = skip(32, 3, **kw)
     sd = {k: v.detach().clone() for k, v in net.state_dict().items()
           if not k.endswith(("running_mean", "running_var", "num_batches_tracked"))}
     z = torch.rand(1, 32, *hw) * 0.1
     target = torch.rand(1, 3, *hw)
-    spec = O.SkipSpec(32, 3, [128] * 5, [128] * 5, [nskip] * 5, pad="reflection", upsample_mode=mode)
+    spec = O.SkipSpec(32, 3, [128] * 5, [128] * 5, [nskip] * 5, pad="reflection", upsample_mode=mode,
+                      downsample_mode=down)
     lf = lambda o_, dt: torch.nn.functional.mse_loss(o_, target.to(dt))
     zrec = {}
     _, _, g64n = _oracle_grads(spec, sd, z, lf, torch.float64, zrec=zrec)
@@ -234,7 +238,7 @@ def test_against_oracle_fresh_seed(dev, hw, mode, nskip):
     psnr = _psnr(out.detach().cpu().numpy(), oo.numpy())
     rel = abs(loss.item() - lo) / lo
     worst, wk = _grad_report({k: p.grad for k, p in net.named_parameters()}, g64, g32, g64n, spec, sd, masks=hmasks, zrec=zrec)
-    print(f"oracle {hw} {mode} skip{nskip}: PSNR {psnr:.1f} dB, loss rel {rel:.2e}, grad err/tol {worst:.2f} ({wk})")
+    print(f"oracle {hw} {mode} skip{nskip} {down}: PSNR {psnr:.1f} dB, loss rel {rel:.2e}, grad err/tol {worst:.2f} ({wk})")
     assert psnr >= 100.0 and rel <= 1e-5 and worst <= 1.0, (psnr, rel, worst, wk)
 
 
