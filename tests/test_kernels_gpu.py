@@ -78,6 +78,7 @@ CONV_CASES = [
     (16, 16, 8, 2, REPLICATE, 32, 32, False),
     (12, 12, 12, 2, REPLICATE, 24, 40, False),
     (128, 128, 8, 2, REPLICATE, 32, 48, False),
+    (64, 64, 12, 2, REPLICATE, 24, 24, False),   # K = 9216: sliced by dip_conv_plan's accuracy rule
 ]
 
 
