@@ -2,9 +2,12 @@ set -u
 ROOTD="${GRAFT_REPO_ROOT:-/root/repo}"
 cd "$ROOTD"
 mkdir -p gpurun_out; export TMPDIR=/tmp
-python __graft_entry__.py build > gpurun_out/c30_build.log 2>&1
-# SQ counters in a pass of their own (no trace domain besides --kernel-trace); library preloaded (counter service vs dlopen)
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS -d $ROOTD/gpurun_out/pmc_SQ -o pmc -- env DIP_TWO_STREAMS=0 LD_PRELOAD=$ROOTD/deep-image-prior_amd/lib/libdip_hip.so python $ROOTD/bench.py --steps 3 --warmup 2 --mode eager --no-cpu-baseline --no-roofline --no-eager-line > $ROOTD/gpurun_out/c30_sq.log 2>&1 ); echo "sq rc=$?"
-python tools/pmc_sq.py gpurun_out/pmc_SQ > gpurun_out/pmc_SQ_summary.txt 2>> gpurun_out/c30_sq.log
-rm -rf gpurun_out/pmc_SQ
-head -12 gpurun_out/pmc_SQ_summary.txt | cut -c1-160
+python __graft_entry__.py build > gpurun_out/c31_build.log 2>&1
+: > gpurun_out/c31_ab.log
+for rep in 1 2; do
+for v in base DIP_BN_APPLY_BLOCKS=2048 DIP_BN_APPLY_BLOCKS=4096 DIP_BN_BLOCKS=2048 DIP_BN_BLOCKS=2048,DIP_BN_APPLY_BLOCKS=4096; do
+  if [ "$v" = base ]; then envs=""; else envs="${v//,/ }"; fi
+  line=$(env $envs timeout 300 python bench.py --steps 100 --warmup 20 --no-cpu-baseline 2>/dev/null | grep '^{"metric"' | tail -1)
+  echo "$v rep$rep $(echo "$line" | python -c 'import sys,json; d=json.loads(sys.stdin.read()); h=d["roofline_hbm"]; print(d["value"], d["ms_per_step"], "hbm_ms", h["ms_per_step"], "TB/s", h["achieved"])' 2>/dev/null)" | tee -a gpurun_out/c31_ab.log
+done
+done
