@@ -9,9 +9,17 @@ tot = sum(r[2] for r in rows)
 print(f"# source: {db}")
 print(f"# {steps} optimisation steps profiled; total kernel time {tot/1e3:.2f} ms = {tot/steps/1e3:.3f} ms per step")
 print(f"{'kernel':78s} {'calls':>6s} {'calls/step':>10s} {'total_ms':>9s} {'ms/step':>8s} {'avg_us':>9s} {'min_us':>8s} {'max_us':>9s} {'%':>6s}")
+setup_only = False
 for n, c, s, a, mi, ma in rows:
     n = re.sub(r"\(anonymous namespace\)::", "", n)
-    print(f"{n[:78]:78s} {c:6d} {c/steps:10.1f} {s/1e3:9.2f} {s/steps/1e3:8.3f} {a:9.1f} {mi:8.1f} {ma:9.1f} {100*s/tot:6.2f}")
+    # a call count that is not a multiple of the step count = (mostly) one-time launches of the set-up, e.g. the ~400
+    # __amd_rocclr_copyBuffer that move module parameters into the arenas: "calls/step" is NOT a per-iteration figure there
+    mark = "" if c % steps == 0 else " ~"
+    setup_only |= bool(mark)
+    print(f"{n[:78]:78s} {c:6d} {c/steps:10.1f} {s/1e3:9.2f} {s/steps/1e3:8.3f} {a:9.1f} {mi:8.1f} {ma:9.1f} {100*s/tot:6.2f}{mark}")
+if setup_only:
+    print("# ~ : call count not a multiple of the profiled steps (set-up launches included); see tools/prof_timeline.py for "
+          "the launches of one steady-state iteration")
 print()
 print("# per launch geometry of the MFMA kernels (grid in workgroups)")
 for pat in ("conv_igemm_dma_kernel", "conv_igemm_kernel", "conv_wgrad_kernel"):
