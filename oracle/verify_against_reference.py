@@ -1,6 +1,7 @@
 """Pin the oracle: run the REAL reference (/root/reference) and the restatement
 (oracle/dip_oracle.py) on the same state_dict + input and require torch.equal on the
-output, the loss and every gradient; then one Adam step -> identical parameters.
+output, the loss and every gradient; then one Adam step -> identical parameters.  Ten net configurations (the
+notebooks' nets, avg / max pooling, centre crops at non-divisible sizes, Lanczos down-sampling inside conv).
 
 Run:  python oracle/verify_against_reference.py        (build container only)
 """
@@ -37,6 +38,22 @@ CONFIGS = {
     "avg_down": dict(args=(32, 3), kw=dict(num_channels_down=[64] * 4, num_channels_up=[64] * 4,
                                            num_channels_skip=[4] * 4, upsample_mode="bilinear", downsample_mode="avg",
                                            need_sigmoid=True, need_bias=True, pad="reflection"), hw=(64, 96)),
+    # round 3: Concat's centre crop beyond one row / column (pooling, skip-less scales at non-divisible sizes,
+    # models/common.py:29-37) and the Lanczos Downsampler inside conv (models/common.py:107-108)
+    "max_down_crop": dict(args=(16, 3), kw=dict(num_channels_down=[32] * 4, num_channels_up=[32] * 4,
+                                                num_channels_skip=[4] * 4, upsample_mode="bilinear", downsample_mode="max",
+                                                need_sigmoid=True, need_bias=True, pad="reflection"), hw=(77, 93)),
+    "noskip_crop": dict(args=(16, 3), kw=dict(num_channels_down=[32] * 4, num_channels_up=[32] * 4,
+                                              num_channels_skip=[4, 0, 4, 0], upsample_mode="nearest",
+                                              need_sigmoid=True, need_bias=True, pad="reflection"), hw=(61, 75)),
+    "lanczos2_down": dict(args=(16, 3), kw=dict(num_channels_down=[64] * 3, num_channels_up=[64] * 3,
+                                                num_channels_skip=[4] * 3, upsample_mode="bilinear",
+                                                downsample_mode="lanczos2",
+                                                need_sigmoid=True, need_bias=True, pad="reflection"), hw=(64, 96)),
+    "lanczos3_down_odd": dict(args=(8, 3), kw=dict(num_channels_down=[16, 32], num_channels_up=[16, 32],
+                                                   num_channels_skip=[4, 4], upsample_mode="nearest",
+                                                   downsample_mode=["lanczos3", "lanczos2"],
+                                                   need_sigmoid=True, need_bias=True, pad="zero"), hw=(45, 38)),
 }
 
 
@@ -67,9 +84,9 @@ def check(name, cfg):
     H, W = cfg["hw"]
     x = O.get_noise(cfg["args"][0], "noise", (H, W)) if cfg["args"][0] != 2 else \
         O.get_noise(2, "meshgrid", (H, W)).float()
-    target = torch.rand(1, cfg["args"][1], H, W)
-
     out_ref = net(x)
+    # (with pooling / skip-less scales at non-divisible sizes Concat's crop makes the output smaller than the input)
+    target = torch.rand(1, cfg["args"][1], *out_ref.shape[2:])
     loss_ref = torch.nn.functional.mse_loss(out_ref, target)
     loss_ref.backward()
 
