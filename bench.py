@@ -384,7 +384,7 @@ def dominant_ops(eng, fl):
             if name.partition(":")[0] not in ("conv_fwd", "dgrad", "dgrad+"):
                 continue
             d = args[0]._obj
-            if d.ks != 3 or d.Cout < 128:
+            if d.ks != 3 or d.Cout < 128 or fn is lib.dip_conv_small:      # (low-resolution layers: conv_small_kernel)
                 continue
             v = lib.dip_conv_variant(args[0])
             if v not in (1, 3):

@@ -1,6 +1,7 @@
 // BatchNorm2d (train mode, N=1) statistics finalisation and the three backward phases, fused with
 // LeakyReLU backward and the adjoint of ReflectionPad2d.  All HBM-bound: float4 per lane, NHWC.
 #include "dip_common.h"
+#include "bn_ticket.h"
 #include <stdlib.h>
 
 namespace {
@@ -160,8 +161,10 @@ __device__ __forceinline__ void block_reduce_2(const RowLayout& L, f32x4 s1, f32
 __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const DipGradSrc src, const float* __restrict__ y, int H,
                                                            int W, int Cy, int C, const float* __restrict__ state,
                                                            int Cs, float slope, float* dz, int Cdz, float* partials,
-                                                           int ppb /*pixels per block*/) {
-    __shared__ __attribute__((aligned(16))) float sh[256 * 8];
+                                                           int ppb /*pixels per block*/, const DipBnbFin fin) {
+    __shared__ __attribute__((aligned(16))) double shd[256 * 8];        // float tree, then the fp64 finalisation tree
+    __shared__ unsigned flag;
+    float* sh = reinterpret_cast<float*>(shd);
     const RowLayout L = row_layout(C);
     f32x4 s1 = f32x4{0.f, 0.f, 0.f, 0.f}, s2 = s1;
     if (L.active) {
@@ -200,7 +203,21 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const DipGradSrc src,
             one(p, grad_src4(src, r, c, H, W, ch), ld4(y + (size_t)p * Cy + ch));
         }
     }
-    block_reduce_2(L, s1, s2, partials, Cs, sh);
+    if (fin.coef == nullptr) {
+        block_reduce_2(L, s1, s2, partials, Cs, sh);
+        return;
+    }
+    // in-launch finalisation (bn_ticket.h): write-through rows, ticket, the last block reduces them all
+    dip_tree_sum8(sh, L.nc4, L.rpi, L.prow, L.cg, L.active, s1, s2);
+    if (L.active && L.prow == 0) {
+        float* o = partials + (size_t)blockIdx.x * 2 * Cs + L.cg * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { dip_st_sc1(o + e, s1[e]); dip_st_sc1(o + Cs + e, s2[e]); }
+    }
+    if (dip_ticket_last(fin.ticket, gridDim.x, &flag)) {
+        dip_bnb_fin_rows(partials, gridDim.x, Cs, 0, C, fin, shd);
+        dip_ticket_reset(fin.ticket);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -369,17 +386,31 @@ extern "C" int dip_bn_bwd_nblk(int H, int W, int C) {
     return nblk;
 }
 
-extern "C" int dip_bn_bwd_stats(const DipGradSrc* src, const float* y, int H, int W, int Cy, int C,
-                                const float* state, int Cs, float slope, float* dz, int Cdz, float* partials,
-                                int nblk, void* stream) {
+// fin == NULL (or fin->coef == NULL): partials only (dip_bn_bwd_finalize follows); otherwise phase 2 rides in the launch:
+// the last block to arrive writes dgamma, dbeta and coef (<= 256 rows and channels: dip_fin_rows_ok)
+extern "C" int dip_bn_bwd_stats_fin(const DipGradSrc* src, const float* y, int H, int W, int Cy, int C,
+                                    const float* state, int Cs, float slope, float* dz, int Cdz, float* partials,
+                                    int nblk, const DipBnbFin* finp, void* stream) {
     if (C > 1024) DIP_FAIL("bn_bwd_stats: C > 1024 unsupported");
     int nb;
     const int ppb = pixels_per_block(H * W, C, &nb);
     if (nb != nblk) DIP_FAIL("bn_bwd_stats: nblk mismatch (use dip_bn_bwd_nblk)");
+    DipBnbFin fin = {};
+    if (finp != nullptr && finp->coef != nullptr) {
+        fin = *finp;
+        if (C > 256 || nb > 256 || fin.ticket == nullptr || fin.C != C)
+            DIP_FAIL("bn_bwd_stats_fin: needs <= 256 channels and rows (dip_fin_rows_ok), a ticket, C");
+    }
     hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *src, y, H, W, Cy, C,
-                       state, Cs, slope, dz, Cdz, partials, ppb);
+                       state, Cs, slope, dz, Cdz, partials, ppb, fin);
     DIP_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int dip_bn_bwd_stats(const DipGradSrc* src, const float* y, int H, int W, int Cy, int C,
+                                const float* state, int Cs, float slope, float* dz, int Cdz, float* partials,
+                                int nblk, void* stream) {
+    return dip_bn_bwd_stats_fin(src, y, H, W, Cy, C, state, Cs, slope, dz, Cdz, partials, nblk, nullptr, stream);
 }
 
 extern "C" int dip_bn_bwd_finalize(const float* partials, int nblk, int Cs, int C, int npix, float* dgamma,

@@ -2,6 +2,8 @@
 // statistics (forward), and the adjoint gather fused with LeakyReLU backward + BatchNorm backward
 // phase 1 (backward).  HBM-bound, float4 per lane, NHWC.
 #include "dip_common.h"
+#include "bn_ticket.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -33,13 +35,41 @@ __device__ __forceinline__ RowLayout row_layout(int C) {
     return L;
 }
 
+// partial row of this block -> d.stats; with fin.state != NULL the last block to arrive finalises the BatchNorm (bn_ticket.h)
+__device__ __forceinline__ void upcat_rows_out(const DipUpcatDesc& d, const DipBnFin& fin, const RowLayout& L, float n,
+                                               const f32x4& mean, const f32x4& M2, int C, double* shd, unsigned* flag) {
+    if (L.active && L.prow == 0) {
+        float* o = d.stats + (size_t)blockIdx.x * 3 * d.Cs_cat + L.cg * 4;
+        if (fin.state != nullptr) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                dip_st_sc1(o + e, n);
+                dip_st_sc1(o + d.Cs_cat + e, mean[e]);
+                dip_st_sc1(o + 2 * d.Cs_cat + e, M2[e]);
+            }
+        } else {
+            st4(o, f32x4{n, n, n, n});
+            st4(o + d.Cs_cat, mean);
+            st4(o + 2 * d.Cs_cat, M2);
+        }
+    }
+    if (fin.state != nullptr) {
+        if (dip_ticket_last(fin.ticket, gridDim.x, flag)) {
+            dip_bn_fin_rows(d.stats, gridDim.x, d.Cs_cat, 0, C, fin, shd);
+            dip_ticket_reset(fin.ticket);
+        }
+    }
+}
+
 // One thread = 4 channels of a 2x2 block of output pixels (low-resolution pixel (i, j) -> outputs (2i..2i+1, 2j..2j+1)):
 // the 3x3 low-resolution neighbourhood is loaded and put through the producer's BatchNorm+activation ONCE (2.25
 // transforms and loads per output instead of 4), the column blends are shared by the two output rows.  Scale-2
 // bilinear weights (align_corners = False): odd outputs (0.75, 0.25) on (i, i+1), even outputs (0.25, 0.75) on
 // (i-1, i), except output 0 = (1, 0) -- exactly upsample_bilinear2d's lambdas (bil_src above).
-__global__ __launch_bounds__(256) void upcat_fwd_kernel(const DipUpcatDesc d, int qpb) {
-    __shared__ __attribute__((aligned(16))) float sh[256 * 12];
+__global__ __launch_bounds__(256) void upcat_fwd_kernel(const DipUpcatDesc d, int qpb, const DipBnFin fin) {
+    __shared__ __attribute__((aligned(16))) double shd[DIP_TICKET_SH_DOUBLES];      // float trees, then the fp64 finalisation
+    __shared__ unsigned flag;
+    float* sh = reinterpret_cast<float*>(shd);
     const int C = d.ns + d.nd;
     const RowLayout L = row_layout(C);
     // shifted sums per thread, 4 channels
@@ -150,20 +180,17 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const DipUpcatDesc d, in
         }
     }
     dip_tree_chan4(sh, L.nc4, L.rpi, L.prow, L.cg, L.active, n, mean, M2);
-    if (L.active && L.prow == 0) {
-        float* o = d.stats + (size_t)blockIdx.x * 3 * d.Cs_cat + L.cg * 4;
-        st4(o, f32x4{n, n, n, n});
-        st4(o + d.Cs_cat, mean);
-        st4(o + 2 * d.Cs_cat, M2);
-    }
+    upcat_rows_out(d, fin, L, n, mean, M2, C, shd, &flag);
 }
 
 // General centre crop (models/common.py:29-37): one thread = 4 channels of ONE output pixel (r, c); the skip branch is
 // read at (r + os_y, c + os_x) of its [Hs][Ws] tensor, the deeper branch at the up-sampled coordinate (r + od_y, c + od_x)
 // of its [2*Hd][2*Wd] image (upsample_bilinear2d's own source-index rule, bil_src, or nearest).  Used only for the
 // geometries the 2x2-block kernel above does not cover (pooling nets / skip-less scales at non-divisible sizes).
-__global__ __launch_bounds__(256) void upcat_fwd_crop_kernel(const DipUpcatDesc d, int ppb) {
-    __shared__ __attribute__((aligned(16))) float sh[256 * 12];
+__global__ __launch_bounds__(256) void upcat_fwd_crop_kernel(const DipUpcatDesc d, int ppb, const DipBnFin fin) {
+    __shared__ __attribute__((aligned(16))) double shd[DIP_TICKET_SH_DOUBLES];
+    __shared__ unsigned flag;
+    float* sh = reinterpret_cast<float*>(shd);
     const int C = d.ns + d.nd;
     const RowLayout L = row_layout(C);
     f32x4 K = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = K, s2 = K;
@@ -224,12 +251,7 @@ __global__ __launch_bounds__(256) void upcat_fwd_crop_kernel(const DipUpcatDesc 
         }
     }
     dip_tree_chan4(sh, L.nc4, L.rpi, L.prow, L.cg, L.active, n, mean, M2);
-    if (L.active && L.prow == 0) {
-        float* o = d.stats + (size_t)blockIdx.x * 3 * d.Cs_cat + L.cg * 4;
-        st4(o, f32x4{n, n, n, n});
-        st4(o + d.Cs_cat, mean);
-        st4(o + 2 * d.Cs_cat, M2);
-    }
+    upcat_rows_out(d, fin, L, n, mean, M2, C, shd, &flag);
 }
 
 // low-res pixel (i,j): du = sum over the <=4x4 high-res pixels whose interpolation touches it.  The deeper branch is
@@ -240,8 +262,10 @@ __global__ __launch_bounds__(256) void upsample_bwd_stats_kernel(const float* __
                                                                  const float* __restrict__ y,
                                                                  int Cy, int C, const float* __restrict__ state, int Cs,
                                                                  float slope, float* dz, int Cdz, float* partials,
-                                                                 int ppb) {
-    __shared__ __attribute__((aligned(16))) float sh[256 * 8];
+                                                                 int ppb, const DipBnbFin fin) {
+    __shared__ __attribute__((aligned(16))) double shd[256 * 8];
+    __shared__ unsigned flag;
+    float* sh = reinterpret_cast<float*>(shd);
     const RowLayout L = row_layout(C);
     f32x4 s1 = f32x4{0.f, 0.f, 0.f, 0.f}, s2 = s1;
     if (L.active) {
@@ -313,8 +337,19 @@ __global__ __launch_bounds__(256) void upsample_bwd_stats_kernel(const float* __
     dip_tree_sum8(sh, L.nc4, L.rpi, L.prow, L.cg, L.active, s1, s2);
     if (L.active && L.prow == 0) {
         float* o = partials + (size_t)blockIdx.x * 2 * Cs + L.cg * 4;
-        st4(o, s1);
-        st4(o + Cs, s2);
+        if (fin.coef != nullptr) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { dip_st_sc1(o + e, s1[e]); dip_st_sc1(o + Cs + e, s2[e]); }
+        } else {
+            st4(o, s1);
+            st4(o + Cs, s2);
+        }
+    }
+    if (fin.coef != nullptr) {      // the last block to arrive reduces the rows: dgamma, dbeta, k1, k2 (bn_ticket.h)
+        if (dip_ticket_last(fin.ticket, gridDim.x, &flag)) {
+            dip_bnb_fin_rows(partials, gridDim.x, Cs, 0, C, fin, shd);
+            dip_ticket_reset(fin.ticket);
+        }
     }
 }
 
@@ -453,8 +488,18 @@ extern "C" int dip_upcat_nblk(int H, int W, int C) {
     return nblk;
 }
 
-extern "C" int dip_upcat_fwd(const DipUpcatDesc* d, void* stream) {
+// rows a launch may finalise itself: the last block reads them all through L2-bypassing loads
+static constexpr int FIN_MAX_ROWS = 256;
+
+static int upcat_fwd_impl(const DipUpcatDesc* d, const DipBnFin* finp, void* stream) {
     const int C = d->ns + d->nd;
+    DipBnFin fin = {};
+    if (finp != nullptr && finp->state != nullptr) {
+        fin = *finp;
+        if (C > 256 || fin.ticket == nullptr || fin.gamma == nullptr || fin.beta == nullptr || fin.C != C)
+            DIP_FAIL("upcat_fwd_fin: needs <= 256 channels, ticket, gamma, beta, C = ns + nd");
+        if (d->nblk > FIN_MAX_ROWS) DIP_FAIL("upcat_fwd_fin: too many partial rows (dip_fin_rows_ok)");
+    }
     if ((d->ns & 3) || (d->nd & 3)) DIP_FAIL("upcat_fwd: channel counts must be multiples of 4");
     if (C > 1024) DIP_FAIL("upcat_fwd: C > 1024 unsupported");
     int nb;
@@ -471,15 +516,25 @@ extern "C" int dip_upcat_fwd(const DipUpcatDesc* d, void* stream) {
         const bool dflt = g.Hs == g.H && g.Ws == g.W && g.os_y == 0 && g.os_x == 0 && g.Hd == (g.H + 1) / 2 &&
                           g.Wd == (g.W + 1) / 2 && g.od_y == 0 && g.od_x == 0;
         if (!dflt) {
-            hipLaunchKernelGGL(upcat_fwd_crop_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, g, ppb);
+            hipLaunchKernelGGL(upcat_fwd_crop_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, g, ppb, fin);
             DIP_CHECK_LAUNCH();
             return 0;
         }
     }
     const int qpb = dip_cdiv(((d->H + 1) / 2) * ((d->W + 1) / 2), nb);       // 2x2 output blocks per workgroup
-    hipLaunchKernelGGL(upcat_fwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *d, qpb);
+    hipLaunchKernelGGL(upcat_fwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *d, qpb, fin);
     DIP_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int dip_upcat_fwd(const DipUpcatDesc* d, void* stream) { return upcat_fwd_impl(d, nullptr, stream); }
+extern "C" int dip_upcat_fwd_fin(const DipUpcatDesc* d, const DipBnFin* fin, void* stream) {
+    return upcat_fwd_impl(d, fin, stream);
+}
+// 1 when a launch that writes `rows` partial rows of C channels may finalise them itself (DipBnFin / DipBnbFin)
+extern "C" int dip_fin_rows_ok(int rows, int C) {
+    static const bool off = getenv("DIP_NO_TICKET_FIN") != nullptr;
+    return (!off && rows <= FIN_MAX_ROWS && C <= 256) ? 1 : 0;
 }
 
 static int pool2_fwd(bool maxp, const float* x, int H, int W, int Cx, int C, float* y, int Cy, float* stats, int nblk,
@@ -529,15 +584,24 @@ extern "C" int dip_avgpool2_bwd(const float* dy, int H, int W, int Cdy, int C, f
     return 0;
 }
 
-extern "C" int dip_upsample_bwd_stats(const float* dcat, int Cs_cat, int choff, int H, int W, int mode,
-                                      const float* y, int Cy, int C, const float* state, int Cs, float slope,
-                                      float* dz, int Cdz, float* partials, int nblk, void* stream) {
-    if (C > 1024) DIP_FAIL("upsample_bwd_stats: C > 1024 unsupported");
+// fin == NULL (or fin->coef == NULL): partials only; otherwise the last block finalises (dgamma, dbeta, coef)
+extern "C" int dip_upsample_bwd_stats_crop_fin(const float* dcat, int Cs_cat, int choff, int H, int W, int Hd, int Wd,
+                                               int od_y, int od_x, int mode, const float* y, int Cy, int C,
+                                               const float* state, int Cs, float slope, float* dz, int Cdz,
+                                               float* partials, int nblk, const DipBnbFin* finp, void* stream) {
+    if (C > 1024) DIP_FAIL("upsample_bwd_stats_crop: C > 1024 unsupported");
+    if (od_y < 0 || od_x < 0 || od_y + H > 2 * Hd || od_x + W > 2 * Wd) DIP_FAIL("upsample_bwd_stats_crop: crop window outside the up-sampled image");
     int nb;
-    const int ppb = pixels_per_block(((H + 1) / 2) * ((W + 1) / 2), C, &nb);
-    if (nb != nblk) DIP_FAIL("upsample_bwd_stats: nblk mismatch (use dip_bn_bwd_nblk((H+1)/2, (W+1)/2, C))");
+    const int ppb = pixels_per_block(Hd * Wd, C, &nb);
+    if (nb != nblk) DIP_FAIL("upsample_bwd_stats_crop: nblk mismatch (use dip_bn_bwd_nblk(Hd, Wd, C))");
+    DipBnbFin fin = {};
+    if (finp != nullptr && finp->coef != nullptr) {
+        fin = *finp;
+        if (C > 256 || nb > FIN_MAX_ROWS || fin.ticket == nullptr || fin.C != C)
+            DIP_FAIL("upsample_bwd_stats_fin: needs <= 256 channels and rows (dip_fin_rows_ok), a ticket, C");
+    }
     hipLaunchKernelGGL(upsample_bwd_stats_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dcat, Cs_cat, choff, H,
-                       W, (H + 1) / 2, (W + 1) / 2, 0, 0, mode, y, Cy, C, state, Cs, slope, dz, Cdz, partials, ppb);
+                       W, Hd, Wd, od_y, od_x, mode, y, Cy, C, state, Cs, slope, dz, Cdz, partials, ppb, fin);
     DIP_CHECK_LAUNCH();
     return 0;
 }
@@ -546,13 +610,13 @@ extern "C" int dip_upsample_bwd_stats_crop(const float* dcat, int Cs_cat, int ch
                                            int od_y, int od_x, int mode, const float* y, int Cy, int C,
                                            const float* state, int Cs, float slope, float* dz, int Cdz, float* partials,
                                            int nblk, void* stream) {
-    if (C > 1024) DIP_FAIL("upsample_bwd_stats_crop: C > 1024 unsupported");
-    if (od_y < 0 || od_x < 0 || od_y + H > 2 * Hd || od_x + W > 2 * Wd) DIP_FAIL("upsample_bwd_stats_crop: crop window outside the up-sampled image");
-    int nb;
-    const int ppb = pixels_per_block(Hd * Wd, C, &nb);
-    if (nb != nblk) DIP_FAIL("upsample_bwd_stats_crop: nblk mismatch (use dip_bn_bwd_nblk(Hd, Wd, C))");
-    hipLaunchKernelGGL(upsample_bwd_stats_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dcat, Cs_cat, choff, H,
-                       W, Hd, Wd, od_y, od_x, mode, y, Cy, C, state, Cs, slope, dz, Cdz, partials, ppb);
-    DIP_CHECK_LAUNCH();
-    return 0;
+    return dip_upsample_bwd_stats_crop_fin(dcat, Cs_cat, choff, H, W, Hd, Wd, od_y, od_x, mode, y, Cy, C, state, Cs, slope,
+                                           dz, Cdz, partials, nblk, nullptr, stream);
+}
+
+extern "C" int dip_upsample_bwd_stats(const float* dcat, int Cs_cat, int choff, int H, int W, int mode,
+                                      const float* y, int Cy, int C, const float* state, int Cs, float slope,
+                                      float* dz, int Cdz, float* partials, int nblk, void* stream) {
+    return dip_upsample_bwd_stats_crop_fin(dcat, Cs_cat, choff, H, W, (H + 1) / 2, (W + 1) / 2, 0, 0, mode, y, Cy, C, state,
+                                           Cs, slope, dz, Cdz, partials, nblk, nullptr, stream);
 }

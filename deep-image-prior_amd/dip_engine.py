@@ -79,9 +79,11 @@ class Act:
         self.Cs = round_up(Cch, 4)
         self.bn, self.slope = bn, slope
 
-    def transform(self) -> N.DipTransform:
+    def transform(self, shape_only=False) -> N.DipTransform:
         if self.bn is None:
             return N.DipTransform(None, None, 1.0)
+        if shape_only:          # planner's sizing pass: only "there is a transform" matters (never dereferenced)
+            return N.DipTransform(1, 1, self.slope)
         assert self.bn.Cs == self.Cs
         return N.DipTransform(_ptr(self.bn.state, 2 * self.Cs), _ptr(self.bn.state, 3 * self.Cs), self.slope)
 
@@ -124,6 +126,11 @@ class SkipEngine:
         # per-lane reads of y cost the big launches 35..75 us each, as much as the streaming statistics kernels they
         # replace (+0.5 % on a fast-class box, -1.5 % on a slow-class one) -- so it is opt-in
         self.fuse_bnb = os.environ.get("DIP_BNB_FUSE", "0") == "1"
+        # low-resolution layers (<= DIP_SMALL_MAX_PIXELS output pixels): ONE dip_conv_small launch per convolution
+        # (conv + in-workgroup split-K + BatchNorm partials + in-launch finalisation) instead of conv + split-K finish +
+        # bn_finalize, and data gradient + BatchNorm-backward statistics + finalisation instead of four launches
+        # (csrc/conv_small.hip, csrc/bn_ticket.h); DIP_CONV_NO_SMALL=1 / DIP_NO_TICKET_FIN=1 restore the round-3 lists
+        self.use_small = os.environ.get("DIP_CONV_NO_SMALL") is None
         self.device = None
         self.shape_key = None
         self.lib = None
@@ -259,6 +266,7 @@ class SkipEngine:
         self.stat2_need = self.ws2_need = 4            # scratch of the skip-branch convs (side stream)
         self.bwdp2_need = 4                            # ... and of the skip-branch BatchNorm backward
         self.bwdp3_need = 4                            # fused BatchNorm-backward partials of the thin data-gradient columns
+        self.ticket_need = 8                           # arrival counters of the in-launch finalisations (bn_ticket.h)
 
     def _build_plan(self, H, W, Cin_img):
         if min(H, W) < 2 ** self.nscales:
@@ -283,6 +291,10 @@ class SkipEngine:
                 self.ws_scratch2 = self._new(self.ws2_need)
                 self.bwd_scratch2 = self._new(self.bwdp2_need)
                 self.bwd_scratch3 = self._new(self.bwdp3_need)
+                # zero-initialised; every launch leaves its counters at zero
+                self.tickets = torch.zeros(self.ticket_need, dtype=torch.int32, device=self.device)
+                self._alloc.append(self.tickets)
+            self._ticket_off = 0
             self._fused_bnb = {}
             self._deferred = []
             self._replicate_bufs = set()
@@ -381,6 +393,27 @@ class SkipEngine:
         return None if self._sizing else self._new(n)
 
     # ------------------------------------------------------------------ op emitters
+    def _ticket(self, n=8):
+        """n arrival counters for one in-launch finalisation (sizing pass: only counts them)."""
+        if self._sizing:
+            self.ticket_need += n
+            return None
+        off = self._ticket_off
+        self._ticket_off += n
+        assert self._ticket_off <= self.tickets.numel()
+        return self.tickets.data_ptr() + 4 * off
+
+    def _bn_fin(self, bn: BNRec, ticket) -> N.DipBnFin:
+        m = bn.module
+        return N.DipBnFin(_ptr(self.params, bn.gamma_off), _ptr(self.params, bn.beta_off), float(m.eps), float(m.momentum),
+                          _ptr(bn.state), bn.Cs, bn.C,
+                          _ptr(self.bnbuf, bn.rm_off) if bn.rm_off >= 0 else None,
+                          _ptr(self.bnbuf, bn.rv_off) if bn.rv_off >= 0 else None, ticket)
+
+    def _bnb_fin(self, bn: BNRec, npix, ticket) -> N.DipBnbFin:
+        return N.DipBnbFin(_ptr(self.grads, bn.gamma_off), _ptr(self.grads, bn.beta_off), _ptr(bn.coef), bn.C, npix,
+                           ticket)
+
     def _emit_bn_finalize(self, bn: BNRec, scratch, rows, cstride):
         """Partial rows -> state block + running statistics (dip_bn_finalize).  A separate launch on
         purpose: finishing inside the producer ("last-arriving workgroup", arrival tickets) was built and
@@ -397,13 +430,25 @@ class SkipEngine:
         assert x.C == r.Cin, (r.name, x.C, r.Cin)
         Ho = (x.H + 2 * r.P - r.ks) // r.stride + 1
         Wo = (x.W + 2 * r.P - r.ks) // r.stride + 1
-        ksplit, ntiles, wsf = N.conv_plan(Ho, Wo, round_up(x.C, 4), r.Cout, r.ks, r.stride)
+        Cy = round_up(r.Cout, 4)
+        sizing = self._sizing
+        # (sizing pass: the descriptor carries the shape only -- buffers are None)
+        d = N.DipConvDesc(_ptr(x.buf), x.H, x.W, x.Cs, round_up(x.C, 4), x.transform(sizing),
+                          None if sizing else _ptr(self.packed, r.fwd_off),
+                          _ptr(self.params, r.b_off) if (r.b_off >= 0 and not sizing) else None,
+                          _ptr(y), Ho, Wo, Cy, r.Cout, 0, r.ks, r.stride, r.pad_mode, r.P, 1, 0, None, 1, None)
+        small = self.use_small and bool(self.lib.dip_conv_small_eligible(C.byref(d)))
+        if small:
+            ksplit, ntiles, wsf = 1, self.lib.dip_conv_small_rows(C.byref(d)), 0
+        else:
+            ksplit, ntiles, wsf = N.conv_plan(Ho, Wo, round_up(x.C, 4), r.Cout, r.ks, r.stride)
         # the skip-branch convs run on the side stream next to the encoder convs of their scale
         # (_run_two_streams), so they get scratch of their own
         side = r.name.endswith("skip_conv")
         if side and Ho * Wo >= self.side_min_pixels and bn is not None:
             self._fwd_side.update(("conv_fwd:" + r.name, "bn_fin:" + bn.name))
-        if self._sizing:
+        ticket = self._ticket() if (small and bn is not None) else None
+        if sizing:
             if side:
                 if bn is not None:
                     self.stat2_need = max(self.stat2_need, ntiles * 3 * round_up(r.Cout, 32))
@@ -415,14 +460,17 @@ class SkipEngine:
             return
         stats_scratch = self.stats_scratch2 if side else self.stats_scratch
         ws_scratch = self.ws_scratch2 if side else self.ws_scratch
-        Cy = round_up(r.Cout, 4)
-        d = N.DipConvDesc(_ptr(x.buf), x.H, x.W, x.Cs, round_up(x.C, 4), x.transform(),
-                          _ptr(self.packed, r.fwd_off), _ptr(self.params, r.b_off) if r.b_off >= 0 else None,
-                          _ptr(y), Ho, Wo, Cy, r.Cout, 0, r.ks, r.stride, r.pad_mode, r.P, 1, 0,
-                          _ptr(stats_scratch) if bn is not None else None,
-                          ksplit, _ptr(ws_scratch) if ksplit > 1 else None)
+        d.stats = _ptr(stats_scratch) if bn is not None else None
+        d.ksplit = ksplit
+        d.ws = _ptr(ws_scratch) if ksplit > 1 else None
         self.keep.append(d)
         lib = self.lib
+        if small:
+            # one launch: conv + BatchNorm partials + finalisation by the last workgroup to arrive
+            if bn is not None:
+                d.fin = self._bn_fin(bn, ticket)
+            self.fwd_ops.append((lib.dip_conv_small, (C.byref(d),), "conv_fwd:" + r.name))
+            return
         self.fwd_ops.append((lib.dip_conv_igemm, (C.byref(d),), "conv_fwd:" + r.name))
         if bn is not None:
             self._emit_bn_finalize(bn, stats_scratch, ntiles, round_up(r.Cout, 32))
@@ -441,6 +489,8 @@ class SkipEngine:
         Ccat = s.ns + deep.C
         Cs_cat = round_up(Ccat, 4)
         nblk = self.lib.dip_upcat_nblk(H, W, Ccat)
+        fin_ok = self.use_small and bool(self.lib.dip_fin_rows_ok(nblk, Ccat))
+        ticket = self._ticket() if fin_ok else None
         if self._sizing:
             self.stat_need = max(self.stat_need, nblk * 3 * Cs_cat)
             return
@@ -453,6 +503,11 @@ class SkipEngine:
             for k, v in geom.items():
                 setattr(d, k, v)
         self.keep.append(d)
+        if fin_ok:      # few partial rows: the last block to arrive finalises the concat BatchNorm (bn_ticket.h)
+            fin = self._bn_fin(s.cat_bn, ticket)
+            self.keep.append(fin)
+            self.fwd_ops.append((self.lib.dip_upcat_fwd_fin, (C.byref(d), C.byref(fin)), "upcat:" + s.cat_bn.name))
+            return
         self.fwd_ops.append((self.lib.dip_upcat_fwd, (C.byref(d),), "upcat:" + s.cat_bn.name))
         self._emit_bn_finalize(s.cat_bn, self.stats_scratch, nblk, Cs_cat)
 
@@ -519,7 +574,8 @@ class SkipEngine:
                               N.DipTransform(None, None, 1.0), _ptr(self.packed, r.dgrad_off), None,
                               ybase, Hg, Wg, Cg, r.Cin, Wg2, r.ks, 1, N.PAD_ZERO, off, 1, 1, None)
             self.keep.append(d)
-            ops.append((self.lib.dip_conv_igemm, (C.byref(d),), "dgrad+:" + r.name))
+            small = self.use_small and bool(self.lib.dip_conv_small_eligible(C.byref(d)))
+            ops.append((self.lib.dip_conv_small if small else self.lib.dip_conv_igemm, (C.byref(d),), "dgrad+:" + r.name))
             return accumulate_into
         gbuf = self._buf(Hg * Wg * Cg)
         if r.stride == 2:
@@ -531,6 +587,30 @@ class SkipEngine:
                           N.DipTransform(None, None, 1.0), None if sizing else _ptr(self.packed, r.dgrad_off), None,
                           None if sizing else _ptr(gbuf), Hg, Wg, Cg, r.Cin, 0, r.ks, 1, N.PAD_ZERO, off, r.stride, 0, None,
                           ksplit, (None if sizing else _ptr(self.ws_scratch)) if ksplit > 1 else None)
+        small = self.use_small and bool(self.lib.dip_conv_small_eligible(C.byref(d)))
+        if small:
+            # low resolution: ONE launch for all (<= 160) columns, no split-K workspace; when x feeds this conv only, phase 1
+            # of its BatchNorm(+activation) backward rides in the epilogue and the last workgroup to arrive finalises it
+            d.ksplit, d.ws = 1, None
+            rows = self.lib.dip_conv_small_rows(C.byref(d))
+            fuse = fuse_bn and x.bn is not None and r.pad_mode != N.PAD_REPLICATE and x.bn.C <= 256
+            ticket = self._ticket() if fuse else None
+            if sizing:
+                if fuse:
+                    self.bwdp_need = max(self.bwdp_need, rows * 2 * x.bn.Cs)
+                return (gbuf, pad)
+            if r.pad_mode == N.PAD_REPLICATE:
+                self._replicate_bufs.add(gbuf.data_ptr())
+            if fuse:
+                bn = x.bn
+                d.bnb_y, d.bnb_state = _ptr(x.buf), _ptr(bn.state)
+                d.bnb_partials = _ptr(self.bwd_scratch)
+                d.bnb_Cy, d.bnb_Cs, d.bnb_pad, d.bnb_slope = x.Cs, bn.Cs, pad, float(x.slope)
+                d.bnb_fin = self._bnb_fin(bn, x.H * x.W, ticket)
+                self._fused_bnb[gbuf.data_ptr()] = "small"
+            self.keep.append(d)
+            ops.append((self.lib.dip_conv_small, (C.byref(d),), "dgrad:" + r.name))
+            return (gbuf, pad)
         variant = self.lib.dip_conv_variant(C.byref(d))
         fused = None
         if fuse_bn and self.fuse_bnb and x.bn is not None and self.lib.dip_conv_bnb_fusable(C.byref(d)):
@@ -581,6 +661,8 @@ class SkipEngine:
         side=True: the op runs on the side stream (skip branch) and gets partial-sum scratch of its own."""
         bn = a.bn
         nblk = self.lib.dip_bn_bwd_nblk(a.H, a.W, a.C)
+        fin_ok = self.use_small and bool(self.lib.dip_fin_rows_ok(nblk, a.C))
+        ticket = self._ticket() if fin_ok else None      # (unused when the data gradient carried the statistics)
         if self._sizing:
             if side:
                 self.bwdp2_need = max(self.bwdp2_need, nblk * 2 * a.Cs)
@@ -594,7 +676,16 @@ class SkipEngine:
         # phase 1 only reduces (dz = NULL); phase 3 recomputes the masked gradient from the source:
         # 5 tensor passes per BatchNorm instead of 6
         fused = self._fused_bnb.get(g[0].data_ptr()) if (choff == 0 and not side) else None
-        if fused is not None:
+        if fused == "small":
+            pass        # phases 1 and 2 ran inside the data-gradient launch (dip_conv_small: bnb_* + bnb_fin)
+        elif fused is None and fin_ok:
+            # few partial rows: phase 2 rides in the statistics launch (the last block to arrive reduces them)
+            fin = self._bnb_fin(bn, a.H * a.W, ticket)
+            self.keep.append(fin)
+            ops.append((lib.dip_bn_bwd_stats_fin, (C.byref(src), _ptr(a.buf), a.H, a.W, a.Cs, a.C, _ptr(bn.state), bn.Cs,
+                                                   float(a.slope), None, a.Cs, _ptr(scratch), nblk, C.byref(fin)),
+                        "bnb_stats:" + bn.name))
+        elif fused is not None:
             # phase 1 already ran in the epilogue of the data-gradient launch(es) that produced g (_emit_dgrad)
             rows, rows_lo, c_lo = fused
             ops.append((lib.dip_bn_bwd_finalize2, (_ptr(self.bwd_scratch), rows, _ptr(self.bwd_scratch3) if c_lo else None,
@@ -615,12 +706,26 @@ class SkipEngine:
     def _emit_up_bwd(self, deep: Act, dcat, Cs_cat, choff, H, W, mode, ops, geom=None):
         bn = deep.bn
         nblk = self.lib.dip_bn_bwd_nblk(deep.H, deep.W, deep.C)
+        fin_ok = self.use_small and bool(self.lib.dip_fin_rows_ok(nblk, deep.C))
+        ticket = self._ticket() if fin_ok else None
         if self._sizing:
             self.bwdp_need = max(self.bwdp_need, nblk * 2 * deep.Cs)
             return None
         dz = self._new(deep.H * deep.W * deep.Cs)
         lib = self.lib
         m = N.UP_BILINEAR if mode == "bilinear" else N.UP_NEAREST
+        if fin_ok:
+            # adjoint of the up-sampling + phases 1 and 2 of the deeper branch's BatchNorm backward in one launch
+            fin = self._bnb_fin(bn, deep.H * deep.W, ticket)
+            self.keep.append(fin)
+            gm = geom if geom is not None else dict(Hd=(H + 1) // 2, Wd=(W + 1) // 2, od_y=0, od_x=0)
+            ops.append((lib.dip_upsample_bwd_stats_crop_fin,
+                        (_ptr(dcat), Cs_cat, choff, H, W, gm["Hd"], gm["Wd"], gm["od_y"], gm["od_x"], m,
+                         _ptr(deep.buf), deep.Cs, deep.C, _ptr(bn.state), bn.Cs, float(deep.slope), _ptr(dz), deep.Cs,
+                         _ptr(self.bwd_scratch), nblk, C.byref(fin)), "upb_stats:" + bn.name))
+            ops.append((lib.dip_bn_bwd_apply, (_ptr(dz), deep.Cs, _ptr(deep.buf), deep.Cs, deep.H * deep.W, deep.C,
+                                               _ptr(bn.state), bn.Cs, _ptr(bn.coef)), "bnb_apply:" + bn.name))
+            return dz
         if geom is None:
             ops.append((lib.dip_upsample_bwd_stats, (_ptr(dcat), Cs_cat, choff, H, W, m, _ptr(deep.buf), deep.Cs, deep.C,
                                                      _ptr(bn.state), bn.Cs, float(deep.slope), _ptr(dz), deep.Cs,

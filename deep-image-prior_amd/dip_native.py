@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdip_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 PAD_ZERO, PAD_REFLECT, PAD_REPLICATE = 0, 1, 2
 UP_NEAREST, UP_BILINEAR = 0, 1
@@ -28,6 +28,17 @@ class DipPackRec(C.Structure):
                 ("CinP4", C.c_int32), ("CoutP32", C.c_int32), ("CoutP4", C.c_int32), ("CinP32", C.c_int32)]
 
 
+class DipBnFin(C.Structure):
+    _fields_ = [("gamma", C.c_void_p), ("beta", C.c_void_p), ("eps", C.c_float), ("momentum", C.c_float),
+                ("state", C.c_void_p), ("Cs", C.c_int32), ("C", C.c_int32), ("running_mean", C.c_void_p),
+                ("running_var", C.c_void_p), ("ticket", C.c_void_p)]
+
+
+class DipBnbFin(C.Structure):
+    _fields_ = [("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("coef", C.c_void_p), ("C", C.c_int32),
+                ("npix", C.c_int32), ("ticket", C.c_void_p)]
+
+
 class DipConvDesc(C.Structure):
     _fields_ = [("x", C.c_void_p), ("Hin", C.c_int32), ("Win", C.c_int32), ("Cx", C.c_int32), ("Cin", C.c_int32),
                 ("tr", DipTransform), ("wp", C.c_void_p), ("bias", C.c_void_p), ("y", C.c_void_p),
@@ -39,7 +50,9 @@ class DipConvDesc(C.Structure):
                 # fused phase 1 of the BatchNorm backward of the conv's INPUT activation (data-gradient launches)
                 ("bnb_y", C.c_void_p), ("bnb_state", C.c_void_p), ("bnb_partials", C.c_void_p),
                 ("bnb_partials_thin", C.c_void_p), ("bnb_Cy", C.c_int32), ("bnb_Cs", C.c_int32),
-                ("bnb_pad", C.c_int32), ("bnb_slope", C.c_float)]
+                ("bnb_pad", C.c_int32), ("bnb_slope", C.c_float),
+                # dip_conv_small: in-launch finalisation of the consumer BatchNorm / of the fused backward partials
+                ("fin", DipBnFin), ("bnb_fin", DipBnbFin)]
 
 
 class DipWgradDesc(C.Structure):
@@ -91,6 +104,9 @@ _SIGS = {
     "dip_conv_bnb_fusable": (C.c_int, [C.POINTER(DipConvDesc)]),
     "dip_conv_thin4_ntiles": (C.c_int, [C.c_int, C.c_int]),
     "dip_conv_splitk_finish": (C.c_int, [C.POINTER(DipConvDesc), C.c_void_p]),
+    "dip_conv_small": (C.c_int, [C.POINTER(DipConvDesc), C.c_void_p]),
+    "dip_conv_small_eligible": (C.c_int, [C.POINTER(DipConvDesc)]),
+    "dip_conv_small_rows": (C.c_int, [C.POINTER(DipConvDesc)]),
     "dip_conv_thin4": (C.c_int, [C.POINTER(DipConvDesc), C.c_int, C.c_void_p]),
     "dip_conv_igemm_dma_cols": (C.c_int, [C.POINTER(DipConvDesc), C.c_int, C.c_void_p]),
     "dip_conv_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
@@ -122,6 +138,15 @@ _SIGS = {
     "dip_fold_to_nhwc": (C.c_int, [C.POINTER(DipGradSrc), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "dip_upcat_fwd": (C.c_int, [C.POINTER(DipUpcatDesc), C.c_void_p]),
     "dip_upcat_nblk": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "dip_upcat_fwd_fin": (C.c_int, [C.POINTER(DipUpcatDesc), C.POINTER(DipBnFin), C.c_void_p]),
+    "dip_fin_rows_ok": (C.c_int, [C.c_int, C.c_int]),
+    "dip_bn_bwd_stats_fin": (C.c_int, [C.POINTER(DipGradSrc), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                       C.POINTER(DipBnbFin), C.c_void_p]),
+    "dip_upsample_bwd_stats_crop_fin": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                  C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                                  C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                                  C.POINTER(DipBnbFin), C.c_void_p]),
     "dip_avgpool2_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                    C.c_int, C.c_void_p]),
     "dip_avgpool2_bwd": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DIP_ABI_VERSION 3
+#define DIP_ABI_VERSION 4
 
 #define DIP_PAD_ZERO 0
 #define DIP_PAD_REFLECT 1
@@ -82,6 +82,32 @@ int dip_pack_weights(const float* params, float* packed, const DipPackRec* recs_
                      int max_elems, void* stream);
 
 /* ---------------------------------------------------------------- convolution ------------- */
+/* In-launch finalisation of the BatchNorm2d that FOLLOWS a convolution (dip_conv_small; dip_upcat_fwd): the last
+ * workgroup to arrive (fence-free ticket, one counter per 32-channel block) reduces the partial rows in fp64 and
+ * writes the state block + running statistics -- exactly what dip_bn_finalize computes in a launch of its own
+ * (nn.BatchNorm2d training forward, models/common.py:95-96).  state == NULL: off (the caller runs dip_bn_finalize).
+ * `ticket` points at zero-initialised counters (ceil(Cout / 32) of them) that the launch leaves at zero. */
+typedef struct DipBnFin {
+    const float* gamma;
+    const float* beta;
+    float eps, momentum;
+    float* state;                /* [4][Cs]: mean, rstd, a, b */
+    int32_t Cs, C;
+    float* running_mean;         /* or NULL */
+    float* running_var;
+    uint32_t* ticket;
+} DipBnFin;
+/* The same for phase 2 of a BatchNorm backward whose phase 1 rides in a launch's epilogue (DipConvDesc.bnb_*;
+ * dip_upsample_bwd_stats): dgamma, dbeta (may be NULL) and coef [2][bnb_Cs] = {k1 = S1 / npix, k2 = S2 / npix}, what
+ * dip_bn_bwd_finalize computes.  coef == NULL: off. */
+typedef struct DipBnbFin {
+    float* dgamma;
+    float* dbeta;
+    float* coef;
+    int32_t C, npix;
+    uint32_t* ticket;
+} DipBnbFin;
+
 /* Implicit-GEMM convolution on the fp32 MFMA (v_mfma_f32_32x32x2_f32):
  *   y[q][o] (+)= bias[o] + sum_{tap,c} u[src(q,tap)][c] * Wp[tap][c][o],  u = transform(x)
  * per spatial dim  v = q*stride + k - off ; pad_mode reflect mirrors v into [0,Hv), zero drops
@@ -125,6 +151,10 @@ typedef struct DipConvDesc {
     float* bnb_partials_thin;
     int32_t bnb_Cy, bnb_Cs, bnb_pad;
     float bnb_slope;
+    /* dip_conv_small only (ABI 4): finalisation of the consumer BatchNorm (needs `stats`) / of the fused
+     * BatchNorm-backward partials (needs bnb_*) by the last workgroup to arrive; other kernels ignore them */
+    DipBnFin fin;
+    DipBnbFin bnb_fin;
 } DipConvDesc;
 int dip_conv_igemm(const DipConvDesc* d, void* stream);
 /* number of 8x16 output tiles */
@@ -159,6 +189,18 @@ int dip_conv_variant(const DipConvDesc* d);
  * n_base on the LDS-DMA kernel.  Same descriptor as dip_conv_igemm. */
 int dip_conv_thin4(const DipConvDesc* d, int ncols, void* stream);
 int dip_conv_igemm_dma_cols(const DipConvDesc* d, int n_base, void* stream);
+/* Low-resolution layers (models/skip.py:57-91 at depth >= 2: <= 64x64 outputs in the notebooks' nets): ONE launch per
+ * convolution instead of conv + split-K finish + dip_bn_finalize.  A wave computes 32 pixels x 32 channels x a K slice
+ * with operands straight from L2 (no LDS staging), 1 / 2 / 4 waves of a workgroup share a tile and are summed in a
+ * fixed order, the epilogue emits the BatchNorm partials (`stats`: [rows][3][CoutP32]) and -- d->fin.state != NULL --
+ * finalises them; data gradients: d->bnb_* partials ([rows][2][bnb_Cs], any 1..160 output columns, no conv_thin4
+ * side launch) and d->bnb_fin.  1x1 / 3x3, stride 1 / 2, dil 1 / 2 (dil == 2: per output-parity class, only the taps
+ * that hit non-zero positions), every padding mode and activation; d->ksplit / d->ws are ignored.
+ * dip_conv_small_eligible: the shape is served AND Hout * Wout <= DIP_SMALL_MAX_PIXELS (default 4624 = 68 x 68);
+ * dip_conv_small_rows: rows of the partial buffers (0: shape not served). */
+int dip_conv_small(const DipConvDesc* d, void* stream);
+int dip_conv_small_eligible(const DipConvDesc* d);
+int dip_conv_small_rows(const DipConvDesc* d);
 /* second half of a split-K dispatch (d->ksplit > 1): fixed-order sum of the workspace slices, bias,
  * store, BatchNorm partials.  dip_conv_igemm calls it itself; exported for per-kernel timing. */
 int dip_conv_splitk_finish(const DipConvDesc* d, void* stream);
@@ -228,6 +270,11 @@ int dip_bn_bwd_stats(const DipGradSrc* src, const float* y, int H, int W, int Cy
                      const float* state, int Cs, float slope, float* dz, int Cdz,
                      float* partials /*[nblk][2][Cs]*/, int nblk, void* stream);
 int dip_bn_bwd_nblk(int H, int W, int C);
+/* phase 1 + in-launch phase 2 (fin->coef != NULL; needs dip_fin_rows_ok(nblk, C)): the last block to arrive writes
+ * dgamma, dbeta and coef, no dip_bn_bwd_finalize launch */
+int dip_bn_bwd_stats_fin(const DipGradSrc* src, const float* y, int H, int W, int Cy, int C,
+                         const float* state, int Cs, float slope, float* dz, int Cdz,
+                         float* partials /*[nblk][2][Cs]*/, int nblk, const DipBnbFin* fin, void* stream);
 /* phase 2: reduce partials -> dgamma, dbeta (grad arena) and k1 = S1/N, k2 = S2/N in `coef` [2][Cs] */
 int dip_bn_bwd_finalize(const float* partials, int nblk, int Cs, int C, int npix, float* dgamma,
                         float* dbeta, float* coef, void* stream);
@@ -268,6 +315,11 @@ typedef struct DipUpcatDesc {
     int32_t Hd, Wd, od_y, od_x;
 } DipUpcatDesc;
 int dip_upcat_fwd(const DipUpcatDesc* d, void* stream);
+/* the same launch + in-launch finalisation of the concat BatchNorm (fin->state != NULL; needs dip_fin_rows_ok(d->nblk, ns + nd)) */
+int dip_upcat_fwd_fin(const DipUpcatDesc* d, const DipBnFin* fin, void* stream);
+/* 1 when a launch that writes `rows` partial rows of C channels may finalise them itself (<= 256 rows, <= 256 channels;
+ * DIP_NO_TICKET_FIN=1 switches every in-launch finalisation off) */
+int dip_fin_rows_ok(int rows, int C);
 int dip_upcat_nblk(int H, int W, int C);
 
 /* nn.AvgPool2d(2,2) behind a stride-1 conv (conv(..., downsample_mode='avg'), models/common.py:101-104):
@@ -296,6 +348,12 @@ int dip_upsample_bwd_stats(const float* dcat, int Cs_cat, int choff, int H, int 
 int dip_upsample_bwd_stats_crop(const float* dcat, int Cs_cat, int choff, int H, int W, int Hd, int Wd, int od_y,
                                 int od_x, int mode, const float* y, int Cy, int C, const float* state, int Cs,
                                 float slope, float* dz, int Cdz, float* partials, int nblk, void* stream);
+
+/* dip_upsample_bwd_stats_crop + in-launch phase 2 of the deeper branch's BatchNorm backward (fin as in dip_bn_bwd_stats_fin) */
+int dip_upsample_bwd_stats_crop_fin(const float* dcat, int Cs_cat, int choff, int H, int W, int Hd, int Wd, int od_y,
+                                    int od_x, int mode, const float* y, int Cy, int C, const float* state, int Cs,
+                                    float slope, float* dz, int Cdz, float* partials, int nblk, const DipBnbFin* fin,
+                                    void* stream);
 
 /* ---------------------------------------------------------------- optimiser --------------- */
 /* torch.optim.Adam(lr) defaults, one fused launch over a flat arena

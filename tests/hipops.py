@@ -171,3 +171,99 @@ def lrelu_masks(net, spec):
             z = torch.addcmul(state[3], state[2], y)            # fma(a, y, b), as the kernels do
             masks[key] = (z[:, :, :a.C] > 0).permute(2, 0, 1)[None].contiguous().cpu()
     return masks
+
+
+def _zeros_i32(n, dev):
+    return torch.zeros(n, dtype=torch.int32, device=dev)
+
+
+def conv_small_fwd(x, w, bias, stride, pad_mode, tr=(None, None, 1.0), bn=None):
+    """dip_conv_small forward: y [1,Cout,Ho,Wo], the partial rows [rows][3][CoutP], and -- bn = dict(gamma, beta, eps,
+    momentum, running_mean, running_var) -- the state block / running statistics written by the in-launch finalisation."""
+    lib = N.lib()
+    dev = x.device
+    _, Cin, H, W = x.shape
+    Cout, _, ks, _ = w.shape
+    P = (ks - 1) // 2
+    Ho, Wo = (H + 2 * P - ks) // stride + 1, (W + 2 * P - ks) // stride + 1
+    xb = to_nhwc(x)
+    packed, fo, _ = pack(w)
+    Cy = round_up(Cout, 4)
+    CoutP = round_up(Cout, 32)
+    y = torch.full((Ho * Wo * Cy,), float("nan"), dtype=torch.float32, device=dev)
+    trd, keep = transform(*tr)
+    bb = bias.contiguous().float() if bias is not None else None
+    d = N.DipConvDesc(xb.data_ptr(), H, W, round_up(Cin, 4), round_up(Cin, 4), trd, packed.data_ptr() + 4 * fo,
+                      bb.data_ptr() if bb is not None else None, y.data_ptr(), Ho, Wo, Cy, Cout, 0, ks, stride,
+                      pad_mode if P > 0 else N.PAD_ZERO, P, 1, 0, None, 1, None)
+    rows = lib.dip_conv_small_rows(C.byref(d))
+    assert rows > 0, "shape not served by dip_conv_small"
+    stats = torch.full((rows * 3 * CoutP,), float("nan"), dtype=torch.float32, device=dev)
+    d.stats = stats.data_ptr()
+    out = {}
+    if bn is not None:
+        Cs = round_up(Cout, 4)
+        state = torch.full((4 * Cs,), float("nan"), dtype=torch.float32, device=dev)
+        gamma, beta = bn["gamma"].to(dev).float().contiguous(), bn["beta"].to(dev).float().contiguous()
+        rm, rv = bn["running_mean"].to(dev).float().clone(), bn["running_var"].to(dev).float().clone()
+        tickets = _zeros_i32(8, dev)
+        d.fin = N.DipBnFin(gamma.data_ptr(), beta.data_ptr(), float(bn["eps"]), float(bn["momentum"]), state.data_ptr(),
+                           Cs, Cout, rm.data_ptr(), rv.data_ptr(), tickets.data_ptr())
+        out = dict(state=state.view(4, Cs), running_mean=rm, running_var=rv, tickets=tickets)
+    for _ in range(2 if bn is None else 1):        # (a second launch must find the arrival counters at zero)
+        N.check(lib.dip_conv_small(C.byref(d), stream(dev)), "conv_small")
+    torch.cuda.synchronize()
+    padvals = y.view(Ho, Wo, Cy)[:, :, Cout:]
+    assert torch.all(padvals == 0), "pad channels must be written as zeros"
+    return from_nhwc(y, Cout, Ho, Wo), stats.view(rows, 3, CoutP), out
+
+
+def conv_small_dgrad(dy, w, stride, pad_mode, Hin, Win, bnb=None, accumulate_into=None):
+    """dip_conv_small data gradient of a conv (OIHW w, stride, pad_mode) wrt its [1,Cin,Hin,Win] input, folded to NCHW.
+    bnb = dict(y=[1,Cin,Hin,Win] raw output of the producer conv, state=[4,Cs] (mean, rstd, a, b), slope): phase 1 + 2 of the
+    producer BatchNorm's backward ride in the launch; returns (gx, dict(coef, dgamma, dbeta))."""
+    lib = N.lib()
+    dev = dy.device
+    Cout, Cin, ks, _ = w.shape
+    P = (ks - 1) // 2
+    _, _, Ho, Wo = dy.shape
+    reflect = pad_mode in (N.PAD_REFLECT, N.PAD_REPLICATE) and P > 0
+    pad = P if reflect else 0
+    Hg, Wg = Hin + 2 * pad, Win + 2 * pad
+    off = (ks - 1) if reflect else (ks - 1 - P)
+    packed, _, do = pack(w)
+    dyb = to_nhwc(dy)
+    Cg = round_up(Cin, 4)
+    g = torch.full((Hg * Wg * Cg,), float("nan"), dtype=torch.float32, device=dev)
+    d = N.DipConvDesc(dyb.data_ptr(), Ho, Wo, round_up(Cout, 4), round_up(Cout, 4), N.DipTransform(None, None, 1.0),
+                      packed.data_ptr() + 4 * do, None, g.data_ptr(), Hg, Wg, Cg, Cin, 0, ks, 1, N.PAD_ZERO, off,
+                      stride, 0, None, 1, None)
+    rows = lib.dip_conv_small_rows(C.byref(d))
+    assert rows > 0, "shape not served by dip_conv_small"
+    out = {}
+    if bnb is not None:
+        Cs = Cg
+        yb = to_nhwc(bnb["y"].to(dev))
+        state = bnb["state"].to(dev).float().contiguous()
+        assert state.shape == (4, Cs)
+        part = torch.full((rows * 2 * Cs,), float("nan"), dtype=torch.float32, device=dev)
+        coef = torch.full((2 * Cs,), float("nan"), dtype=torch.float32, device=dev)
+        dgamma = torch.full((Cin,), float("nan"), dtype=torch.float32, device=dev)
+        dbeta = torch.full((Cin,), float("nan"), dtype=torch.float32, device=dev)
+        tickets = _zeros_i32(8, dev)
+        d.bnb_y, d.bnb_state, d.bnb_partials = yb.data_ptr(), state.data_ptr(), part.data_ptr()
+        d.bnb_Cy, d.bnb_Cs, d.bnb_pad, d.bnb_slope = Cg, Cs, pad, float(bnb["slope"])
+        d.bnb_fin = N.DipBnbFin(dgamma.data_ptr(), dbeta.data_ptr(), coef.data_ptr(), Cin, Hin * Win, tickets.data_ptr())
+        out = dict(coef=coef.view(2, Cs), dgamma=dgamma, dbeta=dbeta, tickets=tickets, keep=(yb, state, part))
+    N.check(lib.dip_conv_small(C.byref(d), stream(dev)), "conv_small(dgrad)")
+    if bnb is not None:             # a second launch must find the counters at zero and reproduce the result bit for bit
+        torch.cuda.synchronize()
+        c1 = out["coef"].clone()
+        N.check(lib.dip_conv_small(C.byref(d), stream(dev)), "conv_small(dgrad) #2")
+        torch.cuda.synchronize()
+        assert torch.equal(c1, out["coef"]) and int(out["tickets"].abs().sum()) == 0
+    src = N.DipGradSrc(g.data_ptr(), pad, (2 if pad_mode == N.PAD_REPLICATE else 1) if pad else 0, Cg, 0)
+    gx = torch.empty(1, Cin, Hin, Win, dtype=torch.float32, device=dev)
+    N.check(lib.dip_fold_to_nchw(C.byref(src), Hin, Win, Cin, gx.data_ptr(), stream(dev)), "fold")
+    torch.cuda.synchronize()
+    return gx, out

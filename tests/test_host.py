@@ -23,7 +23,7 @@ def test_cabi_exports_every_declared_symbol(built):
     L = ctypes.CDLL(dip_native.LIB_PATH)
     for name in declared:
         assert hasattr(L, name), name
-    assert built.dip_abi_version() == dip_native.ABI_VERSION == 3
+    assert built.dip_abi_version() == dip_native.ABI_VERSION == 4
     # struct layouts agree with the header's field order (sizes on LP64)
     assert ctypes.sizeof(dip_native.DipTransform) == 24
     assert ctypes.sizeof(dip_native.DipGradSrc) == 40     # + the crop window of round 3
