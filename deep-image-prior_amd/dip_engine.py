@@ -131,6 +131,11 @@ class SkipEngine:
         # bn_finalize, and data gradient + BatchNorm-backward statistics + finalisation instead of four launches
         # (csrc/conv_small.hip, csrc/bn_ticket.h); DIP_CONV_NO_SMALL=1 / DIP_NO_TICKET_FIN=1 restore the round-3 lists
         self.use_small = os.environ.get("DIP_CONV_NO_SMALL") is None
+        # in-launch BatchNorm finalisation by the last workgroup to arrive (csrc/bn_ticket.h) for up-sample + concat and
+        # the backward statistics passes: built, parity-tested, and measured SLOWER than a finalisation launch of its own
+        # (the write-through stores, the ticket and the L2-bypassing row loads are three dependent memory round trips at
+        # the end of the producer: -1.5 % end to end) -- opt-in
+        self.ticket_fin = os.environ.get("DIP_TICKET_FIN") == "1"
         self.device = None
         self.shape_key = None
         self.lib = None
@@ -447,7 +452,6 @@ class SkipEngine:
         side = r.name.endswith("skip_conv")
         if side and Ho * Wo >= self.side_min_pixels and bn is not None:
             self._fwd_side.update(("conv_fwd:" + r.name, "bn_fin:" + bn.name))
-        ticket = self._ticket() if (small and bn is not None) else None
         if sizing:
             if side:
                 if bn is not None:
@@ -465,13 +469,8 @@ class SkipEngine:
         d.ws = _ptr(ws_scratch) if ksplit > 1 else None
         self.keep.append(d)
         lib = self.lib
-        if small:
-            # one launch: conv + BatchNorm partials + finalisation by the last workgroup to arrive
-            if bn is not None:
-                d.fin = self._bn_fin(bn, ticket)
-            self.fwd_ops.append((lib.dip_conv_small, (C.byref(d),), "conv_fwd:" + r.name))
-            return
-        self.fwd_ops.append((lib.dip_conv_igemm, (C.byref(d),), "conv_fwd:" + r.name))
+        # low resolution: one launch for conv + in-workgroup split-K + BatchNorm partials (no workspace, no finish launch)
+        self.fwd_ops.append((lib.dip_conv_small if small else lib.dip_conv_igemm, (C.byref(d),), "conv_fwd:" + r.name))
         if bn is not None:
             self._emit_bn_finalize(bn, stats_scratch, ntiles, round_up(r.Cout, 32))
 
@@ -489,7 +488,7 @@ class SkipEngine:
         Ccat = s.ns + deep.C
         Cs_cat = round_up(Ccat, 4)
         nblk = self.lib.dip_upcat_nblk(H, W, Ccat)
-        fin_ok = self.use_small and bool(self.lib.dip_fin_rows_ok(nblk, Ccat))
+        fin_ok = self.ticket_fin and bool(self.lib.dip_fin_rows_ok(nblk, Ccat))
         ticket = self._ticket() if fin_ok else None
         if self._sizing:
             self.stat_need = max(self.stat_need, nblk * 3 * Cs_cat)
@@ -590,11 +589,10 @@ class SkipEngine:
         small = self.use_small and bool(self.lib.dip_conv_small_eligible(C.byref(d)))
         if small:
             # low resolution: ONE launch for all (<= 160) columns, no split-K workspace; when x feeds this conv only, phase 1
-            # of its BatchNorm(+activation) backward rides in the epilogue and the last workgroup to arrive finalises it
+            # of its BatchNorm(+activation) backward rides in the epilogue
             d.ksplit, d.ws = 1, None
             rows = self.lib.dip_conv_small_rows(C.byref(d))
-            fuse = fuse_bn and x.bn is not None and r.pad_mode != N.PAD_REPLICATE and x.bn.C <= 256
-            ticket = self._ticket() if fuse else None
+            fuse = fuse_bn and x.bn is not None and r.pad_mode != N.PAD_REPLICATE
             if sizing:
                 if fuse:
                     self.bwdp_need = max(self.bwdp_need, rows * 2 * x.bn.Cs)
@@ -606,8 +604,7 @@ class SkipEngine:
                 d.bnb_y, d.bnb_state = _ptr(x.buf), _ptr(bn.state)
                 d.bnb_partials = _ptr(self.bwd_scratch)
                 d.bnb_Cy, d.bnb_Cs, d.bnb_pad, d.bnb_slope = x.Cs, bn.Cs, pad, float(x.slope)
-                d.bnb_fin = self._bnb_fin(bn, x.H * x.W, ticket)
-                self._fused_bnb[gbuf.data_ptr()] = "small"
+                self._fused_bnb[gbuf.data_ptr()] = (rows, 0, 0)        # -> dip_bn_bwd_finalize2 over these rows, then apply
             self.keep.append(d)
             ops.append((self.lib.dip_conv_small, (C.byref(d),), "dgrad:" + r.name))
             return (gbuf, pad)
@@ -661,7 +658,7 @@ class SkipEngine:
         side=True: the op runs on the side stream (skip branch) and gets partial-sum scratch of its own."""
         bn = a.bn
         nblk = self.lib.dip_bn_bwd_nblk(a.H, a.W, a.C)
-        fin_ok = self.use_small and bool(self.lib.dip_fin_rows_ok(nblk, a.C))
+        fin_ok = self.ticket_fin and bool(self.lib.dip_fin_rows_ok(nblk, a.C))
         ticket = self._ticket() if fin_ok else None      # (unused when the data gradient carried the statistics)
         if self._sizing:
             if side:
@@ -676,9 +673,7 @@ class SkipEngine:
         # phase 1 only reduces (dz = NULL); phase 3 recomputes the masked gradient from the source:
         # 5 tensor passes per BatchNorm instead of 6
         fused = self._fused_bnb.get(g[0].data_ptr()) if (choff == 0 and not side) else None
-        if fused == "small":
-            pass        # phases 1 and 2 ran inside the data-gradient launch (dip_conv_small: bnb_* + bnb_fin)
-        elif fused is None and fin_ok:
+        if fused is None and fin_ok:
             # few partial rows: phase 2 rides in the statistics launch (the last block to arrive reduces them)
             fin = self._bnb_fin(bn, a.H * a.W, ticket)
             self.keep.append(fin)
@@ -706,7 +701,7 @@ class SkipEngine:
     def _emit_up_bwd(self, deep: Act, dcat, Cs_cat, choff, H, W, mode, ops, geom=None):
         bn = deep.bn
         nblk = self.lib.dip_bn_bwd_nblk(deep.H, deep.W, deep.C)
-        fin_ok = self.use_small and bool(self.lib.dip_fin_rows_ok(nblk, deep.C))
+        fin_ok = self.ticket_fin and bool(self.lib.dip_fin_rows_ok(nblk, deep.C))
         ticket = self._ticket() if fin_ok else None
         if self._sizing:
             self.bwdp_need = max(self.bwdp_need, nblk * 2 * deep.Cs)

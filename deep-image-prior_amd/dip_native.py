@@ -50,9 +50,7 @@ class DipConvDesc(C.Structure):
                 # fused phase 1 of the BatchNorm backward of the conv's INPUT activation (data-gradient launches)
                 ("bnb_y", C.c_void_p), ("bnb_state", C.c_void_p), ("bnb_partials", C.c_void_p),
                 ("bnb_partials_thin", C.c_void_p), ("bnb_Cy", C.c_int32), ("bnb_Cs", C.c_int32),
-                ("bnb_pad", C.c_int32), ("bnb_slope", C.c_float),
-                # dip_conv_small: in-launch finalisation of the consumer BatchNorm / of the fused backward partials
-                ("fin", DipBnFin), ("bnb_fin", DipBnbFin)]
+                ("bnb_pad", C.c_int32), ("bnb_slope", C.c_float)]
 
 
 class DipWgradDesc(C.Structure):

@@ -82,7 +82,7 @@ int dip_pack_weights(const float* params, float* packed, const DipPackRec* recs_
                      int max_elems, void* stream);
 
 /* ---------------------------------------------------------------- convolution ------------- */
-/* In-launch finalisation of the BatchNorm2d that FOLLOWS a convolution (dip_conv_small; dip_upcat_fwd): the last
+/* In-launch finalisation of the BatchNorm2d that follows a launch (dip_upcat_fwd_fin; opt-in, DIP_TICKET_FIN=1): the last
  * workgroup to arrive (fence-free ticket, one counter per 32-channel block) reduces the partial rows in fp64 and
  * writes the state block + running statistics -- exactly what dip_bn_finalize computes in a launch of its own
  * (nn.BatchNorm2d training forward, models/common.py:95-96).  state == NULL: off (the caller runs dip_bn_finalize).
@@ -97,8 +97,7 @@ typedef struct DipBnFin {
     float* running_var;
     uint32_t* ticket;
 } DipBnFin;
-/* The same for phase 2 of a BatchNorm backward whose phase 1 rides in a launch's epilogue (DipConvDesc.bnb_*;
- * dip_upsample_bwd_stats): dgamma, dbeta (may be NULL) and coef [2][bnb_Cs] = {k1 = S1 / npix, k2 = S2 / npix}, what
+/* The same for phase 2 of a BatchNorm backward (dip_bn_bwd_stats_fin, dip_upsample_bwd_stats_crop_fin): dgamma, dbeta (may be NULL) and coef [2][bnb_Cs] = {k1 = S1 / npix, k2 = S2 / npix}, what
  * dip_bn_bwd_finalize computes.  coef == NULL: off. */
 typedef struct DipBnbFin {
     float* dgamma;
@@ -151,10 +150,6 @@ typedef struct DipConvDesc {
     float* bnb_partials_thin;
     int32_t bnb_Cy, bnb_Cs, bnb_pad;
     float bnb_slope;
-    /* dip_conv_small only (ABI 4): finalisation of the consumer BatchNorm (needs `stats`) / of the fused
-     * BatchNorm-backward partials (needs bnb_*) by the last workgroup to arrive; other kernels ignore them */
-    DipBnFin fin;
-    DipBnbFin bnb_fin;
 } DipConvDesc;
 int dip_conv_igemm(const DipConvDesc* d, void* stream);
 /* number of 8x16 output tiles */
@@ -190,12 +185,13 @@ int dip_conv_variant(const DipConvDesc* d);
 int dip_conv_thin4(const DipConvDesc* d, int ncols, void* stream);
 int dip_conv_igemm_dma_cols(const DipConvDesc* d, int n_base, void* stream);
 /* Low-resolution layers (models/skip.py:57-91 at depth >= 2: <= 64x64 outputs in the notebooks' nets): ONE launch per
- * convolution instead of conv + split-K finish + dip_bn_finalize.  A wave computes 32 pixels x 32 channels x a K slice
- * with operands straight from L2 (no LDS staging), 1 / 2 / 4 waves of a workgroup share a tile and are summed in a
- * fixed order, the epilogue emits the BatchNorm partials (`stats`: [rows][3][CoutP32]) and -- d->fin.state != NULL --
- * finalises them; data gradients: d->bnb_* partials ([rows][2][bnb_Cs], any 1..160 output columns, no conv_thin4
- * side launch) and d->bnb_fin.  1x1 / 3x3, stride 1 / 2, dil 1 / 2 (dil == 2: per output-parity class, only the taps
- * that hit non-zero positions), every padding mode and activation; d->ksplit / d->ws are ignored.
+ * convolution instead of conv + split-K finish.  A workgroup computes one 32-pixel x 32-channel tile; its 4 / 8 / 16 waves
+ * split K, each with its whole slice of operand loads in flight at once, straight from L2 into the MFMA registers (no LDS
+ * staging: such a layer is latency-bound, not bandwidth-bound), and are summed through LDS in a fixed order; the epilogue
+ * emits the BatchNorm partials (`stats`: [rows][3][CoutP32], for dip_bn_finalize) or -- data gradients -- the d->bnb_*
+ * partials ([rows][2][bnb_Cs], for dip_bn_bwd_finalize2 with nblk_lo = 0); any 1..160 output columns (no conv_thin4 side
+ * launch).  1x1 / 3x3, stride 1 / 2, dil 1 / 2 (dil == 2: per output-parity class, only the taps that hit non-zero
+ * positions), every padding mode and activation; d->ksplit / d->ws are ignored.
  * dip_conv_small_eligible: the shape is served AND Hout * Wout <= DIP_SMALL_MAX_PIXELS (default 4624 = 68 x 68);
  * dip_conv_small_rows: rows of the partial buffers (0: shape not served). */
 int dip_conv_small(const DipConvDesc* d, void* stream);

@@ -179,7 +179,7 @@ def _zeros_i32(n, dev):
 
 def conv_small_fwd(x, w, bias, stride, pad_mode, tr=(None, None, 1.0), bn=None):
     """dip_conv_small forward: y [1,Cout,Ho,Wo], the partial rows [rows][3][CoutP], and -- bn = dict(gamma, beta, eps,
-    momentum, running_mean, running_var) -- the state block / running statistics written by the in-launch finalisation."""
+    momentum, running_mean, running_var) -- the state block / running statistics dip_bn_finalize makes of the rows."""
     lib = N.lib()
     dev = x.device
     _, Cin, H, W = x.shape
@@ -201,17 +201,17 @@ def conv_small_fwd(x, w, bias, stride, pad_mode, tr=(None, None, 1.0), bn=None):
     stats = torch.full((rows * 3 * CoutP,), float("nan"), dtype=torch.float32, device=dev)
     d.stats = stats.data_ptr()
     out = {}
+    for _ in range(2):                           # (launching twice must not change anything)
+        N.check(lib.dip_conv_small(C.byref(d), stream(dev)), "conv_small")
     if bn is not None:
         Cs = round_up(Cout, 4)
         state = torch.full((4 * Cs,), float("nan"), dtype=torch.float32, device=dev)
         gamma, beta = bn["gamma"].to(dev).float().contiguous(), bn["beta"].to(dev).float().contiguous()
         rm, rv = bn["running_mean"].to(dev).float().clone(), bn["running_var"].to(dev).float().clone()
-        tickets = _zeros_i32(8, dev)
-        d.fin = N.DipBnFin(gamma.data_ptr(), beta.data_ptr(), float(bn["eps"]), float(bn["momentum"]), state.data_ptr(),
-                           Cs, Cout, rm.data_ptr(), rv.data_ptr(), tickets.data_ptr())
-        out = dict(state=state.view(4, Cs), running_mean=rm, running_var=rv, tickets=tickets)
-    for _ in range(2 if bn is None else 1):        # (a second launch must find the arrival counters at zero)
-        N.check(lib.dip_conv_small(C.byref(d), stream(dev)), "conv_small")
+        N.check(lib.dip_bn_finalize(stats.data_ptr(), rows, CoutP, Cout, gamma.data_ptr(), beta.data_ptr(), float(bn["eps"]),
+                                    float(bn["momentum"]), state.data_ptr(), Cs, rm.data_ptr(), rv.data_ptr(), stream(dev)),
+                "bn_finalize")
+        out = dict(state=state.view(4, Cs), running_mean=rm, running_var=rv)
     torch.cuda.synchronize()
     padvals = y.view(Ho, Wo, Cy)[:, :, Cout:]
     assert torch.all(padvals == 0), "pad channels must be written as zeros"
@@ -250,18 +250,13 @@ def conv_small_dgrad(dy, w, stride, pad_mode, Hin, Win, bnb=None, accumulate_int
         coef = torch.full((2 * Cs,), float("nan"), dtype=torch.float32, device=dev)
         dgamma = torch.full((Cin,), float("nan"), dtype=torch.float32, device=dev)
         dbeta = torch.full((Cin,), float("nan"), dtype=torch.float32, device=dev)
-        tickets = _zeros_i32(8, dev)
         d.bnb_y, d.bnb_state, d.bnb_partials = yb.data_ptr(), state.data_ptr(), part.data_ptr()
         d.bnb_Cy, d.bnb_Cs, d.bnb_pad, d.bnb_slope = Cg, Cs, pad, float(bnb["slope"])
-        d.bnb_fin = N.DipBnbFin(dgamma.data_ptr(), dbeta.data_ptr(), coef.data_ptr(), Cin, Hin * Win, tickets.data_ptr())
-        out = dict(coef=coef.view(2, Cs), dgamma=dgamma, dbeta=dbeta, tickets=tickets, keep=(yb, state, part))
+        out = dict(coef=coef.view(2, Cs), dgamma=dgamma, dbeta=dbeta, keep=(yb, state, part))
     N.check(lib.dip_conv_small(C.byref(d), stream(dev)), "conv_small(dgrad)")
-    if bnb is not None:             # a second launch must find the counters at zero and reproduce the result bit for bit
-        torch.cuda.synchronize()
-        c1 = out["coef"].clone()
-        N.check(lib.dip_conv_small(C.byref(d), stream(dev)), "conv_small(dgrad) #2")
-        torch.cuda.synchronize()
-        assert torch.equal(c1, out["coef"]) and int(out["tickets"].abs().sum()) == 0
+    if bnb is not None:
+        N.check(lib.dip_bn_bwd_finalize2(part.data_ptr(), rows, None, 0, 0, Cs, Cin, Hin * Win, dgamma.data_ptr(),
+                                         dbeta.data_ptr(), coef.data_ptr(), stream(dev)), "bn_bwd_finalize2")
     src = N.DipGradSrc(g.data_ptr(), pad, (2 if pad_mode == N.PAD_REPLICATE else 1) if pad else 0, Cg, 0)
     gx = torch.empty(1, Cin, Hin, Win, dtype=torch.float32, device=dev)
     N.check(lib.dip_fold_to_nchw(C.byref(src), Hin, Win, Cin, gx.data_ptr(), stream(dev)), "fold")

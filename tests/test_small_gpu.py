@@ -38,7 +38,7 @@ SMALL_CASES = [
 
 
 @pytest.mark.parametrize("case", SMALL_CASES, ids=lambda c: "x".join(map(str, c)))
-def test_conv_small_forward_stats_and_finalisation(dev, case):
+def test_conv_small_forward_and_stats(dev, case):
     Cin, Cout, ks, stride, pad, Hh, Ww, use_tr = case
     x, w, b, a, bb = _mk(case)
     slope = 0.2
@@ -60,7 +60,7 @@ def test_conv_small_forward_stats_and_finalisation(dev, case):
     assert np.allclose(N_, r.shape[1])
     assert np.allclose(mean, r.mean(1).numpy(), rtol=1e-5, atol=1e-5 * float(r.std()))
     assert np.allclose(var, r.var(1, unbiased=False).numpy(), rtol=2e-5)
-    # the in-launch finalisation == nn.BatchNorm2d (training) statistics of the launch's own output
+    # dip_bn_finalize over the launch's rows == nn.BatchNorm2d (training) statistics of the launch's own output
     yc = y.cpu().double()[0].reshape(Cout, -1)
     mu, vb = yc.mean(1), yc.var(1, unbiased=False)
     rstd = 1.0 / torch.sqrt(vb + 1e-5)
@@ -76,7 +76,6 @@ def test_conv_small_forward_stats_and_finalisation(dev, case):
     rv = 0.9 * bn["running_var"].double() + 0.1 * vb * npix / (npix - 1)
     assert torch.allclose(out["running_mean"].cpu().double(), rm, rtol=1e-5, atol=2e-6 * scale)
     assert torch.allclose(out["running_var"].cpu().double(), rv, rtol=2e-5)
-    assert int(out["tickets"].abs().sum()) == 0, "arrival counters must be left at zero"
 
 
 DGRAD_CASES = [
@@ -88,7 +87,7 @@ DGRAD_CASES = [
     (128, 128, 3, 2, REFLECT, 19, 27),           # odd sizes: ragged parity classes
     (128, 64, 3, 2, ZERO, 18, 22),
     (36, 64, 3, 1, ZERO, 21, 13),
-    (256, 128, 3, 1, REFLECT, 16, 16),
+    (160, 128, 3, 1, REFLECT, 16, 16),           # 5 full column blocks
     (16, 16, 3, 1, REPLICATE, 12, 20),
 ]
 
@@ -156,7 +155,6 @@ def test_conv_small_dgrad_with_fused_batchnorm_backward(dev, case):
                            ("k1", fin["coef"][0, :Cin] * npix, s1), ("k2", fin["coef"][1, :Cin] * npix, s2)):
         err = (got.cpu().double() - ref).abs().max().item()
         assert err <= 3e-6 * scale, f"{name}: {err:.3e} vs scale {scale:.3e}"
-    assert int(fin["tickets"].abs().sum()) == 0
 
 
 def test_upcat_and_backward_statistics_with_in_launch_finalisation(dev):
@@ -255,22 +253,3 @@ def test_upcat_and_backward_statistics_with_in_launch_finalisation(dev):
         out.append((coef.clone(), dga.clone(), dbe.clone(), dz.clone()))
     for a, b in zip(*out):
         assert torch.equal(a, b)
-
-
-def test_ticket_finalisation_is_repeatable(dev):
-    """200 launches of a small convolution with in-launch finalisation on fresh inputs: the state block always equals the
-    statistics of that launch's own output (a stale read of a partial row -- the failure mode of a broken write-through /
-    ticket protocol -- would show up as a state that belongs to another launch)."""
-    case = (128, 128, 3, 1, REFLECT, 32, 32, True)
-    Cin, Cout = case[0], case[1]
-    g = torch.Generator().manual_seed(5)
-    bn = dict(gamma=torch.ones(Cout), beta=torch.zeros(Cout), eps=1e-5, momentum=0.1, running_mean=torch.zeros(Cout),
-              running_var=torch.ones(Cout))
-    for it in range(40):
-        x, w, b, a, bb = _mk(case, seed=100 + it)
-        x = x * (1.0 + it) + it                      # very different statistics from launch to launch
-        y, stats, out = H.conv_small_fwd(x.to(dev), w.to(dev), b.to(dev), 1, REFLECT, (a.to(dev), bb.to(dev), 0.2), bn=bn)
-        yc = y.double()[0].reshape(Cout, -1)
-        mu = yc.mean(1)
-        scale = float(yc.std())
-        assert torch.allclose(out["state"][0, :Cout].double(), mu, rtol=1e-5, atol=2e-6 * scale), it
