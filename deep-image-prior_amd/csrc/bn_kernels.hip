@@ -31,7 +31,15 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     double K[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) K[e] = (c0 + e < Cstride) ? (double)partials[Cstride + c0 + e] : 0.0;
-#pragma unroll 2
+    // the parameters the last four threads need are requested NOW: their round trip overlaps the row loads instead of
+    // following the tree (the launch sits in the dependent chain of every BatchNorm: 30 per iteration)
+    float pg = 0.f, pb = 0.f, prm = 0.f, prv = 0.f;
+    if (row < 4 && c0 + row < C) {
+        pg = gamma[c0 + row];
+        pb = beta[c0 + row];
+        if (running_mean != nullptr) { prm = running_mean[c0 + row]; prv = running_var[c0 + row]; }
+    }
+#pragma unroll 8
     for (int t = row; t < ntiles; t += 256) {
         const float* p = partials + (size_t)t * 3 * Cstride + c0;
         float n[4], m[4], q[4];
@@ -69,21 +77,21 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
         const int c = c0 + row;
         const double N = sh[0][row], S1 = sh[0][4 + row], S2 = sh[0][8 + row];
         const double dmean = N > 0.0 ? S1 / N : 0.0;
-        const double mean = (double)partials[Cstride + c] + dmean;
+        const double mean = K[row] + dmean;
         double M2 = S2 - N * dmean * dmean;
         if (M2 < 0.0) M2 = 0.0;
         const double var = N > 0.0 ? M2 / N : 0.0;          // biased (normalisation)
         const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float a = gamma[c] * rstd;
+        const float a = pg * rstd;
         const float fm = (float)mean;
         state[c] = fm;
         state[Cs + c] = rstd;
         state[2 * Cs + c] = a;
-        state[3 * Cs + c] = beta[c] - fm * a;
+        state[3 * Cs + c] = pb - fm * a;
         if (running_mean != nullptr) {
             const double unb = N > 1.0 ? M2 / (N - 1.0) : var;
-            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * fm;
-            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+            running_mean[c] = (1.f - momentum) * prm + momentum * fm;
+            running_var[c] = (1.f - momentum) * prv + momentum * (float)unb;
         }
     }
 }
@@ -233,7 +241,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     const int c0 = blockIdx.x * 4;
     if (c0 < c_lo) { partials = partials_lo; nblk = nblk_lo; }      // (channels of the thin-column launch)
     double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 2
+#pragma unroll 8
     for (int t = row; t < nblk; t += 256) {
         const float* p = partials + (size_t)t * 2 * Cs + c0;      // Cs % 4 == 0, c0 + 3 < Cs
         const f32x4 v1 = ld4(p), v2 = ld4(p + Cs);

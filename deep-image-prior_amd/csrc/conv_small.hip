@@ -31,7 +31,7 @@
 namespace {
 
 constexpr int SM_TR_MAX = 512;      // input channels whose BatchNorm coefficients are cached in LDS
-constexpr int SM_MAX_TAPS = 9;
+constexpr int SM_MAX_TAPS = 27;     // ring mode: up to 3 mirror sources x 9 taps per target pixel
 
 struct SmallGeom {
     int ncls;                 // 1, or 4 output-parity classes (dil == 2: transposed stride-2 conv)
@@ -40,7 +40,23 @@ struct SmallGeom {
     int ngroups;              // = grid.x = rows of the partial-statistics buffers
     int nblk;                 // 32-column blocks of the output = grid.y
     int nw;                   // waves per workgroup = K slices of its tile (4, 8, 16)
+    int ring;                 // 1: dip_conv_dgrad_ring -- the tile's pixels are the frame rows 1, H-2 / columns 1, W-2 of
+                              // an H x W image and every pixel sums the data gradient of the reflection-padded ring
+                              // positions that mirror onto it (<= 3 sources x 9 taps), accumulated into y
 };
+
+// frame pixel i of an H x W image: rows 1 and H-2 (W pixels each), then columns 1 and W-2 without those rows
+__device__ __forceinline__ void sm_ring_pixel(int i, int H, int W, int& r, int& c) {
+    if (i < W) { r = 1; c = i; return; }
+    i -= W;
+    if (i < W) { r = H - 2; c = i; return; }
+    i -= W;
+    const int col = i < H - 2 ? 1 : W - 2;
+    if (i >= H - 2) i -= H - 2;
+    // rows 0 .. H-1 without 1 and H-2
+    r = i == 0 ? 0 : (i < H - 3 ? i + 1 : H - 1);
+    c = col;
+}
 
 // K steps (8 input channels of one tap = 4 MFMAs) a wave keeps in flight at once; 16 waves x 64 lanes x (8 * SMAX + ..)
 // registers must fit the 512-register file of a SIMD four times
@@ -67,7 +83,7 @@ __device__ __forceinline__ void sm_wait(f32x4& a, f32x4& b) {
 
 // TR: 0 = no input transform, 1 = BatchNorm + LeakyReLU / identity (slope in (0, 1]), 2 = BatchNorm + Swish / ELU
 // One workgroup = one 32-pixel x 32-channel output tile; its NW waves split K and are summed through LDS.
-template <int TR, int NW>
+template <int TR, int NW, bool RING = false>
 __global__ __launch_bounds__(64 * NW) void conv_small_kernel(const DipConvDesc d, const SmallGeom g) {
     constexpr int SMAX = SmCfg<NW>::SMAX;
     constexpr int RPW = 16 / NW;                // accumulator registers a wave reduces across the K slices
@@ -75,10 +91,10 @@ __global__ __launch_bounds__(64 * NW) void conv_small_kernel(const DipConvDesc d
     extern __shared__ __attribute__((aligned(16))) float red[];      // [NW][16][64] K-slice partial tiles
     __shared__ __attribute__((aligned(16))) float tra[TR ? SM_TR_MAX : 4];
     __shared__ __attribute__((aligned(16))) float trb[TR ? SM_TR_MAX : 4];
-    __shared__ int srcoff[SM_MAX_TAPS][32];     // source pixel of (tap, output pixel), -1: padding zero / outside
+    __shared__ int srcoff[RING ? SM_MAX_TAPS : 9][32];     // source pixel of (tap, output pixel), -1: padding zero / outside
     __shared__ int yoff[32];                    // output pixel offset (oy * pitch + ox) of the 32 pixels, -1: none
     __shared__ int boff[32];                    // mirror pixel of the fused BatchNorm backward (bnb_y index), -1: none
-    __shared__ int taps[NW][12];
+    __shared__ int taps[NW][(RING ? SM_MAX_TAPS : 9) + 1];
     __shared__ float fin[16 * 64];              // the summed tile, handed to wave 0
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
@@ -100,9 +116,32 @@ __global__ __launch_bounds__(64 * NW) void conv_small_kernel(const DipConvDesc d
         else if (group >= g.gstart[2]) { Hc = g.Hc[2]; Wc = g.Wc[2]; gs = g.gstart[2]; py = 1; px = 0; }
         else if (group >= g.gstart[1]) { Hc = g.Hc[1]; Wc = g.Wc[1]; gs = g.gstart[1]; py = 0; px = 1; }
     }
-    for (int e = tid; e < (KK + 1) * 32; e += NT) {
+    const int KV = RING ? 3 * KK : KK;        // (virtual) taps: ring mode walks up to 3 mirror sources per pixel
+    for (int e = tid; e < (KV + 1) * 32; e += NT) {
         const int t = e >> 5, p = e & 31;
         const int pi = (group - gs) * 32 + p;
+        if constexpr (RING) {
+            // target pixel (r, c) of the frame; source s = t / KK: 0 = the ring position above / below it (row -1 mirrors
+            // onto row 1, row H onto H-2), 1 = left / right of it, 2 = the corner; the ring position's data gradient
+            // is the zero-padded 3x3 correlation of dy with the flipped filter at (rho, gam), rho / gam in -1 .. H / W
+            const int H = d.Hout, W = d.Wout;
+            const bool pvalid = pi < 2 * W + 2 * (H - 2);
+            int r = 0, c = 0;
+            if (pvalid) sm_ring_pixel(pi, H, W, r, c);
+            if (t < KV) {
+                const int src = t / KK, tt = t - src * KK;
+                const int ky = tt / d.ks, kx = tt - ky * d.ks;
+                const int mr = r == 1 ? -1 : (r == H - 2 ? H : -2), mc = c == 1 ? -1 : (c == W - 2 ? W : -2);   // -2: none
+                const int rho = src == 1 ? r : mr, gam = src == 0 ? c : mc;
+                const int sr = rho + ky - d.off, sc = gam + kx - d.off;
+                const bool ok = pvalid && rho != -2 && gam != -2 && sr >= 0 && sr < d.Hin && sc >= 0 && sc < d.Win;
+                srcoff[t][p] = ok ? sr * d.Win + sc : -1;
+            } else {
+                const int pitch = d.y_pitch > 0 ? d.y_pitch : d.Wout;
+                yoff[p] = pvalid ? r * pitch + c : -1;
+                boff[p] = -1;
+            }
+        } else {
         const bool pvalid = pi < Hc * Wc;
         const int iy = pvalid ? pi / Wc : 0, ix = pvalid ? pi - iy * Wc : 0;
         const int oy = iy * pstep + py, ox = ix * pstep + px;
@@ -121,11 +160,12 @@ __global__ __launch_bounds__(64 * NW) void conv_small_kernel(const DipConvDesc d
             }
             boff[p] = bo;
         }
+        }
     }
     __syncthreads();
     // taps no pixel of the tile can see (zero padding; the other parities of a dilated gradient) are skipped
     int ntv = 0;
-    for (int t = 0; t < KK; ++t) {
+    for (int t = 0; t < KV; ++t) {
         if (__ballot(srcoff[t][l31] >= 0) != 0ull) {
             if (lane == 0) taps[w][ntv] = t;
             ++ntv;
@@ -155,8 +195,9 @@ __global__ __launch_bounds__(64 * NW) void conv_small_kernel(const DipConvDesc d
 #pragma unroll
         for (int i = 0; i < SMAX; ++i) {
             const bool on = cs + i < t1;                                 // wave-uniform
-            const int tap = taps[w][on ? lti : 0];
-            const int so = srcoff[tap][l31];
+            const int vtap = taps[w][on ? lti : 0];
+            const int so = srcoff[vtap][l31];
+            const int tap = !RING ? vtap : (vtap >= 2 * KK ? vtap - 2 * KK : (vtap >= KK ? vtap - KK : vtap));   // its filter tap
             const int c = 8 * lj + 4 * half;
             const bool cv = on && c < d.Cin;                             // (the 4-channel tail of a 132-channel input)
             const bool av = cv && so >= 0;
@@ -221,7 +262,7 @@ __global__ __launch_bounds__(64 * NW) void conv_small_kernel(const DipConvDesc d
     {
         const float bias = (d.bias != nullptr && n < d.Cout) ? d.bias[n] : 0.f;
         const bool ncol = n < d.Cy;
-        if (d.accumulate) {
+        if (d.accumulate || RING) {
             float old[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) old[r] = (ncol && yo[r] >= 0) ? d.y[(size_t)yo[r] * d.Cy + n] : 0.f;
@@ -315,6 +356,7 @@ bool small_geom(const DipConvDesc& d, SmallGeom* g) {
     if (d.Cout < 1 || d.Cout > 160 || d.Cy < d.Cout) return false;
     if (d.Hout < 1 || d.Wout < 1) return false;
     g->ncls = d.dil == 2 ? 4 : 1;
+    g->ring = 0;
     g->ngroups = 0;
     for (int c = 0; c < 4; ++c) { g->Hc[c] = g->Wc[c] = 0; g->gstart[c] = 0; }
     if (g->ncls == 1) {
@@ -343,9 +385,9 @@ bool small_geom(const DipConvDesc& d, SmallGeom* g) {
     return true;
 }
 
-template <int TR, int NW>
+template <int TR, int NW, bool RING = false>
 int small_launch(const DipConvDesc& d, const SmallGeom& g, hipStream_t st) {
-    auto kern = conv_small_kernel<TR, NW>;
+    auto kern = conv_small_kernel<TR, NW, RING>;
     constexpr int lds = NW * 16 * 64 * 4;
     static bool attr_set[16] = {};
     int dev = 0;
@@ -368,6 +410,39 @@ int small_launch_nw(const DipConvDesc& d, const SmallGeom& g, hipStream_t st) {
 }
 
 }  // namespace
+
+// Reflection-padded 3x3 stride-1 convs: the data gradient on the padded (H+2) x (W+2) domain costs the LDS-DMA kernel
+// 561 tiles instead of 512 at 256^2 -- a lonely second round, 240 us instead of 160 (+14 for this launch).  The engine computes the INTERIOR
+// H x W positions with the big kernel (a plain zero-padded correlation, off = 1) and this launch adds what the ring of
+// the padded domain folds onto the frame rows 1, H-2 / columns 1, W-2 (adjoint of nn.ReflectionPad2d(1)): `d` is the
+// interior descriptor (x = dy [H][W], y = the gradient [H][W][Cy], ks 3, stride 1, dil 1, off 1, zero padding).
+extern "C" int dip_conv_dgrad_ring_ok(const DipConvDesc* dp) {
+    const DipConvDesc& d = *dp;
+    static const bool off = getenv("DIP_CONV_NO_RING") != nullptr;
+    static const int maxpix = getenv("DIP_DGRAD_RING_MAX") ? atoi(getenv("DIP_DGRAD_RING_MAX")) : 300000;
+    SmallGeom g;
+    if (off || !small_geom(d, &g)) return 0;
+    if (d.ks != 3 || d.stride != 1 || d.dil != 1 || d.off != 1 || d.pad_mode != DIP_PAD_ZERO) return 0;
+    if (d.Hin != d.Hout || d.Win != d.Wout || d.Hout < 4 || d.Wout < 4 || d.tr.a != nullptr || d.bias != nullptr) return 0;
+    return d.Hout * d.Wout <= maxpix ? 1 : 0;
+}
+
+extern "C" int dip_conv_dgrad_ring(const DipConvDesc* dp, void* stream) {
+    const DipConvDesc& d = *dp;
+    SmallGeom g;
+    if (!small_geom(d, &g) || d.ks != 3 || d.stride != 1 || d.dil != 1 || d.off != 1 || d.pad_mode != DIP_PAD_ZERO ||
+        d.Hin != d.Hout || d.Win != d.Wout || d.Hout < 4 || d.Wout < 4 || d.tr.a != nullptr || d.bias != nullptr ||
+        d.stats != nullptr || d.bnb_y != nullptr)
+        DIP_FAIL("conv_dgrad_ring: needs the interior descriptor of a 3x3 stride-1 data gradient (off 1, zero padding)");
+    g.ring = 1;
+    g.ncls = 1;
+    g.Hc[0] = 1; g.Wc[0] = 2 * d.Wout + 2 * (d.Hout - 2);
+    g.gstart[0] = 0;
+    g.ngroups = dip_cdiv(g.Wc[0], 32);
+    g.gstart[1] = g.ngroups;
+    g.nw = 16;
+    return small_launch<0, 16, true>(d, g, reinterpret_cast<hipStream_t>(stream));
+}
 
 // 1 when the engine should run `d` through dip_conv_small: a shape the kernel serves and a small output
 extern "C" int dip_conv_small_eligible(const DipConvDesc* dp) {

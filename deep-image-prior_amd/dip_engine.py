@@ -576,6 +576,14 @@ class SkipEngine:
             small = self.use_small and bool(self.lib.dip_conv_small_eligible(C.byref(d)))
             ops.append((self.lib.dip_conv_small if small else self.lib.dip_conv_igemm, (C.byref(d),), "dgrad+:" + r.name))
             return accumulate_into
+        ring = False
+        if reflect and r.pad_mode == N.PAD_REFLECT and r.ks == 3 and r.stride == 1 and self.use_small:
+            # interior domain + a frame launch instead of the padded domain (dip_conv_dgrad_ring): no lonely second round
+            # of tiles at 256^2 (561 -> 512), and the gradient buffer needs no fold
+            di = N.DipConvDesc(None, Ho, Wo, round_up(r.Cout, 4), round_up(r.Cout, 4), N.DipTransform(None, None, 1.0), None,
+                               None, None, x.H, x.W, Cg, r.Cin, 0, r.ks, 1, N.PAD_ZERO, 1, 1, 0, None, 1, None)
+            if self.lib.dip_conv_dgrad_ring_ok(C.byref(di)) and not self.lib.dip_conv_small_eligible(C.byref(di)):
+                ring, pad, Hg, Wg, off = True, 0, x.H, x.W, 1
         gbuf = self._buf(Hg * Wg * Cg)
         if r.stride == 2:
             ksplit, _, wsf = N.conv_plan_dil2(Hg, Wg, round_up(r.Cout, 4), r.Cin, r.ks)
@@ -610,7 +618,7 @@ class SkipEngine:
             return (gbuf, pad)
         variant = self.lib.dip_conv_variant(C.byref(d))
         fused = None
-        if fuse_bn and self.fuse_bnb and x.bn is not None and self.lib.dip_conv_bnb_fusable(C.byref(d)):
+        if fuse_bn and self.fuse_bnb and not ring and x.bn is not None and self.lib.dip_conv_bnb_fusable(C.byref(d)):
             bn = x.bn
             rows = self.lib.dip_conv_ntiles(Hg, Wg)
             c_lo = (r.Cin - 128) if variant == 3 else 0          # columns of the conv_thin4 launch (always 4 here: % 4)
@@ -641,6 +649,12 @@ class SkipEngine:
             ops.append((self.lib.dip_conv_igemm_dma_cols, (C.byref(d), ncols), "dgrad:" + r.name))
         else:
             ops.append((self.lib.dip_conv_igemm, (C.byref(d),), "dgrad:" + r.name))
+        if ring:
+            # what the reflected ring folds onto the frame rows / columns, accumulated into the interior gradient
+            dr = N.DipConvDesc.from_buffer_copy(d)
+            dr.ksplit, dr.ws = 1, None
+            self.keep.append(dr)
+            ops.append((self.lib.dip_conv_dgrad_ring, (C.byref(dr),), "dgring:" + r.name))
         return (gbuf, pad)
 
     def _gradsrc(self, g, Cg, choff=0, window=None):

@@ -105,6 +105,8 @@ _SIGS = {
     "dip_conv_small": (C.c_int, [C.POINTER(DipConvDesc), C.c_void_p]),
     "dip_conv_small_eligible": (C.c_int, [C.POINTER(DipConvDesc)]),
     "dip_conv_small_rows": (C.c_int, [C.POINTER(DipConvDesc)]),
+    "dip_conv_dgrad_ring": (C.c_int, [C.POINTER(DipConvDesc), C.c_void_p]),
+    "dip_conv_dgrad_ring_ok": (C.c_int, [C.POINTER(DipConvDesc)]),
     "dip_conv_thin4": (C.c_int, [C.POINTER(DipConvDesc), C.c_int, C.c_void_p]),
     "dip_conv_igemm_dma_cols": (C.c_int, [C.POINTER(DipConvDesc), C.c_int, C.c_void_p]),
     "dip_conv_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),

@@ -197,6 +197,16 @@ int dip_conv_igemm_dma_cols(const DipConvDesc* d, int n_base, void* stream);
 int dip_conv_small(const DipConvDesc* d, void* stream);
 int dip_conv_small_eligible(const DipConvDesc* d);
 int dip_conv_small_rows(const DipConvDesc* d);
+/* Data gradient of a reflection-padded 3x3 stride-1 convolution WITHOUT the padded domain (models/common.py:116-121 +
+ * autograd's ReflectionPad2dBackward): the caller computes the interior H x W positions as a plain zero-padded correlation
+ * (dip_conv_igemm with off = 1: 512 tiles at 256^2 instead of the 561 of the (H+2) x (W+2) domain) and this launch adds
+ * what the ring of the padded domain folds onto the frame rows 1, H-2 / columns 1, W-2 -- per frame pixel the gradient of
+ * the <= 3 ring positions that mirror onto it, accumulated into y.  `d` = the interior descriptor (x = dy [H][W],
+ * y = gradient [H][W][Cy], ks 3, stride 1, dil 1, off 1, DIP_PAD_ZERO, no transform / bias / stats).  The gradient buffer
+ * then needs no fold (DipGradSrc.pad = 0).  dip_conv_dgrad_ring_ok: shape served and H * W <= DIP_DGRAD_RING_MAX
+ * (default 300000: up to 512 x 512). */
+int dip_conv_dgrad_ring(const DipConvDesc* d, void* stream);
+int dip_conv_dgrad_ring_ok(const DipConvDesc* d);
 /* second half of a split-K dispatch (d->ksplit > 1): fixed-order sum of the workspace slices, bias,
  * store, BatchNorm partials.  dip_conv_igemm calls it itself; exported for per-kernel timing. */
 int dip_conv_splitk_finish(const DipConvDesc* d, void* stream);

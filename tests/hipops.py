@@ -262,3 +262,24 @@ def conv_small_dgrad(dy, w, stride, pad_mode, Hin, Win, bnb=None, accumulate_int
     N.check(lib.dip_fold_to_nchw(C.byref(src), Hin, Win, Cin, gx.data_ptr(), stream(dev)), "fold")
     torch.cuda.synchronize()
     return gx, out
+
+
+def conv_dgrad_ring(dy, w, Hin, Win):
+    """Data gradient of a reflection-padded 3x3 stride-1 conv as the engine runs it at >= 128 x 128: the interior H x W
+    positions through dip_conv_igemm (zero-padded correlation, off = 1) + dip_conv_dgrad_ring for what the reflected ring
+    folds onto the frame rows / columns.  Returns the gradient [1,Cin,H,W] (no fold pass)."""
+    lib = N.lib()
+    dev = dy.device
+    Cout, Cin, ks, _ = w.shape
+    assert ks == 3
+    packed, _, do = pack(w)
+    dyb = to_nhwc(dy)
+    Cg = round_up(Cin, 4)
+    g = torch.full((Hin * Win * Cg,), float("nan"), dtype=torch.float32, device=dev)
+    d = N.DipConvDesc(dyb.data_ptr(), Hin, Win, round_up(Cout, 4), round_up(Cout, 4), N.DipTransform(None, None, 1.0),
+                      packed.data_ptr() + 4 * do, None, g.data_ptr(), Hin, Win, Cg, Cin, 0, 3, 1, N.PAD_ZERO, 1, 1, 0, None,
+                      1, None)
+    N.check(lib.dip_conv_igemm(C.byref(d), stream(dev)), "conv_igemm(interior dgrad)")
+    N.check(lib.dip_conv_dgrad_ring(C.byref(d), stream(dev)), "conv_dgrad_ring")
+    torch.cuda.synchronize()
+    return from_nhwc(g, Cin, Hin, Win)

@@ -553,7 +553,7 @@ def test_upcat_forward_backward(dev, ns, nd, Hh, Ww, mode):
 def test_layout_head_roundtrip(dev):
     lib = N.lib()
     st = H.stream(dev)
-    for Cc, HW in ((32, 64 * 48), (3, 1000), (1, 77)):
+    for Cc, HW in ((32, 64 * 48), (3, 1000), (1, 77), (40, 500), (30, 257)):
         x = torch.randn(Cc, HW, device=dev)
         Cs = round_up(Cc, 4)
         nh = torch.full((HW * Cs,), float("nan"), device=dev)
