@@ -567,6 +567,8 @@ extern "C" int dip_conv_igemm_dma_cols(const DipConvDesc* dp, int n_base, void* 
 extern "C" int dip_conv_thin4(const DipConvDesc* dp, int ncols, void* stream);
 extern "C" int dip_conv1x1_res_eligible(const DipConvDesc* dp);
 extern "C" int dip_conv1x1_res(const DipConvDesc* dp, void* stream);
+extern "C" int dip_conv_bf3_eligible(const DipConvDesc* dp);
+extern "C" int dip_conv_bf3_cols(const DipConvDesc* dp, int n_base, int ncols, void* stream);
 
 extern "C" int dip_conv_variant(const DipConvDesc* dp) {
     const DipConvDesc& d = *dp;
@@ -581,6 +583,8 @@ extern "C" int dip_conv_variant(const DipConvDesc* dp) {
     if (!no_thin4 && !no_dma && d.ks == 3 && d.stride == 1 && d.dil == 1 && d.Cout > 128 && d.Cout <= 132 &&
         d.stats == nullptr && d.tr.a == nullptr && d.ksplit <= 1 && dip_conv_dma_eligible(dp))
         return 3;
+    // 3x3 stride-1 layers with >= 256 tiles on the bf16 matrix pipe (DIP_CONV_BF3, conv_bf3.hip)
+    if (dip_conv_bf3_eligible(dp)) return 7;
     // otherwise N = 160 in one pass: a fifth 32-column block spread over the four waves
     if (!no_extra && d.ks == 3 && d.stride == 1 && CoutP == 160 && d.stats == nullptr && (d.Cin % 32) == 0) return 2;
     if (!no_dma && dip_conv_dma_eligible(dp)) return d.stride == 2 ? 5 : 1;
@@ -636,6 +640,7 @@ extern "C" int dip_conv_igemm(const DipConvDesc* dp, void* stream) {
         return dip_conv_igemm_dma_cols(dp, ncols, stream);
     }
     if (variant == 6) return dip_conv1x1_res(dp, stream);
+    if (variant == 7) return dip_conv_bf3_cols(dp, 0, dip_round_up(d.Cout, 128), stream);
     if (variant == 1 || variant == 4 || variant == 5) rc = dip_conv_igemm_dma(dp, ksplit, stream);
     else if (d.ks == 1 && d.stride == 1) rc = launch_bn<1, 1, 32>(d, st, ksplit, d.ws);
     else if (d.ks == 3 && d.stride == 1) rc = launch_bn<3, 1, 32>(d, st, ksplit, d.ws);

@@ -741,8 +741,12 @@ extern "C" int dip_debug_prof_read(void* dst, int nwg) {
 
 // one 128-column block starting at column n_base (3x3 only): the 132-column data gradients run as
 // conv_thin4 (columns 0..3) + this (columns 4..131)
+extern "C" int dip_conv_bf3_eligible(const DipConvDesc* dp);
+extern "C" int dip_conv_bf3_cols(const DipConvDesc* dp, int n_base, int ncols, void* stream);
+
 extern "C" int dip_conv_igemm_dma_cols(const DipConvDesc* dp, int n_base, void* stream) {
     if (dp->ks != 3) DIP_FAIL("conv_igemm_dma_cols: 3x3 only");
+    if (dip_conv_bf3_eligible(dp)) return dip_conv_bf3_cols(dp, n_base, 128, stream);      // (DIP_CONV_BF3: bf16 matrix pipe)
     return launch<3, 128>(*dp, reinterpret_cast<hipStream_t>(stream), n_base, 1, 1, nullptr);
 }
 

@@ -136,6 +136,10 @@ class SkipEngine:
         # (the write-through stores, the ticket and the L2-bypassing row loads are three dependent memory round trips at
         # the end of the producer: -1.5 % end to end) -- opt-in
         self.ticket_fin = os.environ.get("DIP_TICKET_FIN") == "1"
+        # bf16 matrix pipe for the big 3x3 layers (csrc/conv_bf3.hip: fp32 operands as three exact bf16 terms, all nine
+        # cross products accumulated in fp32): the library decides per descriptor (DIP_CONV_BF3=9 | 6), the engine only
+        # keeps the split weight planes up to date
+        self.bf3 = False
         self.device = None
         self.shape_key = None
         self.lib = None
@@ -245,6 +249,25 @@ class SkipEngine:
                                    round_up(r.Cout, 32), round_up(r.Cout, 4), round_up(r.Cin, 32))
             max_elems = max(max_elems, r.fwd_elems + r.dgrad_elems)
         self.packed = torch.zeros(off, dtype=torch.float32, device=device)
+        # three-bf16-plane copies of the 3x3 stride-1 weights (bf16-pipe convolution), when the library has it switched on
+        self.bf3 = bool(self.lib.dip_conv_bf3_terms())
+        if self.bf3:
+            off3, max3 = 0, 0
+            recs3 = (N.DipPackRec3 * len(self.convs))()
+            for k, r in enumerate(self.convs):
+                r.fwd3_off = r.dgrad3_off = -1
+                nchF, nchD = (round_up(r.Cin, 4) + 15) // 16, (round_up(r.Cout, 4) + 15) // 16
+                CoutP, CinP = round_up(r.Cout, 32), round_up(r.Cin, 32)
+                if r.ks == 3 and r.stride == 1 and not r.name.endswith(".down_ds"):
+                    r.fwd3_off = off3
+                    off3 += 9 * nchF * 3 * CoutP * 16
+                    r.dgrad3_off = off3
+                    off3 += 9 * nchD * 3 * CinP * 16
+                    max3 = max(max3, 9 * 16 * (nchF * CoutP + nchD * CinP))
+                recs3[k] = N.DipPackRec3(r.w_off, r.fwd3_off, r.dgrad3_off, r.Cout, r.Cin, r.ks, nchF, CoutP, nchD, CinP)
+            self.packed3 = torch.zeros(max(off3, 8), dtype=torch.int16, device=device)
+            self.pack_recs3 = torch.frombuffer(bytearray(bytes(recs3)), dtype=torch.uint8).to(device)
+            self.pack_max3 = max3
         raw = bytes(recs)
         self.pack_recs = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
         self.pack_max = max_elems
@@ -465,6 +488,8 @@ class SkipEngine:
         stats_scratch = self.stats_scratch2 if side else self.stats_scratch
         ws_scratch = self.ws_scratch2 if side else self.ws_scratch
         d.stats = _ptr(stats_scratch) if bn is not None else None
+        if self.bf3 and getattr(r, "fwd3_off", -1) >= 0:
+            d.wp3 = self.packed3.data_ptr() + 2 * r.fwd3_off
         d.ksplit = ksplit
         d.ws = _ptr(ws_scratch) if ksplit > 1 else None
         self.keep.append(d)
@@ -594,6 +619,8 @@ class SkipEngine:
                           N.DipTransform(None, None, 1.0), None if sizing else _ptr(self.packed, r.dgrad_off), None,
                           None if sizing else _ptr(gbuf), Hg, Wg, Cg, r.Cin, 0, r.ks, 1, N.PAD_ZERO, off, r.stride, 0, None,
                           ksplit, (None if sizing else _ptr(self.ws_scratch)) if ksplit > 1 else None)
+        if self.bf3 and not sizing and getattr(r, "dgrad3_off", -1) >= 0:
+            d.wp3 = self.packed3.data_ptr() + 2 * r.dgrad3_off
         small = self.use_small and bool(self.lib.dip_conv_small_eligible(C.byref(d)))
         if small:
             # low resolution: ONE launch for all (<= 160) columns, no split-K workspace; when x feeds this conv only, phase 1
@@ -975,6 +1002,9 @@ class SkipEngine:
             self.fwd_id += 1
             N.check(lib.dip_pack_weights(_ptr(self.params), _ptr(self.packed), self.pack_recs.data_ptr(),
                                          len(self.convs), self.pack_max, stream), "pack_weights")
+            if self.bf3:
+                N.check(lib.dip_pack_weights_bf3(_ptr(self.params), self.packed3.data_ptr(), self.pack_recs3.data_ptr(),
+                                                 len(self.convs), self.pack_max3, stream), "pack_weights_bf3")
             N.check(lib.dip_nchw_to_nhwc(xs.data_ptr(), _ptr(self.x_nhwc), Cimg, H * W, round_up(Cimg, 4), stream),
                     "nchw_to_nhwc")
             ops = self.fwd_ops if head is None else self.fwd_ops[:-1]      # the last op is the output conv

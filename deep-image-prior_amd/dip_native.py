@@ -28,6 +28,12 @@ class DipPackRec(C.Structure):
                 ("CinP4", C.c_int32), ("CoutP32", C.c_int32), ("CoutP4", C.c_int32), ("CinP32", C.c_int32)]
 
 
+class DipPackRec3(C.Structure):
+    _fields_ = [("w_off", C.c_int64), ("fwd_off", C.c_int64), ("dgrad_off", C.c_int64),
+                ("Cout", C.c_int32), ("Cin", C.c_int32), ("KS", C.c_int32),
+                ("nchF", C.c_int32), ("CoutP32", C.c_int32), ("nchD", C.c_int32), ("CinP32", C.c_int32)]
+
+
 class DipBnFin(C.Structure):
     _fields_ = [("gamma", C.c_void_p), ("beta", C.c_void_p), ("eps", C.c_float), ("momentum", C.c_float),
                 ("state", C.c_void_p), ("Cs", C.c_int32), ("C", C.c_int32), ("running_mean", C.c_void_p),
@@ -50,7 +56,8 @@ class DipConvDesc(C.Structure):
                 # fused phase 1 of the BatchNorm backward of the conv's INPUT activation (data-gradient launches)
                 ("bnb_y", C.c_void_p), ("bnb_state", C.c_void_p), ("bnb_partials", C.c_void_p),
                 ("bnb_partials_thin", C.c_void_p), ("bnb_Cy", C.c_int32), ("bnb_Cs", C.c_int32),
-                ("bnb_pad", C.c_int32), ("bnb_slope", C.c_float)]
+                ("bnb_pad", C.c_int32), ("bnb_slope", C.c_float),
+                ("wp3", C.c_void_p)]            # three-bf16-plane weights (bf16-pipe convolution), or None
 
 
 class DipWgradDesc(C.Structure):
@@ -96,6 +103,11 @@ _SIGS = {
     "dip_head_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "dip_head_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "dip_pack_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "dip_pack_weights_bf3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_void_p]),
+    "dip_conv_bf3_eligible": (C.c_int, [C.POINTER(DipConvDesc)]),
+    "dip_conv_bf3_cols": (C.c_int, [C.POINTER(DipConvDesc), C.c_int, C.c_int, C.c_void_p]),
+    "dip_conv_bf3_terms": (C.c_int, []),
+    "dip_conv_bf3_set_terms": (C.c_int, [C.c_int]),
     "dip_conv_igemm": (C.c_int, [C.POINTER(DipConvDesc), C.c_void_p]),
     "dip_conv_ntiles": (C.c_int, [C.c_int, C.c_int]),
     "dip_conv_variant": (C.c_int, [C.POINTER(DipConvDesc)]),

@@ -80,6 +80,18 @@ typedef struct DipPackRec {
 } DipPackRec;
 int dip_pack_weights(const float* params, float* packed, const DipPackRec* recs_dev, int nrec,
                      int max_elems, void* stream);
+/* The same weights as THREE bf16 planes for the bf16-pipe convolution (conv_bf3.hip: w == w1 + w2 + w3 exactly, 8 + 8 + 8
+ * significand bits), [tap][k / 16][plane][n][16 k] bf16:  forward: k = input channel, n = output channel (CoutP32 of them);
+ * data gradient: k = output channel, n = input channel (CinP32), taps flipped.  Offsets in bf16 elements, -1 = skip. */
+typedef struct DipPackRec3 {
+    int64_t w_off;      /* into `params` (floats) */
+    int64_t fwd_off;    /* into `packed3` (bf16 elements), or -1 */
+    int64_t dgrad_off;  /* into `packed3`, or -1 */
+    int32_t Cout, Cin, KS;
+    int32_t nchF, CoutP32, nchD, CinP32;   /* nchF = ceil(CinP4 / 16), nchD = ceil(CoutP4 / 16) */
+} DipPackRec3;
+int dip_pack_weights_bf3(const float* params, void* packed3, const DipPackRec3* recs_dev, int nrec, long long max_elems,
+                         void* stream);
 
 /* ---------------------------------------------------------------- convolution ------------- */
 /* In-launch finalisation of the BatchNorm2d that follows a launch (dip_upcat_fwd_fin; opt-in, DIP_TICKET_FIN=1): the last
@@ -150,6 +162,11 @@ typedef struct DipConvDesc {
     float* bnb_partials_thin;
     int32_t bnb_Cy, bnb_Cs, bnb_pad;
     float bnb_slope;
+    /* Optional: the same weights as three bf16 planes (DipPackRec3).  With DIP_CONV_BF3=9 (or 6) in the environment,
+     * dip_conv_igemm runs the 3x3 stride-1 layers with >= 256 tiles on the bf16 matrix pipe: fp32 operands split exactly
+     * into three bf16 terms, all nine (six) cross products accumulated in fp32 -- fp32-accurate, 0.56 (0.38) of the
+     * fp32-MFMA time (conv_bf3.hip).  NULL: fp32 MFMA. */
+    const void* wp3;
 } DipConvDesc;
 int dip_conv_igemm(const DipConvDesc* d, void* stream);
 /* number of 8x16 output tiles */
@@ -207,6 +224,13 @@ int dip_conv_small_rows(const DipConvDesc* d);
  * (default 300000: up to 512 x 512). */
 int dip_conv_dgrad_ring(const DipConvDesc* d, void* stream);
 int dip_conv_dgrad_ring_ok(const DipConvDesc* d);
+/* bf16-pipe convolution (see DipConvDesc.wp3): eligibility of `d`, the launch of columns [n_base, n_base + ncols) and the
+ * number of cross products in use (0 = off, 9, 6) */
+int dip_conv_bf3_eligible(const DipConvDesc* d);
+int dip_conv_bf3_cols(const DipConvDesc* d, int n_base, int ncols, void* stream);
+int dip_conv_bf3_terms(void);
+/* overrides DIP_CONV_BF3 for this process: 0 (off), 6, 9; -1 = back to the environment */
+int dip_conv_bf3_set_terms(int terms);
 /* second half of a split-K dispatch (d->ksplit > 1): fixed-order sum of the workspace slices, bias,
  * store, BatchNorm partials.  dip_conv_igemm calls it itself; exported for per-kernel timing. */
 int dip_conv_splitk_finish(const DipConvDesc* d, void* stream);

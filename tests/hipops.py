@@ -283,3 +283,71 @@ def conv_dgrad_ring(dy, w, Hin, Win):
     N.check(lib.dip_conv_dgrad_ring(C.byref(d), stream(dev)), "conv_dgrad_ring")
     torch.cuda.synchronize()
     return from_nhwc(g, Cin, Hin, Win)
+
+
+def pack_bf3(w):
+    """OIHW 3x3 weight -> (int16 buffer with the three bf16 planes, fwd_off, dgrad_off in elements) through
+    dip_pack_weights_bf3."""
+    lib = N.lib()
+    Cout, Cin, ks, _ = w.shape
+    nchF, nchD = (round_up(Cin, 4) + 15) // 16, (round_up(Cout, 4) + 15) // 16
+    CoutP, CinP = round_up(Cout, 32), round_up(Cin, 32)
+    nf, nd = ks * ks * nchF * 3 * CoutP * 16, ks * ks * nchD * 3 * CinP * 16
+    buf = torch.full((nf + nd,), 0x7fc0, dtype=torch.int16, device=w.device)          # bf16 NaN
+    rec = (N.DipPackRec3 * 1)()
+    rec[0] = N.DipPackRec3(0, 0, nf, Cout, Cin, ks, nchF, CoutP, nchD, CinP)
+    recs = torch.frombuffer(bytearray(bytes(rec)), dtype=torch.uint8).to(w.device)
+    wc = w.contiguous().float()
+    N.check(lib.dip_pack_weights_bf3(wc.data_ptr(), buf.data_ptr(), recs.data_ptr(), 1, (nf + nd) // 3, stream(w.device)))
+    torch.cuda.synchronize()
+    return buf, 0, nf
+
+
+def conv_bf3(x, w, bias, pad_mode, tr=(None, None, 1.0), terms=9, dgrad_of=None):
+    """3x3 stride-1 convolution (forward with BatchNorm partials, or -- dgrad_of=(Hin, Win) with x = dy -- the data gradient,
+    folded) on the bf16 matrix pipe: dip_conv_igemm with DipConvDesc.wp3 set and dip_conv_bf3_set_terms(terms)."""
+    lib = N.lib()
+    dev = x.device
+    N.check(lib.dip_conv_bf3_set_terms(terms))
+    try:
+        Cout, Cin, ks, _ = w.shape
+        packed, fo, do = pack(w)
+        p3, fo3, do3 = pack_bf3(w)
+        trd, keep = transform(*tr)
+        if dgrad_of is None:
+            _, _, H, W = x.shape
+            xb = to_nhwc(x)
+            Cy, CoutP = round_up(Cout, 4), round_up(Cout, 32)
+            y = torch.full((H * W * Cy,), float("nan"), dtype=torch.float32, device=dev)
+            ntiles = lib.dip_conv_ntiles(H, W)
+            stats = torch.full((ntiles * 3 * CoutP,), float("nan"), dtype=torch.float32, device=dev)
+            bb = bias.contiguous().float() if bias is not None else None
+            d = N.DipConvDesc(xb.data_ptr(), H, W, round_up(Cin, 4), round_up(Cin, 4), trd, packed.data_ptr() + 4 * fo,
+                              bb.data_ptr() if bb is not None else None, y.data_ptr(), H, W, Cy, Cout, 0, 3, 1, pad_mode, 1, 1, 0,
+                              stats.data_ptr(), 1, None)
+            d.wp3 = p3.data_ptr() + 2 * fo3
+            assert lib.dip_conv_variant(C.byref(d)) == 7, "descriptor not taken by the bf16-pipe kernel"
+            N.check(lib.dip_conv_igemm(C.byref(d), stream(dev)), "conv_igemm(bf3)")
+            torch.cuda.synchronize()
+            return from_nhwc(y, Cout, H, W), stats.view(ntiles, 3, CoutP)
+        Hin, Win = dgrad_of
+        reflect = pad_mode in (N.PAD_REFLECT, N.PAD_REPLICATE)
+        pad = 1 if reflect else 0
+        Hg, Wg = Hin + 2 * pad, Win + 2 * pad
+        off = 2 if reflect else 1
+        dyb = to_nhwc(x)
+        Cg = round_up(Cin, 4)
+        g = torch.full((Hg * Wg * Cg,), float("nan"), dtype=torch.float32, device=dev)
+        d = N.DipConvDesc(dyb.data_ptr(), Hin, Win, round_up(Cout, 4), round_up(Cout, 4), N.DipTransform(None, None, 1.0),
+                          packed.data_ptr() + 4 * do, None, g.data_ptr(), Hg, Wg, Cg, Cin, 0, 3, 1, N.PAD_ZERO, off, 1, 0, None,
+                          1, None)
+        d.wp3 = p3.data_ptr() + 2 * do3
+        assert lib.dip_conv_variant(C.byref(d)) in (3, 7)
+        N.check(lib.dip_conv_igemm(C.byref(d), stream(dev)), "conv_igemm(bf3 dgrad)")
+        src = N.DipGradSrc(g.data_ptr(), pad, (2 if pad_mode == N.PAD_REPLICATE else 1) if pad else 0, Cg, 0)
+        gx = torch.empty(1, Cin, Hin, Win, dtype=torch.float32, device=dev)
+        N.check(lib.dip_fold_to_nchw(C.byref(src), Hin, Win, Cin, gx.data_ptr(), stream(dev)), "fold")
+        torch.cuda.synchronize()
+        return gx
+    finally:
+        lib.dip_conv_bf3_set_terms(-1)

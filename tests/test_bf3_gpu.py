@@ -1,0 +1,79 @@
+"""The bf16-matrix-pipe convolution (csrc/conv_bf3.hip: every fp32 operand split exactly into three bf16 terms, all nine
+cross products accumulated in fp32 by v_mfma_f32_32x32x16_bf16) against a torch-CPU fp64 evaluation of nn.ReflectionPad2d +
+nn.Conv2d (models/common.py:114-124 of the reference) and its autograd data gradient -- with the SAME per-op criterion as
+the fp32-MFMA kernels (error vs fp64 <= 2 x the error of torch's own fp32 CPU kernel): the scheme is fp32-accurate, not a
+reduced-precision mode.  Also asserted: its error is no larger than 1.5 x the fp32-MFMA kernel's own on the same inputs."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import dip_native as N  # noqa: E402
+import hipops as H  # noqa: E402
+from test_kernels_gpu import _apply_tr, _check, _mk, _ref_conv, REFLECT, ZERO  # noqa: E402
+
+BF3_CASES = [
+    # Cin, Cout, pad, H, W, transform   (>= 256 tiles of 8 x 16 pixels)
+    (128, 128, REFLECT, 128, 256, True),      # 128 -> 128 encoder / decoder conv
+    (132, 128, REFLECT, 128, 256, True),      # decoder conv on the concat: 8 full 16-channel chunks + a 4-channel one
+    (32, 128, ZERO, 136, 248, False),         # ragged tiles, zero padding, 2 chunks
+    (128, 256, REFLECT, 128, 256, True),      # two 128-column blocks
+    (20, 160, REFLECT, 128, 256, False),      # a partial second column block, partial second chunk
+]
+
+
+@pytest.mark.parametrize("terms", [9, 6])
+@pytest.mark.parametrize("case", BF3_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_bf3_forward_and_stats(dev, case, terms):
+    Cin, Cout, pad, Hh, Ww, use_tr = case
+    full = (Cin, Cout, 3, 1, pad, Hh, Ww, use_tr)
+    x, w, b, a, bb = _mk(full)
+    slope = 0.2
+    ref64 = _ref_conv(_apply_tr(x, a, bb, slope, torch.float64), w, b, 1, pad, torch.float64)
+    ref32 = _ref_conv(_apply_tr(x, a, bb, slope, torch.float32), w, b, 1, pad, torch.float32)
+    tr = (a.to(dev), bb.to(dev), slope) if use_tr else (None, None, 1.0)
+    y, stats = H.conv_bf3(x.to(dev), w.to(dev), b.to(dev), pad, tr, terms=terms)
+    _check(f"conv_bf3[{terms}]", y, ref64, ref32)
+    y32 = H.conv_fwd(x.to(dev), w.to(dev), b.to(dev), 1, pad, tr)                   # the fp32-MFMA kernel, same inputs
+    e3 = (y.cpu().double() - ref64).pow(2).sum().sqrt().item()
+    e32 = (y32.cpu().double() - ref64).pow(2).sum().sqrt().item()
+    assert e3 <= 1.5 * e32, f"bf16-pipe error {e3:.3e} vs fp32-MFMA error {e32:.3e}"
+    st = stats.cpu().double().numpy()
+    n = st[:, 0, :Cout]; m = st[:, 1, :Cout]; M2 = st[:, 2, :Cout]
+    N_ = n.sum(0)
+    mean = (n * m).sum(0) / N_
+    var = (M2.sum(0) + (n * (m - mean) ** 2).sum(0)) / N_
+    r = ref64[0].reshape(Cout, -1)
+    assert np.allclose(N_, r.shape[1])
+    assert np.allclose(mean, r.mean(1).numpy(), rtol=1e-5, atol=1e-5 * float(r.std()))
+    assert np.allclose(var, r.var(1, unbiased=False).numpy(), rtol=2e-5)
+
+
+@pytest.mark.parametrize("terms", [9, 6])
+@pytest.mark.parametrize("case", [BF3_CASES[0], BF3_CASES[1], (256, 128, ZERO, 136, 248, False)], ids=lambda c: "x".join(map(str, c)))
+def test_conv_bf3_dgrad(dev, case, terms):
+    Cin, Cout, pad, Hh, Ww, _ = case
+    x, w, b, _, _ = _mk((Cin, Cout, 3, 1, pad, Hh, Ww, False), 1)
+    res = {}
+    for dt in (torch.float64, torch.float32):
+        xx = x.to(dt).requires_grad_(True)
+        y = _ref_conv(xx, w, None, 1, pad, dt)
+        dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(7))
+        (y * dy.to(dt)).sum().backward()
+        res[dt] = xx.grad
+    gx = H.conv_bf3(dy.to(dev), w.to(dev), None, pad, terms=terms, dgrad_of=(Hh, Ww))
+    _check(f"conv_bf3_dgrad[{terms}]", gx, res[torch.float64], res[torch.float32])
+
+
+def test_split_is_exact(dev):
+    """w == w1 + w2 + w3 bit for bit for the planes dip_pack_weights_bf3 writes (incl. tiny and huge magnitudes)."""
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(32, 16, 3, 3, generator=g) * torch.logspace(-30, 30, 32).view(32, 1, 1, 1)
+    buf, fo, do = H.pack_bf3(w.to(dev))
+    CoutP = 32
+    planes = buf[:9 * 1 * 3 * CoutP * 16].view(9, 1, 3, CoutP, 16).cpu().to(torch.int32) & 0xFFFF
+    as_f32 = (planes << 16).to(torch.int32).view(torch.float32)
+    total = as_f32[:, :, 0].double() + as_f32[:, :, 1].double() + as_f32[:, :, 2].double()      # [tap][1][n][k]
+    ref = w.permute(2, 3, 0, 1).reshape(9, 32, 16).double()                                     # [tap][o][c]
+    assert torch.equal(total[:, 0].float().double(), ref) and torch.equal(total[:, 0], ref)
