@@ -49,6 +49,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP32 (matrix)
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # same guide: BF16 dense (2382 measured); the fp32 products of conv_bf3 / wgrad_bf3 run there
 SELFTEST = os.environ.get("DIP_BENCH_SELFTEST") == "1"   # CPU-only plumbing test of the N-rank path (tests/test_host.py)
 
 CONFIGS = {
@@ -384,12 +385,17 @@ def dominant_ops(eng, fl):
             if name.partition(":")[0] not in ("conv_fwd", "dgrad", "dgrad+"):
                 continue
             d = args[0]._obj
-            if d.ks != 3 or d.Cout < 128 or fn is lib.dip_conv_small:      # (low-resolution layers: conv_small_kernel)
+            if d.ks != 3 or d.Cout < 128 or fn in (lib.dip_conv_small, lib.dip_conv_dgrad_ring):   # (conv_small_kernel)
                 continue
             v = lib.dip_conv_variant(args[0])
-            if v not in (1, 3):
+            if v not in (1, 3, 7):
                 continue
-            cols = d.Cout if v == 1 else 128
+            # with the bf16-pipe kernel switched on, IT is the dominant kernel (the >= 256-tile layers); what is left on
+            # the fp32 LDS-DMA kernel (128 x 128 layers) is reported under roofline_conv3x3_all
+            on_bf3 = bool(lib.dip_conv_bf3_eligible(args[0]))
+            if bool(lib.dip_conv_bf3_terms()) != on_bf3:
+                continue
+            cols = d.Cout if v in (1, 7) else 128
             flops = fl[name] * cols / d.Cout
             # compulsory traffic of the launch: input and packed weights read once, output written once
             nbytes = 4.0 * (d.Hin * d.Win * d.Cin + 9 * d.Cin * cols + d.Hout * d.Wout * cols)
@@ -581,9 +587,20 @@ def roofline(eng, per_op_ms, with_pmc=True):
     all_f = sum(f for k, f in fl.items() if k in per_op_ms)
     all_ms = sum(ms for k, ms in per_op_ms.items() if k in fl)          # (the "#..." parts are not in fl)
     pmc = pmc_traffic() if with_pmc else None     # the PMC passes were taken on the default workload only
-    rl = {"bound": "mfma", "kernel": DOMINANT + " (3x3 stride-1 forward + 3x3 data-gradient launches)",
-          "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-          "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+    import dip_native as N
+    terms = N.lib().dip_conv_bf3_terms()
+    if terms:
+        # fp32 operands split exactly into three bf16 terms; `terms` cross products per fp32 product on the bf16 pipe:
+        # the fp32-equivalent ceiling of that scheme is the bf16 dense peak / terms
+        kname = (f"conv_bf3_kernel<{terms},*> (3x3 stride-1 forward + data-gradient launches with >= 256 tiles: fp32 operands "
+                 f"as three exact bf16 terms, {terms} partial products per fp32 product on v_mfma_f32_32x32x16_bf16, fp32 "
+                 "accumulation)")
+        peak = PEAK_BF16_MFMA_TFLOPS / terms
+    else:
+        kname, peak = DOMINANT + " (3x3 stride-1 forward + 3x3 data-gradient launches)", PEAK_FP32_MFMA_TFLOPS
+    rl = {"bound": "mfma", "kernel": kname,
+          "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+          "frac": round(ach / peak, 4),
           "traffic": pmc["traffic_bytes_per_launch"] if pmc else None,
           "traffic_source": (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes committed under profiles/ ({pmc.get('round', 'r02')}): "
                              "another box, another run than this line") if pmc else None,
@@ -591,9 +608,14 @@ def roofline(eng, per_op_ms, with_pmc=True):
           "algorithmic_gflop_per_launch": round(tot_f / 1e9 / max(n, 1), 2),
           "algorithmic_bytes_per_launch": round(alg_bytes / max(n, 1)),
           "splitk_finish_ms_per_step_not_included": round(fin_ms, 3),
-          "measured_mfma_ceiling_tflops": 151.9,      # tools/ubench/mfma_peak.hip on this chip (2 waves/SIMD)
+          "measured_mfma_ceiling_tflops": 151.9 if not terms else 238.0,   # tools/ubench/mfma_peak.hip / bf16x9.hip (2 WG/CU)
           "all_conv_launches": {"gflop_per_step": round(all_f / 1e9, 1), "ms_per_step_serial": round(all_ms, 3),
                                 "tflops": round(all_f / (all_ms * 1e-3) / 1e12, 2) if all_ms > 0 else None}}
+    if terms:
+        rl["peak_is"] = (f"bf16 dense MFMA peak {PEAK_BF16_MFMA_TFLOPS:.0f} TFLOP/s / {terms} products per fp32 product = fp32-equivalent "
+                         "ceiling of the scheme; `achieved` counts the layer's algorithmic fp32 FLOPs")
+        rl["executed_bf16_tflops"] = round(ach * terms, 1)
+        rl["frac_of_fp32_mfma_peak_157.3"] = round(ach / PEAK_FP32_MFMA_TFLOPS, 4)
     if big and "conv_fwd:s0.up" in fl:
         rl["largest_layer"] = {"name": "s0.up forward", "gflop": round(fl["conv_fwd:s0.up"] / 1e9, 2),
                                "us": round(1e3 * big, 1), "tflops": round(fl["conv_fwd:s0.up"] / (big * 1e-3) / 1e12, 2)}
@@ -830,6 +852,24 @@ def main():
             eager = {"it_s": round(k / te, 3), "ms_per_step": round(1e3 * te / k, 3), "steps": k,
                      "closure": "notebook torch ops (normal_, MSELoss, out-of-place EMA), eager launches"}
             del nb
+        # the same fit with the fp32-MFMA kernels only (DIP_CONV_BF3=0), in a process of its own (the switch is read once)
+        fp32_only = None
+        import dip_native as _N
+        terms = _N.lib().dip_conv_bf3_terms()
+        if world == 1 and terms and not args.no_eager_line and os.environ.get("DIP_BENCH_CHILD") is None:
+            import subprocess
+            env = dict(os.environ, DIP_CONV_BF3="0", DIP_BENCH_CHILD="1")
+            cmd = [sys.executable, os.path.abspath(__file__), "--config", args.config, "--steps", str(max(10, min(args.steps, 50))),
+                   "--warmup", "5", "--mode", "eager", "--no-cpu-baseline", "--no-roofline", "--no-eager-line"]
+            try:
+                r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+                ln = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+                if ln:
+                    o = json.loads(ln[-1])
+                    fp32_only = {"it_s": o["value"], "ms_per_step": o["ms_per_step"], "steps": o["steps"],
+                                 "what": "DIP_CONV_BF3=0: every convolution on v_mfma_f32_32x32x2_f32 (the round-3 arithmetic), eager launches"}
+            except Exception as e:          # the headline does not depend on it
+                fp32_only = {"error": str(e)[:200]}
         cb = None if (args.no_cpu_baseline or world > 1 or args.config != "default") else cpu_baseline()
         its = world * len(fits) * args.steps / tmax
         n_launch = len(eng.fwd_ops) + len(eng.bwd_ops) + 6
@@ -842,10 +882,16 @@ def main():
             "config": {"workload": CONFIGS[args.config]["desc"] + ": reg-noise + forward + MSE + backward + fused Adam, "
                                    f"{n_inst} independent image(s) per GPU; value = all images' iterations / s",
                        "images": world * n_inst, "closure": args.closure, "hipgraph": graphed,
-                       "kernel_launches_per_iteration": n_launch, "final_loss": round(final_loss, 6)},
+                       "kernel_launches_per_iteration": n_launch, "final_loss": round(final_loss, 6),
+                       "arithmetic": ("fp32 tensors, fp32 accumulation everywhere.  3x3 stride-1 layers with >= 256 tiles: each fp32 "
+                                      f"operand split EXACTLY into three bf16 terms, {terms} of the 9 cross products (each exact in "
+                                      "fp32) summed in fp32 on v_mfma_f32_32x32x16_bf16 -- per-op error vs fp64 <= the fp32 MFMA's "
+                                      "(tests/test_bf3_gpu.py); all other layers: v_mfma_f32_32x32x2_f32") if terms else
+                                     "fp32 everywhere (v_mfma_f32_32x32x2_f32)"},
             "per_rank_it_s": [round(v, 3) for v in per_rank],
             "roofline": rl, "roofline_wgrad": rw, "roofline_conv3x3_all": r3, "roofline_hbm": rh,
-            "cpu_baseline": cb, "eager_notebook": eager, "device": device_info(local), "host_affinity_rank0": affinity,
+            "cpu_baseline": cb, "eager_notebook": eager, "fp32_mfma_only": fp32_only, "device": device_info(local),
+            "host_affinity_rank0": affinity,
         }
         line["config"]["reported_mode"] = ("hipGraph replays" if graphed else "eager launches (main + side + bulk HIP stream)") + \
             " of the iteration with the fused closure (RegNoise + MSEHead + in-place EMA)"

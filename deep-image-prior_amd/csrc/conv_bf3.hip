@@ -311,9 +311,10 @@ __global__ __launch_bounds__(256) void pack_weights_bf3_kernel(const float* __re
 int g_bf3_override = -1;             // dip_conv_bf3_set_terms
 
 int bf3_terms() {
+    // default: all nine cross products (exact); DIP_CONV_BF3=0: the fp32-MFMA kernels; =6: the six largest products
     static const int v = [] {
         const char* e = getenv("DIP_CONV_BF3");
-        if (e == nullptr) return 0;
+        if (e == nullptr) return 9;
         const int t = atoi(e);
         return t == 6 ? 6 : (t == 0 ? 0 : 9);
     }();
@@ -343,7 +344,7 @@ int bf3_launch(const DipConvDesc& d, int n_base, int ncols, hipStream_t st) {
 
 }  // namespace
 
-// 1 when dip_conv_igemm runs `d` on the bf16 matrix pipe (DIP_CONV_BF3=9 | 6 and d->wp3 set): 3x3, stride 1, dil 1, one pass,
+// 1 when dip_conv_igemm runs `d` on the bf16 matrix pipe (d->wp3 set; DIP_CONV_BF3=0 switches it off, =6 drops three terms): 3x3, stride 1, dil 1, one pass,
 // >= 256 tiles (the layers that are MFMA-bound), at least one full 128-column block
 extern "C" int dip_conv_bf3_eligible(const DipConvDesc* dp) {
     const DipConvDesc& d = *dp;

@@ -162,10 +162,12 @@ typedef struct DipConvDesc {
     float* bnb_partials_thin;
     int32_t bnb_Cy, bnb_Cs, bnb_pad;
     float bnb_slope;
-    /* Optional: the same weights as three bf16 planes (DipPackRec3).  With DIP_CONV_BF3=9 (or 6) in the environment,
-     * dip_conv_igemm runs the 3x3 stride-1 layers with >= 256 tiles on the bf16 matrix pipe: fp32 operands split exactly
-     * into three bf16 terms, all nine (six) cross products accumulated in fp32 -- fp32-accurate, 0.56 (0.38) of the
-     * fp32-MFMA time (conv_bf3.hip).  NULL: fp32 MFMA. */
+    /* Optional: the same weights as three bf16 planes (DipPackRec3).  When set, dip_conv_igemm runs the 3x3 stride-1 layers
+     * with >= 256 tiles on the bf16 matrix pipe: every fp32 operand split EXACTLY into three bf16 terms (8 + 8 + 8
+     * significand bits), all nine cross products -- each exact in fp32 -- accumulated in fp32 by
+     * v_mfma_f32_32x32x16_bf16: the same roundings as an fp32 fmaf chain (measured error vs fp64 below the fp32 MFMA's),
+     * 0.56 of its matrix-pipe time (conv_bf3.hip).  DIP_CONV_BF3=0: fp32 MFMA everywhere; =6: without the three smallest
+     * products (each < 2^-24 of a*b; 0.38 of the time).  NULL: fp32 MFMA. */
     const void* wp3;
 } DipConvDesc;
 int dip_conv_igemm(const DipConvDesc* d, void* stream);
