@@ -42,7 +42,7 @@ __device__ __forceinline__ int wmap_src(int v, int n_in, int pad_mode) {
 template <int KS, int S, int NT, int CB, bool SLIDE = false>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d, const int ntx, const int ntiles,
                                                             const int CinP, const int CoutP, const int ragged_parts,
-                                                            const int kw) {
+                                                            const int kw, const int phase2_only) {
     using C = WCfg<KS, S, NT, CB>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Us = smem;
@@ -316,10 +316,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d
         }
     }
     };
-    walk(std::false_type{}, walker, nwalk);
+    // phase2_only (dip_conv_wgrad_tail): the full 32-channel chunks were done by another kernel (wgrad_bf3.hip); this
+    // launch only adds the shared-out tail below
+    if (!phase2_only) walk(std::false_type{}, walker, nwalk);
 
     // ---- write this workgroup's partial slab ----
-    if (pack) {
+    if (phase2_only) {
+    } else if (pack) {
       if (wave_active) {
         const int o = o0 + wcol * 32 + l31;
 #pragma unroll
@@ -451,7 +454,31 @@ int launch(const DipWgradDesc& d, hipStream_t st, int CinP_slab = 0) {
     dim3 grid(d.nsplit / kw, ragged_parts > 0 ? ragged_parts : dip_cdiv(CinP, C::CW), C::NGROUPS * dip_cdiv(CoutP, 128));
     // CinP_slab: row count of the slabs when this launch covers only the leading channels of the layer
     hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, st, d, ntx, ntiles, CinP_slab > 0 ? CinP_slab : CinP, CoutP,
-                       ragged_parts, kw);
+                       ragged_parts, kw, 0);
+    DIP_CHECK_LAUNCH();
+    return 0;
+}
+
+// only phase 2 of conv_wgrad_kernel<3, 1, 9, 1, SLIDE>: the (tap, channel)-packed <= 4-channel tail of a 132-channel layer,
+// shared out among `nfull` workgroups per walker (rows CinMain .. CinMain + 31 of every slab)
+int launch_tail(const DipWgradDesc& d, hipStream_t st) {
+    using C = WCfg<3, 1, 9, 1>;
+    static bool attr_set[16] = {};
+    auto kern = conv_wgrad_kernel<3, 1, 9, 1, true>;
+    int dev = 0;
+    hipGetDevice(&dev);
+    if (dev >= 0 && dev < 16 && !attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e != hipSuccess) { dip_set_error(hipGetErrorString(e)); return (int)e; }
+        attr_set[dev] = true;
+    }
+    const int ntx = dip_cdiv(d.Wout, C::TW), nty = dip_cdiv(d.Hout, C::TH);
+    const int CinP = dip_round_up(d.Cin, 32), CoutP = dip_round_up(d.Cout, 32);
+    const int tail = d.Cin & 31, nfull = d.Cin >> 5;
+    if (!(tail >= 1 && tail <= 4 && nfull >= 1 && nfull <= 8)) DIP_FAIL("conv_wgrad_tail: needs 1..8 full 32-channel chunks + a 1..4-channel tail");
+    if (d.nsplit < 1 || d.nsplit > ntx * nty) DIP_FAIL("conv_wgrad_tail: nsplit out of range");
+    hipLaunchKernelGGL(kern, dim3(d.nsplit, nfull, dip_cdiv(CoutP, 128)), dim3(256), C::LDS_BYTES, st, d, ntx, ntx * nty, CinP, CoutP,
+                       nfull, 1, 1);
     DIP_CHECK_LAUNCH();
     return 0;
 }
@@ -826,10 +853,18 @@ extern "C" int dip_wgrad_plan2(int Hout, int Wout, int Cin, int Cout, int ks, in
     return 0;
 }
 
+extern "C" int dip_wgrad_bf3_eligible(const DipWgradDesc* dp);
+extern "C" int dip_wgrad_bf3(const DipWgradDesc* dp, void* stream);
+
+extern "C" int dip_conv_wgrad_tail(const DipWgradDesc* dp, void* stream) {
+    return launch_tail(*dp, reinterpret_cast<hipStream_t>(stream));
+}
+
 extern "C" int dip_conv_wgrad(const DipWgradDesc* dp, void* stream) {
     const DipWgradDesc& d = *dp;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if ((d.Cx & 3) || (d.Cdy & 3)) DIP_FAIL("conv_wgrad: channel strides must be multiples of 4");
+    if (dip_wgrad_bf3_eligible(dp)) return dip_wgrad_bf3(dp, stream);        // big 3x3 stride-1 layers: bf16 matrix pipe
     if (is_thin(d.ks, d.Cin, d.Cout)) {
         int nblk;
         const int ppb = thin_ppb(d.Hout * d.Wout, d.Cin, &nblk);

@@ -1,0 +1,335 @@
+// Weight gradient of the 3x3 stride-1 convolutions on the bf16 matrix pipe (the arithmetic of conv_bf3.hip: every fp32
+// operand split exactly into three bf16 terms, all nine cross products -- each exact in fp32 -- accumulated in fp32).
+//
+//   dW[tap][c][o] = sum_p  u[p + tap][c] * dy[p][o]            (u = transform(x), as in the forward)
+//
+// GEMM per tap: M = 32 input channels per workgroup, N = 128 output channels (32 per wave), K = output pixels.  The
+// contraction runs over PIXELS, so v_mfma_f32_32x32x16_bf16 wants 8 consecutive pixels of one channel per lane: both
+// operands are staged TRANSPOSED in LDS ([plane][channel][pixel] bf16; the fp32 kernel keeps them pixel-major and feeds
+// one pixel per MFMA).  A workgroup walks a strided list of 2 x 16-pixel tiles (two K = 16 steps) and keeps the nine
+// 32 x 32 accumulators of its taps per wave (conv_wgrad.hip's scheme), one partial slab per workgroup, summed in a fixed
+// order by dip_wgrad_reduce.
+//   * staging: a thread loads TWO horizontally adjacent pixels x 4 channels (2 x 16 B), applies the producer's
+//     BatchNorm + LeakyReLU (u only), splits, and writes 4 channels x 3 planes x one dword (the pixel pair) --
+//     the transposition costs 12 ds_write_b32 per pair; the global loads of tile t + 1 are issued under the MFMAs of tile t;
+//   * the three horizontal taps read the SAME 16-byte-aligned window of a halo row (8 pixels + 2): kx = 1 is a 2-byte
+//     funnel shift (v_alignbyte_b32), kx = 2 a register rename -- one ds_read_b128 + one ds_read_b32 per (row, plane)
+//     serve 3 taps; row pitches (208 B per u channel, 80 B per dy channel) put the 16 lanes of a
+//     ds_read_b128 phase on 16 distinct 4-bank groups;
+//   * per K step and wave: 81 MFMAs (9 taps x 9 products), 21 LDS reads; 144 accumulator + ~100 other registers.
+// The <= 4-channel tail of a 132-channel layer stays on the fp32 kernel's (tap, channel)-packed phase 2
+// (dip_conv_wgrad_tail): 2 MFMAs per K step instead of 9 with 28 of 32 rows idle.
+#include "dip_common.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct W3Cfg {
+    static constexpr int TH = 2, TW = 16;                   // output pixels per tile: two K = 16 steps
+    static constexpr int HTH = TH + 2, HTW = TW + 2;        // 4 x 18 halo
+    static constexpr int U_ROW = 48;                        // bytes per halo row of a channel (24 pixels: 16-B aligned rows)
+    static constexpr int U_CH = HTH * U_ROW + 16;           // 208 B per channel (52 dwords: conflict-free b128 phases)
+    static constexpr int U_PLANE = 32 * U_CH;               // 6656
+    static constexpr int D_ROW = 32;                        // bytes per tile row of a channel (16 pixels)
+    static constexpr int D_CH = TH * D_ROW + 16;            // 80 B per channel (20 dwords)
+    static constexpr int D_PLANE = 128 * D_CH;              // 10240
+    static constexpr int U_PAIRS = HTH * 9 * 8;             // (row, pixel pair, 4-channel group) = 288 slots per tile
+    static constexpr int D_PAIRS = TH * 8 * 32;             // 512
+    static constexpr int U_SLOTS = 2, D_SLOTS = 2;          // per thread
+    static constexpr int LDS_BYTES = 3 * U_PLANE + 3 * D_PLANE + 2 * 512 * 4;      // + the transform tables
+};
+
+__device__ __forceinline__ int w3_map_src(int v, int n_in, int pad_mode) {
+    if (pad_mode == DIP_PAD_REFLECT) v = dip_reflect(v, n_in);
+    else if (pad_mode == DIP_PAD_REPLICATE) v = min(max(v, 0), n_in - 1);
+    return (v < 0 || v >= n_in) ? -1 : v;
+}
+
+// a == h + m + l exactly (three bf16 numbers, by truncation); returned in the HIGH halves
+__device__ __forceinline__ void w3_split(float a, unsigned& h, unsigned& m, unsigned& l) {
+    const unsigned uh = __float_as_uint(a) & 0xFFFF0000u;
+    const float r1 = a - __uint_as_float(uh);
+    const unsigned um = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(um);
+    h = uh; m = um; l = __float_as_uint(r2) & 0xFFFF0000u;
+}
+
+template <int NT, int TR>
+__global__ __launch_bounds__(256, 2) void wgrad_bf3_kernel(const DipWgradDesc d, const int ntx, const int ntiles, const int CinP,
+                                                           const int CoutP) {
+    using C = W3Cfg;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Us = smem;                               // [3][32 c][208 B]
+    unsigned char* Ds = smem + 3 * C::U_PLANE;              // [3][128 o][80 B]
+    float* tra = reinterpret_cast<float*>(Ds + 3 * C::D_PLANE);
+    float* trb = tra + 512;
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int walker = blockIdx.x, nwalk = gridDim.x;
+    const int c0 = blockIdx.y * 32;
+    const int o0 = blockIdx.z * 128;
+    const bool wave_active = (o0 + wave * 32) < CoutP;
+    const bool do_bias = d.bias_partial != nullptr && blockIdx.y == 0;
+    const float slope = d.tr.slope;
+
+    if (TR) {
+        for (int c = tid; c < 32; c += 256) {
+            const bool ok = c0 + c < d.Cin;
+            tra[c] = ok ? d.tr.a[c0 + c] : 1.f;
+            trb[c] = ok ? d.tr.b[c0 + c] : 0.f;
+        }
+    }
+    // zero the pad bytes / the pixels 18..23 of the halo rows once (never written by the staging, read by nobody that matters,
+    // but NaN bit patterns must not sit there: 0 * NaN)
+    for (int i = tid; i < (3 * C::U_PLANE + 3 * C::D_PLANE) / 4; i += 256) reinterpret_cast<unsigned*>(smem)[i] = 0u;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float bs[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};          // bias gradient of this thread's dy channels
+
+    // ---- staging slots of this thread ------------------------------------------------------------------------------
+    // u: slot -> (4-channel group cg = s / 36, halo row = (s % 36) / 9, pixel pair pp = s % 9)
+    // dy: slot -> (4-channel group cg = s / 16 (0..31), tile row = (s % 16) / 8, pixel pair pp = s % 8)
+    f32x4 ur[C::U_SLOTS][2], dr[C::D_SLOTS][2];
+    auto fetch = [&](int tile) {
+        const int ty = tile / ntx, tx = tile - ty * ntx;
+#pragma unroll
+        for (int i = 0; i < C::U_SLOTS; ++i) {
+            const int s = tid + i * 256;
+            const int cg = s / 36, rem = s - cg * 36, hr = rem / 9, pp = rem - hr * 9;
+            const int c = c0 + cg * 4;
+            const int sr = w3_map_src(ty * C::TH + hr - d.off, d.Hin, d.pad_mode);
+            const bool okc = s < C::U_PAIRS && c < d.Cin && sr >= 0;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int sc = w3_map_src(tx * C::TW + 2 * pp + q - d.off, d.Win, d.pad_mode);
+                const bool ok = okc && sc >= 0;
+                // unconditional load from a clamped address; commit() zeroes what is padding (same predicate)
+                ur[i][q] = *reinterpret_cast<const f32x4*>(d.x + ((size_t)(ok ? sr : 0) * d.Win + (ok ? sc : 0)) * d.Cx + (ok ? c : 0));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < C::D_SLOTS; ++i) {
+            const int s = tid + i * 256;
+            const int cg = s >> 4, rem = s & 15, r = rem >> 3, pp = rem & 7;
+            const int o = o0 + cg * 4;
+            const int oy = ty * C::TH + r;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int ox = tx * C::TW + 2 * pp + q;
+                const bool ok = oy < d.Hout && ox < d.Wout && o < d.Cdy;
+                dr[i][q] = *reinterpret_cast<const f32x4*>(d.dy + ((size_t)(ok ? oy : 0) * d.Wout + (ok ? ox : 0)) * d.Cdy + (ok ? o : 0));
+            }
+        }
+    };
+    auto commit = [&](int tile) {
+        const int ty = tile / ntx, tx = tile - ty * ntx;
+#pragma unroll
+        for (int i = 0; i < C::U_SLOTS; ++i) {
+            const int s = tid + i * 256;
+            if (s < C::U_PAIRS) {
+                const int cg = s / 36, rem = s - cg * 36, hr = rem / 9, pp = rem - hr * 9;
+                const int c = c0 + cg * 4;
+                const int sr = w3_map_src(ty * C::TH + hr - d.off, d.Hin, d.pad_mode);
+                unsigned h[2][4], m[2][4], l[2][4];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int sc = w3_map_src(tx * C::TW + 2 * pp + q - d.off, d.Win, d.pad_mode);
+                    const bool ok = c < d.Cin && sr >= 0 && sc >= 0;
+                    f32x4 v = ur[i][q];
+                    if (TR) {
+                        const f32x4 a4 = *reinterpret_cast<const f32x4*>(tra + cg * 4), b4 = *reinterpret_cast<const f32x4*>(trb + cg * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float tv = fmaf(a4[e], v[e], b4[e]);
+                            v[e] = TR == 1 ? dip_act_leaky(tv, slope) : dip_act(tv, slope);
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w3_split(ok ? v[e] : 0.f, h[q][e], m[q][e], l[q][e]);
+                }
+                unsigned char* base = Us + (cg * 4) * C::U_CH + hr * C::U_ROW + pp * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    *reinterpret_cast<unsigned*>(base + e * C::U_CH) = (h[0][e] >> 16) | h[1][e];
+                    *reinterpret_cast<unsigned*>(base + e * C::U_CH + C::U_PLANE) = (m[0][e] >> 16) | m[1][e];
+                    *reinterpret_cast<unsigned*>(base + e * C::U_CH + 2 * C::U_PLANE) = (l[0][e] >> 16) | l[1][e];
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < C::D_SLOTS; ++i) {
+            const int s = tid + i * 256;
+            const int cg = s >> 4, rem = s & 15, r = rem >> 3, pp = rem & 7;
+            const int o = o0 + cg * 4;
+            const int oy = ty * C::TH + r;
+            unsigned h[2][4], m[2][4], l[2][4];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int ox = tx * C::TW + 2 * pp + q;
+                const bool ok = oy < d.Hout && ox < d.Wout && o < d.Cdy;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = ok ? dr[i][q][e] : 0.f;
+                    bs[i][e] += v;
+                    w3_split(v, h[q][e], m[q][e], l[q][e]);
+                }
+            }
+            unsigned char* base = Ds + (cg * 4) * C::D_CH + r * C::D_ROW + pp * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                *reinterpret_cast<unsigned*>(base + e * C::D_CH) = (h[0][e] >> 16) | h[1][e];
+                *reinterpret_cast<unsigned*>(base + e * C::D_CH + C::D_PLANE) = (m[0][e] >> 16) | m[1][e];
+                *reinterpret_cast<unsigned*>(base + e * C::D_CH + 2 * C::D_PLANE) = (l[0][e] >> 16) | l[1][e];
+            }
+        }
+    };
+
+    const unsigned char* ua = Us + l31 * C::U_CH + 16 * half;                   // channel l31, pixels 8 * half ..
+    const unsigned char* da = Ds + (wave * 32 + l31) * C::D_CH + 16 * half;     // output channel of this lane
+
+    __syncthreads();                       // tables + zeroed LDS
+    if (walker < ntiles) fetch(walker);
+    for (int tile = walker; tile < ntiles; tile += nwalk) {
+        __syncthreads();                   // every wave is done with the previous tile
+        commit(tile);
+        __syncthreads();
+        if (tile + nwalk < ntiles) fetch(tile + nwalk);          // in flight under this tile's MFMAs
+        if (wave_active) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {               // tile row = one K = 16 step
+                bf16x8 b[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) b[p] = *reinterpret_cast<const bf16x8*>(da + p * C::D_PLANE + s * C::D_ROW);
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    // the 16-byte-aligned window of halo row s + ky: pixels 8 * half .. + 9
+                    const int hr = s + ky;
+                    u32x4 w0[3];
+                    unsigned w1[3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        w0[p] = *reinterpret_cast<const u32x4*>(ua + p * C::U_PLANE + hr * C::U_ROW);
+                        w1[p] = *reinterpret_cast<const unsigned*>(ua + p * C::U_PLANE + hr * C::U_ROW + 16);
+                    }
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        bf16x8 a[3];
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) {
+                            u32x4 v;
+                            if (kx == 0) v = w0[p];
+                            else if (kx == 2) v = u32x4{w0[p][1], w0[p][2], w0[p][3], w1[p]};
+                            else v = u32x4{__builtin_amdgcn_alignbyte(w0[p][1], w0[p][0], 2), __builtin_amdgcn_alignbyte(w0[p][2], w0[p][1], 2),
+                                           __builtin_amdgcn_alignbyte(w0[p][3], w0[p][2], 2), __builtin_amdgcn_alignbyte(w1[p], w0[p][3], 2)};
+                            a[p] = __builtin_bit_cast(bf16x8, v);
+                        }
+                        const int t = ky * 3 + kx;
+#pragma unroll
+                        for (int sm = 4; sm >= 0; --sm) {               // smallest partial products first
+                            if (NT == 6 && sm > 2) continue;
+#pragma unroll
+                            for (int pa = 0; pa < 3; ++pa) {
+                                const int pb = sm - pa;
+                                if (pb < 0 || pb > 2) continue;
+                                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa], b[pb], acc[t], 0, 0, 0);
+                            }
+                        }
+                    }
+                    // one halo row at a time: hoisting the windows of later rows above these MFMAs spills the accumulators
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+
+    // ---- this workgroup's partial slab: rows c0 .. c0 + 31 of slab `walker` ----
+    if (wave_active) {
+        const int o = o0 + wave * 32 + l31;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (c < CinP) d.partial[(((size_t)walker * 9 + t) * CinP + c) * CoutP + o] = acc[t][r];
+            }
+    }
+    if (do_bias) {
+        // thread (cg, pixel-pair lane): sum over the 16 threads that share a channel group, through LDS
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int i = 0; i < C::D_SLOTS; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[(tid + i * 256) * 4 + e] = bs[i][e];
+        __syncthreads();
+        if (tid < 128 && o0 + tid < CoutP) {
+            const int cg = tid >> 2, e = tid & 3;
+            float sum = 0.f;
+            for (int k = 0; k < 16; ++k) sum += red[(cg * 16 + k) * 4 + e];
+            d.bias_partial[(size_t)walker * CoutP + o0 + tid] = sum;
+        }
+    }
+}
+
+template <int NT, int TR>
+int w3_launch(const DipWgradDesc& d, hipStream_t st) {
+    using C = W3Cfg;
+    auto kern = wgrad_bf3_kernel<NT, TR>;
+    static bool attr_set[16] = {};
+    int dev = 0;
+    hipGetDevice(&dev);
+    if (dev >= 0 && dev < 16 && !attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e != hipSuccess) { dip_set_error(hipGetErrorString(e)); return (int)e; }
+        attr_set[dev] = true;
+    }
+    const int ntx = dip_cdiv(d.Wout, C::TW), nty = dip_cdiv(d.Hout, C::TH);
+    const int CinP = dip_round_up(d.Cin, 32), CoutP = dip_round_up(d.Cout, 32);
+    const int nfull = ((d.Cin & 31) >= 1 && (d.Cin & 31) <= 4 && d.Cin > 32) ? (d.Cin >> 5) : dip_cdiv(d.Cin, 32);
+    hipLaunchKernelGGL(kern, dim3(d.nsplit, nfull, dip_cdiv(CoutP, 128)), dim3(256), C::LDS_BYTES, st, d, ntx, ntx * nty, CinP, CoutP);
+    DIP_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int dip_conv_bf3_terms(void);
+extern "C" int dip_conv_wgrad_tail(const DipWgradDesc* dp, void* stream);
+
+// 1 when dip_conv_wgrad runs `d` on the bf16 matrix pipe: 3x3, stride 1, >= 32 input channels, one tap group, one slab per
+// walker, and a layer large enough to be MFMA-bound (>= 2048 tiles of 2 x 16 pixels = 256 x 256)
+extern "C" int dip_wgrad_bf3_eligible(const DipWgradDesc* dp) {
+    const DipWgradDesc& d = *dp;
+    static const bool off = getenv("DIP_WGRAD_NO_BF3") != nullptr;
+    if (off || dip_conv_bf3_terms() == 0) return 0;
+    if (d.ks != 3 || d.stride != 1 || d.Cin < 32 || d.Cout < 97 || d.tap_groups > 1) return 0;
+    if ((d.Cx & 3) || (d.Cdy & 3) || (d.tr.a != nullptr && d.Cin > 512)) return 0;
+    const int tail = d.Cin & 31;
+    if (tail >= 1 && tail <= 4 && (d.Cin >> 5) > 8) return 0;            // (dip_conv_wgrad_tail shares the tail among <= 8 chunks)
+    const int ntiles = dip_cdiv(d.Wout, 16) * dip_cdiv(d.Hout, 2);
+    if (d.nsplit < 1 || d.nsplit > dip_cdiv(d.Wout, 16) * dip_cdiv(d.Hout, 4)) return 0;
+    return ntiles >= 2048 ? 1 : 0;
+}
+
+extern "C" int dip_wgrad_bf3(const DipWgradDesc* dp, void* stream) {
+    const DipWgradDesc& d = *dp;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int nt = dip_conv_bf3_terms();
+    if (nt == 0) DIP_FAIL("wgrad_bf3: the bf16-pipe arithmetic is switched off (DIP_CONV_BF3=0)");
+    const int tr = d.tr.a == nullptr ? 0 : (d.tr.slope > 0.f ? 1 : 2);
+    int rc;
+    if (nt == 6) rc = tr == 0 ? w3_launch<6, 0>(d, st) : (tr == 1 ? w3_launch<6, 1>(d, st) : w3_launch<6, 2>(d, st));
+    else rc = tr == 0 ? w3_launch<9, 0>(d, st) : (tr == 1 ? w3_launch<9, 1>(d, st) : w3_launch<9, 2>(d, st));
+    if (rc) return rc;
+    // the <= 4-channel tail of a 132-channel layer: the fp32 kernel's (tap, channel)-packed phase 2 on its own
+    if ((d.Cin & 31) >= 1 && (d.Cin & 31) <= 4 && d.Cin > 32) return dip_conv_wgrad_tail(dp, stream);
+    return 0;
+}

@@ -126,6 +126,9 @@ _SIGS = {
     "dip_conv_plan_dil2": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
                                      C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "dip_conv_wgrad": (C.c_int, [C.POINTER(DipWgradDesc), C.c_void_p]),
+    "dip_wgrad_bf3_eligible": (C.c_int, [C.POINTER(DipWgradDesc)]),
+    "dip_wgrad_bf3": (C.c_int, [C.POINTER(DipWgradDesc), C.c_void_p]),
+    "dip_conv_wgrad_tail": (C.c_int, [C.POINTER(DipWgradDesc), C.c_void_p]),
     "dip_conv_wgrad_ntiles": (C.c_int, [C.c_int, C.c_int]),
     "dip_wgrad_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "dip_wgrad_plan2": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),

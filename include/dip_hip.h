@@ -257,6 +257,14 @@ typedef struct DipWgradDesc {
     int32_t chan_block;           /* 1x1 MFMA kernel: input channels per workgroup / 32: 4 (default, 0) or 1 */
 } DipWgradDesc;
 int dip_conv_wgrad(const DipWgradDesc* d, void* stream);
+/* dip_conv_wgrad routes the 3x3 stride-1 layers with >= 32 input channels and >= 256 x 256 outputs to the bf16 matrix pipe
+ * (wgrad_bf3.hip: the exact three-way operand split of DipConvDesc.wp3's kernel, here applied to BOTH activations while
+ * they are staged transposed in LDS; same slabs, same dip_wgrad_reduce): eligibility, the launch, and the
+ * (tap, channel)-packed <= 4-channel tail of a 132-channel layer that stays on the fp32 MFMA (phase 2 of the fp32 kernel on
+ * its own).  DIP_WGRAD_NO_BF3=1 / DIP_CONV_BF3=0 switch it off. */
+int dip_wgrad_bf3_eligible(const DipWgradDesc* d);
+int dip_wgrad_bf3(const DipWgradDesc* d, void* stream);
+int dip_conv_wgrad_tail(const DipWgradDesc* d, void* stream);
 /* number of 4x16 output tiles walked by the wgrad workgroups (upper bound for nsplit) */
 int dip_conv_wgrad_ntiles(int Hout, int Wout);
 /* nsplit (number of partial slabs) to run dip_conv_wgrad with; mandatory for 1x1 convs with

@@ -77,3 +77,49 @@ def test_split_is_exact(dev):
     total = as_f32[:, :, 0].double() + as_f32[:, :, 1].double() + as_f32[:, :, 2].double()      # [tap][1][n][k]
     ref = w.permute(2, 3, 0, 1).reshape(9, 32, 16).double()                                     # [tap][o][c]
     assert torch.equal(total[:, 0].float().double(), ref) and torch.equal(total[:, 0], ref)
+
+
+WGRAD_BF3_CASES = [
+    # Cin, Cout, pad, H, W, transform   (>= 2048 tiles of 2 x 16 pixels)
+    (128, 128, REFLECT, 256, 256, True),
+    (132, 128, REFLECT, 256, 256, True),      # four full chunks on the bf16 pipe + the 4-channel tail (dip_conv_wgrad_tail)
+    (48, 160, ZERO, 250, 280, False),         # a 16-channel partial chunk, two 128-column blocks, ragged tiles, zero padding
+]
+
+
+@pytest.mark.parametrize("terms", [9, 6])
+@pytest.mark.parametrize("case", WGRAD_BF3_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_wgrad_bf3(dev, case, terms):
+    """Weight + bias gradient of the big 3x3 layers through dip_conv_wgrad -> wgrad_bf3_kernel (+ dip_wgrad_reduce), against
+    autograd in fp64, with the criterion of the fp32-MFMA kernel (tests/test_kernels_gpu.py::test_conv_wgrad)."""
+    import ctypes as C
+    Cin, Cout, pad, Hh, Ww, use_tr = case
+    full = (Cin, Cout, 3, 1, pad, Hh, Ww, use_tr)
+    x, w, b, a, bb = _mk(full, 2)
+    slope = 0.2
+    res = {}
+    for dt in (torch.float64, torch.float32):
+        ww = w.to(dt).requires_grad_(True)
+        bias = b.to(dt).requires_grad_(True)
+        y = _ref_conv(_apply_tr(x, a, bb, slope, dt), ww, bias, 1, pad, dt)
+        dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(9))
+        (y * dy.to(dt)).sum().backward()
+        res[dt] = (ww.grad, bias.grad)
+    tr = (a.to(dev), bb.to(dev), slope) if use_tr else (None, None, 1.0)
+    lib = N.lib()
+    N.check(lib.dip_conv_bf3_set_terms(terms))
+    try:
+        n, g, cb = N.wgrad_plan2(Hh, Ww, Cin, Cout, 3, 1)
+        d = N.DipWgradDesc(None, Hh, Ww, N.round_up(Cin, 4), Cin, N.DipTransform(None, None, 1.0), None, Hh, Ww, N.round_up(Cout, 4),
+                           Cout, 3, 1, pad, 1, None, None, n, g, cb)
+        assert lib.dip_wgrad_bf3_eligible(C.byref(d)) == 1, "descriptor not taken by the bf16-pipe weight gradient"
+        dw, db = H.conv_wgrad(x.to(dev), dy.to(dev), 3, 1, pad, tr, nsplit="plan")
+        lib.dip_conv_bf3_set_terms(0)
+        dw32, db32 = H.conv_wgrad(x.to(dev), dy.to(dev), 3, 1, pad, tr, nsplit="plan")       # the fp32-MFMA kernel
+    finally:
+        lib.dip_conv_bf3_set_terms(-1)
+    _check(f"wgrad_bf3[{terms}].dw", dw, res[torch.float64][0], res[torch.float32][0], floor=4e-6)
+    _check(f"wgrad_bf3[{terms}].db", db, res[torch.float64][1], res[torch.float32][1], floor=4e-6)
+    e3 = (dw.cpu().double() - res[torch.float64][0]).pow(2).sum().sqrt().item()
+    e32 = (dw32.cpu().double() - res[torch.float64][0]).pow(2).sum().sqrt().item()
+    assert e3 <= 1.5 * e32, f"bf16-pipe error {e3:.3e} vs fp32-MFMA error {e32:.3e}"
