@@ -366,6 +366,31 @@ def profile_ops(eng, reps=3):
     return {k: float(np.mean(v)) for k, v in acc.items()}
 
 
+def count_kernels(eng):
+    """Kernel launches of one iteration: the engine's op lists (an op = one C-ABI call; split-K dispatches are conv + finish,
+    a 132-column data gradient inside dip_conv_igemm is thin4 + 128 columns, a bf16-pipe weight gradient of a 132-channel
+    layer has a packed-tail launch behind it) + noise, counter, weight packing (+ the bf16 planes), layout, loss reduction, Adam
+    tick + step."""
+    import dip_native as N
+    lib = N.lib()
+    n = 0
+    for ops in (eng.fwd_ops, eng.bwd_ops):
+        for fn, args, name in ops:
+            n += 1
+            if fn is lib.dip_conv_igemm:
+                d = args[0]._obj
+                v = lib.dip_conv_variant(args[0])
+                if d.ksplit > 1:
+                    n += 1
+                if v == 3:
+                    n += 1
+            elif fn is lib.dip_conv_wgrad:
+                d = args[0]._obj
+                if lib.dip_wgrad_bf3_eligible(args[0]) and 1 <= (d.Cin & 31) <= 4:
+                    n += 1
+    return n + 7 + (1 if getattr(eng, "bf3", False) else 0)
+
+
 DOMINANT = "conv_igemm_dma_kernel<3,128,*>"
 WGRAD = "conv_wgrad_kernel<3,*,9,1>"
 
@@ -475,7 +500,8 @@ def roofline_hbm(eng, per_op_ms):
     untimed = sum(b for k, b in B.items() if k not in timed and ":" not in k)
     pmc = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as f:
+        pth = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
+        with open(pth if os.path.exists(pth) else os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as f:
             pmc = json.load(f).get("memory_bound_group")
     except (OSError, ValueError):
         pass
@@ -560,11 +586,13 @@ def device_info(dev_index=0):
 def pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
     (profiles/r0N_pmc_traffic.json, produced by tools/pmc_traffic.py); None when absent."""
-    for rnd in ("r03", "r02", "r01"):
+    import dip_native as N
+    want = "conv_bf3_kernel<*>" if N.lib().dip_conv_bf3_terms() else DOMINANT
+    for rnd in ("r04", "r03", "r02", "r01"):
         try:
             with open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")) as f:
                 t = json.load(f)
-            if t.get("kernel") == DOMINANT:
+            if t.get("kernel") == want:
                 t["round"] = rnd
                 return t
         except (OSError, ValueError):
@@ -611,6 +639,17 @@ def roofline(eng, per_op_ms, with_pmc=True):
           "measured_mfma_ceiling_tflops": 151.9 if not terms else 238.0,   # tools/ubench/mfma_peak.hip / bf16x9.hip (2 WG/CU)
           "all_conv_launches": {"gflop_per_step": round(all_f / 1e9, 1), "ms_per_step_serial": round(all_ms, 3),
                                 "tflops": round(all_f / (all_ms * 1e-3) / 1e12, 2) if all_ms > 0 else None}}
+    try:        # matrix-pipe utilisation from the committed counter pass (tools/pmc_mfma.py; another run than this line)
+        with open(os.path.join(ROOT, "profiles", "r04_pmc_mfma.json")) as f:
+            pm = json.load(f)
+        key = "conv_bf3_kernel" if terms else "conv_igemm_dma_kernel<3, 128"
+        us = [(v["launches"], v["utilisation"]) for k, v in pm["kernels"].items() if k.startswith(key)]
+        if us:
+            rl["mfma_util_pmc"] = round(sum(n * u for n, u in us) / sum(n for n, _ in us), 4)
+            rl["mfma_util_pmc_source"] = ("profiles/r04_rocprofv3_pmc_MFMA.txt: SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE, normalised "
+                                          "on the pure-MFMA loops of tools/ubench (calibrated in the same call)")
+    except (OSError, ValueError, KeyError):
+        pass
     if terms:
         rl["peak_is"] = (f"bf16 dense MFMA peak {PEAK_BF16_MFMA_TFLOPS:.0f} TFLOP/s / {terms} products per fp32 product = fp32-equivalent "
                          "ceiling of the scheme; `achieved` counts the layer's algorithmic fp32 FLOPs")
@@ -631,6 +670,18 @@ def roofline(eng, per_op_ms, with_pmc=True):
           "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(w_ach / PEAK_FP32_MFMA_TFLOPS, 4),
           "traffic": None, "launches_per_step": len(wk), "ms_per_step": round(w_ms, 3),
           "reduce_ms_per_step_not_included": round(sum(ms for k, ms in per_op_ms.items() if k.startswith("wgred:")), 3)}
+    # the big layers' weight gradients run wgrad_bf3_kernel (bf16 pipe) when it is switched on: split the set
+    lib3 = N.lib()
+    w3 = {name for fn, args, name in eng.bwd_ops if name in wk and lib3.dip_wgrad_bf3_eligible(args[0])}
+    if w3:
+        f3, ms3 = sum(wk[k] for k in w3), sum(per_op_ms[k] for k in w3)
+        a3 = f3 / (ms3 * 1e-3) / 1e12 if ms3 > 0 else 0.0
+        rw["kernel"] = (f"wgrad_bf3_kernel<{terms},*> on the {len(w3)} layers with >= 256 x 256 outputs (bf16 pipe, incl. the fp32 packed-tail "
+                        f"launch of the 132-channel layers) + {WGRAD} on the other {len(wk) - len(w3)}: `achieved` / `frac` are the whole set "
+                        "against the fp32 MFMA peak")
+        rw["bf16_pipe_launches"] = {"launches_per_step": len(w3), "ms_per_step": round(ms3, 3), "achieved": round(a3, 2),
+                                    "peak": round(PEAK_BF16_MFMA_TFLOPS / terms, 1), "frac": round(a3 / (PEAK_BF16_MFMA_TFLOPS / terms), 4),
+                                    "frac_of_fp32_mfma_peak_157.3": round(a3 / PEAK_FP32_MFMA_TFLOPS, 4)}
     if bigw and "wgrad:s0.up" in fl:
         rw["largest_layer"] = {"name": "s0.up weight gradient", "gflop": round(fl["wgrad:s0.up"] / 1e9, 2),
                                "us": round(1e3 * bigw, 1), "tflops": round(fl["wgrad:s0.up"] / (bigw * 1e-3) / 1e12, 2)}
@@ -872,7 +923,7 @@ def main():
                 fp32_only = {"error": str(e)[:200]}
         cb = None if (args.no_cpu_baseline or world > 1 or args.config != "default") else cpu_baseline()
         its = world * len(fits) * args.steps / tmax
-        n_launch = len(eng.fwd_ops) + len(eng.bwd_ops) + 6
+        n_launch = count_kernels(eng)
         line = {
             "metric": "optimisation iters/sec per image (skip-net 512x512 denoising)" if args.config == "default"
             else f"optimisation iters/sec per image ({args.config} config)",

@@ -224,25 +224,26 @@ extern "C" int dip_conv1x1_res_eligible(const DipConvDesc* dp) {
 extern "C" int dip_conv1x1_res(const DipConvDesc* dp, void* stream) {
     const DipConvDesc& d = *dp;
     if (!dip_conv1x1_res_eligible(dp)) DIP_FAIL("conv1x1_res: descriptor outside the kernel's domain");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[16] = {};
+    if (dip_once_per_device(attr_set)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_res_kernel<true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS_BYTES);
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_res_kernel<false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS_BYTES);
         if (e != hipSuccess) { dip_set_error(hipGetErrorString(e)); return (int)e; }
-        attr_set = true;
     }
     const int nmacro = d.Hout * d.Wout / (2 * R_TP);           // (the domain guarantees whole macro tiles)
     const int CoutP = dip_round_up(d.Cout, 32);
-    static int ncu = 0;
-    if (ncu == 0) {
-        int dev = 0;
+    static int ncus[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    if (ncus[dev] == 0) {
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
-        if (ncu <= 0) ncu = 256;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) ncus[dev] = prop.multiProcessorCount;
+        if (ncus[dev] <= 0) ncus[dev] = 256;
     }
+    const int ncu = ncus[dev];
     const int grid = nmacro < 2 * ncu ? nmacro : 2 * ncu;          // two persistent workgroups per CU
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (d.tr.a != nullptr)

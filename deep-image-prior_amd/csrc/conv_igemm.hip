@@ -423,13 +423,12 @@ int finish_ppb(int npix, int Cy, int* nblk) {
 template <int KS, int S, int CCH, int BN, bool EXTRA = false>
 int launch(const DipConvDesc& d, hipStream_t st, int n_base, int grid_y, int ksplit, float* ws) {
     using C = Cfg<KS, S, CCH, BN, EXTRA>;
-    static bool attr_set = false;
+    static bool attr_set[16] = {};
     auto kern = conv_igemm_kernel<KS, S, CCH, BN, EXTRA>;
-    if (!attr_set) {
+    if (dip_once_per_device(attr_set)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e != hipSuccess) { dip_set_error(hipGetErrorString(e)); return (int)e; }
-        attr_set = true;
     }
     const int ntx = dip_cdiv(d.Wout, C::TW), nty = dip_cdiv(d.Hout, C::TH);
     const int ntiles = ntx * nty;
@@ -507,7 +506,7 @@ extern "C" int dip_conv_plan(int Hout, int Wout, int Cin, int Cout, int ks, int 
     // per-op tolerance is calibrated on).  Only the dense 8x8 / 12x12 Lanczos convs of conv(..., 'lanczos*') at >= 72
     // channels get here (K = 8192 at 128 channels: 4 slices, summed in fixed order by splitk_finish_kernel)
     const int Kred = ks * ks * dip_round_up(Cin, 4);
-    if (Kred > 4608) {
+    if (Kred > 4608 && ks >= 8) {          // (7x7 x >= 96 channels etc. keep their one-pass plans: round-3 advisor finding)
         int kmin = dip_cdiv(Kred, 2304);
         if (kmin > units / 2) kmin = units / 2;
         if (k < kmin) k = kmin;

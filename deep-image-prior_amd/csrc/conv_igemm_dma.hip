@@ -673,13 +673,12 @@ template <int KS, int BN, bool TR, int MODE = 0>
 int launch_tr(const DipConvDesc& d, hipStream_t st, int n_base, int grid_y, int ksplit, float* ws) {
     using C = DCfg<KS, BN, MODE == 2 ? 4 : 1>;
     constexpr bool PH = (MODE == 1);
-    static bool attr_set = false;
+    static bool attr_set[16] = {};
     auto kern = conv_igemm_dma_kernel<KS, BN, TR, MODE>;
-    if (!attr_set) {
+    if (dip_once_per_device(attr_set)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e != hipSuccess) { dip_set_error(hipGetErrorString(e)); return (int)e; }
-        attr_set = true;
     }
     // phase mode tiles the (Hout+1)/2 x (Wout+1)/2 sub-grid of one parity, 4 workgroups per tile
     const int ntx = dip_cdiv(PH ? (d.Wout + 1) / 2 : d.Wout, C::TW), nty = dip_cdiv(PH ? (d.Hout + 1) / 2 : d.Hout, C::TH);

@@ -425,13 +425,12 @@ int wgrad_kw(int CoutP) {
 template <int KS, int S, int NT, int CB, bool SLIDE = false>
 int launch(const DipWgradDesc& d, hipStream_t st, int CinP_slab = 0) {
     using C = WCfg<KS, S, NT, CB>;
-    static bool attr_set = false;
+    static bool attr_set[16] = {};
     auto kern = conv_wgrad_kernel<KS, S, NT, CB, SLIDE>;
-    if (!attr_set) {
+    if (dip_once_per_device(attr_set)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e != hipSuccess) { dip_set_error(hipGetErrorString(e)); return (int)e; }
-        attr_set = true;
     }
     const int ntx = dip_cdiv(d.Wout, C::TW), nty = dip_cdiv(d.Hout, C::TH);
     const int ntiles = ntx * nty;

@@ -29,6 +29,15 @@ extern "C" void dip_set_error(const char* msg);
     } while (0)
 
 static inline int dip_round_up(int x, int m) { return (x + m - 1) / m * m; }
+// "has this one-time per-device set-up (hipFuncSetAttribute, ...) been done on the CURRENT device?": the flag array is
+// owned by the caller (one per kernel instantiation); a process that drives several GPUs sets every one of them up
+static inline bool dip_once_per_device(bool (&done)[16]) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return true;      // (unknown device: redo the set-up)
+    const bool first = !done[dev];
+    done[dev] = true;
+    return first;
+}
 static inline int dip_cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // Activation behind a BatchNorm, encoded in DipTransform.slope (models/common.py:76-92 of the reference):

@@ -472,8 +472,10 @@ class SkipEngine:
             ksplit, ntiles, wsf = N.conv_plan(Ho, Wo, round_up(x.C, 4), r.Cout, r.ks, r.stride)
         # the skip-branch convs run on the side stream next to the encoder convs of their scale
         # (_run_two_streams), so they get scratch of their own
-        side = r.name.endswith("skip_conv")
-        if side and Ho * Wo >= self.side_min_pixels and bn is not None:
+        # (a skip conv below DIP_SIDE_MIN_PIXELS stays on the main stream AND on the main stream's scratch: the side
+        # stream may still be running the previous scale's skip conv out of scratch set 2 -- round-3 advisor finding)
+        side = r.name.endswith("skip_conv") and Ho * Wo >= self.side_min_pixels and bn is not None
+        if side:
             self._fwd_side.update(("conv_fwd:" + r.name, "bn_fin:" + bn.name))
         if sizing:
             if side:

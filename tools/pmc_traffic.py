@@ -57,14 +57,18 @@ def group_bytes(fetch, write, ff, wf):
 
 
 def main():
+    global DOM
     fetch, write = load(sys.argv[1]), load(sys.argv[2])
+    bf3 = any("conv_bf3_kernel" in k for k, _ in fetch.values())
+    if bf3:                      # round 4: the dominant kernel is the bf16-pipe convolution
+        DOM = "conv_bf3_kernel<"
     T = 512 * 512 * 128 * 4
     ff, fr = calib(fetch, 2 * T)
     wf, wr = calib(write, T)
     fv = [v * 1024 * ff for k, v in fetch.values() if DOM in k]
     wv = [v * 1024 * wf for k, v in write.values() if DOM in k]
     out = {
-        "kernel": "conv_igemm_dma_kernel<3,128,*>",
+        "kernel": "conv_bf3_kernel<*>" if bf3 else "conv_igemm_dma_kernel<3,128,*>",
         "n_launches_fetch_pass": len(fv), "n_launches_write_pass": len(wv),
         "fetch_bytes_per_launch": round(sum(fv) / len(fv)), "write_bytes_per_launch": round(sum(wv) / len(wv)),
         "traffic_bytes_per_launch": round(sum(fv) / len(fv) + sum(wv) / len(wv)),
