@@ -643,11 +643,21 @@ def roofline(eng, per_op_ms, with_pmc=True):
         with open(os.path.join(ROOT, "profiles", "r04_pmc_mfma.json")) as f:
             pm = json.load(f)
         key = "conv_bf3_kernel" if terms else "conv_igemm_dma_kernel<3, 128"
-        us = [(v["launches"], v["utilisation"]) for k, v in pm["kernels"].items() if k.startswith(key)]
+        us = [(v["launches"], v["utilisation"], v.get("clock_ghz", 2.4)) for k, v in pm["kernels"].items() if k.startswith(key)]
         if us:
-            rl["mfma_util_pmc"] = round(sum(n * u for n, u in us) / sum(n for n, _ in us), 4)
-            rl["mfma_util_pmc_source"] = ("profiles/r04_rocprofv3_pmc_MFMA.txt: SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE, normalised "
-                                          "on the pure-MFMA loops of tools/ubench (calibrated in the same call)")
+            nl = sum(n for n, _, _ in us)
+            util, ghz = sum(n * u for n, u, _ in us) / nl, sum(n * g for n, _, g in us) / nl
+            rl["mfma_util_pmc"] = round(util, 4)
+            rl["clock_ghz_pmc"] = round(ghz, 3)
+            # frac prices the kernel against the peak at the nominal 2.4 GHz; the counters count CYCLES: the two meet at
+            # utilisation x (clock the kernel ran at) / 2.4 (every executed MFMA of these launches is algorithmic work)
+            rl["frac_from_pmc"] = round(util * ghz / 2.4, 4)
+            rl["mfma_util_pmc_source"] = ("profiles/r04_rocprofv3_pmc_MFMA.txt (another run than this line): utilisation = "
+                                          "SQ_VALU_MFMA_BUSY_CYCLES / (128 x GRBM_GUI_ACTIVE), clock = GRBM_GUI_ACTIVE / (8 x duration), "
+                                          "units calibrated on the pure-MFMA loops of tools/ubench in the same call; frac_from_pmc = "
+                                          "utilisation x clock / 2.4 GHz is the counter-derived value of `frac` -- the matrix pipes of "
+                                          "this kernel are busy 62 % of the cycles, and the cycles come at ~1.96 GHz (power management "
+                                          "under bf16 MFMA load; the bare bf16 MFMA loop runs at 2.06 GHz)")
     except (OSError, ValueError, KeyError):
         pass
     if terms:

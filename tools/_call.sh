@@ -1,15 +1,12 @@
 set -u
-ROOTD="${GRAFT_REPO_ROOT:-/root/repo}"
-cd "$ROOTD"
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out; export TMPDIR=/tmp
-T=r4c14
-timeout 900 python -m pytest tests/test_fullsize_gpu.py -q -m gpu --no-header -p no:cacheprovider 2>&1 | tail -2
-timeout 900 python -m pytest tests/test_net_gpu.py -q -m gpu -k "not end_quality" --no-header -p no:cacheprovider 2>&1 | tail -2
-: > gpurun_out/${T}_ab.log
-for rep in 1 2; do
-for v in base DIP_WGRAD_NO_BF3=1 DIP_CONV_BF3=0 DIP_CONV_BF3=6; do
-  if [ "$v" = base ]; then envs=""; else envs="${v//,/ }"; fi
-  line=$(env $envs timeout 300 python bench.py --steps 100 --warmup 20 --mode eager --no-cpu-baseline --no-roofline --no-eager-line 2>gpurun_out/${T}_bench_err.log | grep '^{"metric"' | tail -1)
-  echo "$v rep$rep $(echo "$line" | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"], d["config"]["kernel_launches_per_iteration"], d["config"]["final_loss"])' 2>/dev/null)" | tee -a gpurun_out/${T}_ab.log
-done
-done
+ROOTD=$(pwd); O=$ROOTD/gpurun_out; T=r04
+P="--steps 3 --warmup 2 --mode eager --no-cpu-baseline --no-roofline --no-eager-line"
+PRE="env LD_PRELOAD=$ROOTD/deep-image-prior_amd/lib/libdip_hip.so DIP_TWO_STREAMS=0"
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/pmc_cal/a -o pmc -- $ROOTD/tools/ubench/bin/mfma_peak > /dev/null 2>&1 )
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/pmc_cal/b -o pmc -- $ROOTD/tools/ubench/bin/bf16x9 > /dev/null 2>&1 )
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/pmc_MFMA -o pmc -- $PRE python $ROOTD/bench.py $P > /dev/null 2>&1 )
+python tools/pmc_mfma.py $O/pmc_cal $O/pmc_MFMA $O/${T}_pmc_mfma.json > $O/${T}_rocprofv3_pmc_MFMA.txt
+rm -rf $O/pmc_cal $O/pmc_MFMA
+head -24 $O/${T}_rocprofv3_pmc_MFMA.txt
