@@ -543,6 +543,72 @@ def conv3x3_all(eng, per_op_ms, fl):
             "ms_per_step_serial": round(ms, 3), "launches_per_step": n, "traffic": None}
 
 
+class PowerSampler:
+    """Side thread: the GPU's hwmon power1_average / power1_input (PPT) and freq1_input (sclk) at ~20 Hz from before the
+    warm-up to the end of the timed region -- the pool has two speed classes of boxes that differ in what they draw / clock
+    under the same code.  summary(t0, t1): mean / max over the timed window, plus the raw trace (ms relative to t0)."""
+
+    def __init__(self, dev_index=0, period=0.05):
+        import glob
+        import threading
+        self.paths = []
+        cards = sorted(glob.glob("/sys/class/drm/card*/device"), key=lambda c: int("".join(ch for ch in c.split("/")[-2] if ch.isdigit()) or 0))
+        cards = [c for c in cards if os.path.exists(c + "/pp_dpm_sclk") and glob.glob(c + "/hwmon/hwmon*/power1_*")]
+        if dev_index < len(cards):
+            for hw in glob.glob(cards[dev_index] + "/hwmon/hwmon*"):
+                pw = next((hw + "/" + f for f in ("power1_average", "power1_input") if os.path.exists(hw + "/" + f)), None)
+                fq = hw + "/freq1_input" if os.path.exists(hw + "/freq1_input") else None
+                if pw:
+                    self.paths.append((pw, fq))
+        self.period, self.samples = period, []
+        self._stop = threading.Event()
+        self._th = threading.Thread(target=self._run, daemon=True)
+
+    def _read(self):
+        for pw, fq in self.paths[:1]:
+            try:
+                t = time.perf_counter()
+                with open(pw) as f:
+                    w = int(f.read()) / 1e6
+                mhz = None
+                if fq:
+                    with open(fq) as f:
+                        mhz = int(f.read()) / 1e6
+                self.samples.append((t, w, mhz))
+            except (OSError, ValueError):
+                pass
+
+    def _run(self):
+        while not self._stop.is_set():
+            self._read()
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        if self.paths:
+            self._th.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        if self.paths:
+            self._th.join(timeout=1.0)
+            self._read()
+
+    def summary(self, t0, t1):
+        if not self.samples:
+            return None
+        win = [x for x in self.samples if t0 <= x[0] <= t1] or self.samples[-1:]
+        out = {"sensor": os.path.basename(self.paths[0][0]) + " (PPT)", "samples_in_timed_region": len(win),
+               "power_w_mean": round(float(np.mean([x[1] for x in win])), 1), "power_w_max": round(float(np.max([x[1] for x in win])), 1),
+               "power_w_max_since_warmup": round(float(np.max([x[1] for x in self.samples])), 1)}
+        mh = [x[2] for x in win if x[2] is not None]
+        if mh:
+            out["sclk_mhz_mean"], out["sclk_mhz_min"] = round(float(np.mean(mh))), round(float(np.min(mh)))
+        k = max(1, len(self.samples) // 40)
+        out["trace_ms_w_mhz"] = [[round(1e3 * (x[0] - t0)), round(x[1]), None if x[2] is None else round(x[2])] for x in self.samples[::k]]
+        return out
+
+
 def device_info(dev_index=0):
     """Clocks / power cap / partition mode of the GPU this line was measured on (the pool has two speed classes of
     boxes): sysfs + rocm-smi, best effort."""
@@ -717,7 +783,7 @@ def cpu_baseline(seed=0, timed=5):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import dip_oracle as O
     # torch-CPU conv scaling collapses on many-core hosts: on the 256-thread MI355X host a sweep
-    # (tests/cpu_sweep.py, 256x256) gave 3.47 / 2.38 / 1.25 / 0.59 / 0.011 it/s at 16 / 32 / 64 /
+    # (tools/cpu_sweep.py, 256x256) gave 3.47 / 2.38 / 1.25 / 0.59 / 0.011 it/s at 16 / 32 / 64 /
     # 128 / 256 threads, so the baseline uses the best setting, 16 threads, not all of them.
     cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
@@ -763,33 +829,35 @@ def timed_run(fits, steps, warmup, use_graph, barrier):
     from dip_optim import GraphedIteration
     note = None
     graph = None
-    if use_graph:
-        try:
-            graph = GraphedIteration.group([(f.opt, f.closure) for f in fits], warmup=min(3, max(warmup, 1)))
-            rest = warmup - graph.iterations
-            if rest > 0:
-                graph.run(rest)
-        except Exception as e:                               # report, then time the eager loop instead
-            note = f"graph capture failed: {type(e).__name__}: {e}"
-            graph = None
-            torch.cuda.synchronize()
-    if graph is None:
-        for _ in range(warmup):
-            for f in fits:
-                f.step()
-    torch.cuda.synchronize()
+    with PowerSampler(torch.cuda.current_device()) as ps:
+        if use_graph:
+            try:
+                graph = GraphedIteration.group([(f.opt, f.closure) for f in fits], warmup=min(3, max(warmup, 1)))
+                rest = warmup - graph.iterations
+                if rest > 0:
+                    graph.run(rest)
+            except Exception as e:                               # report, then time the eager loop instead
+                note = f"graph capture failed: {type(e).__name__}: {e}"
+                graph = None
+                torch.cuda.synchronize()
+        if graph is None:
+            for _ in range(warmup):
+                for f in fits:
+                    f.step()
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        if graph is not None:
+            graph.run(steps)
+        else:
+            for _ in range(steps):
+                for f in fits:
+                    f.step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        t = t1 - t0
     barrier()
-    t0 = time.perf_counter()
-    if graph is not None:
-        graph.run(steps)
-    else:
-        for _ in range(steps):
-            for f in fits:
-                f.step()
-    torch.cuda.synchronize()
-    t = time.perf_counter() - t0
-    barrier()
-    return t, graph is not None, note
+    return t, graph is not None, note, ps.summary(t0, t1)
 
 
 def selftest_rank(args, rank, world, barrier):
@@ -885,13 +953,17 @@ def main():
         per_op = profile_ops(fits[0].engine)
     runs = []
     for use_graph in modes:
-        t, graphed, note = timed_run(fits, args.steps, args.warmup, use_graph, barrier)
-        runs.append({"t": reduce_max_time(t), "mine": len(fits) * args.steps / t, "graphed": graphed, "note": note})
+        t, graphed, note, power = timed_run(fits, args.steps, args.warmup, use_graph, barrier)
+        runs.append({"t": reduce_max_time(t), "mine": len(fits) * args.steps / t, "graphed": graphed, "note": note,
+                     "power": power})
     runs.sort(key=lambda r: r["t"])
     best = runs[0]
     tmax, graphed, note = best["t"], best["graphed"], best["note"]
     per_rank = gather_floats(best["mine"])
     final_loss = float(fits[0].loss.item())
+    # every rank's first fit: rank r's image index is r * instances, i.e. "rank r == the solo fit with that seed" can be
+    # checked bitwise across runs
+    per_rank_loss = gather_floats(final_loss)
 
     if rank == 0:
         eng = fits[0].engine
@@ -909,7 +981,7 @@ def main():
             # the notebook's own torch closure, eager launches (what an unmodified notebook cell runs)
             nb = Fit(args.config, 0, dev, "notebook")
             k = max(10, min(args.steps, 30))
-            te, _, _ = timed_run([nb], k, 3, False, lambda: None)
+            te, _, _, _ = timed_run([nb], k, 3, False, lambda: None)
             eager = {"it_s": round(k / te, 3), "ms_per_step": round(1e3 * te / k, 3), "steps": k,
                      "closure": "notebook torch ops (normal_, MSELoss, out-of-place EMA), eager launches"}
             del nb
@@ -950,6 +1022,8 @@ def main():
                                       "(tests/test_bf3_gpu.py); all other layers: v_mfma_f32_32x32x2_f32") if terms else
                                      "fp32 everywhere (v_mfma_f32_32x32x2_f32)"},
             "per_rank_it_s": [round(v, 3) for v in per_rank],
+            "per_rank_final_loss": [round(v, 6) for v in per_rank_loss],
+            "timed_region_power": best.get("power"),
             "roofline": rl, "roofline_wgrad": rw, "roofline_conv3x3_all": r3, "roofline_hbm": rh,
             "cpu_baseline": cb, "eager_notebook": eager, "fp32_mfma_only": fp32_only, "device": device_info(local),
             "host_affinity_rank0": affinity,

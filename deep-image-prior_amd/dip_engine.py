@@ -853,7 +853,7 @@ class SkipEngine:
         if self._entered_defer_scale:
             ops += self._flush_deferred_wgrads()          # ... and its encoder ones
         s.dbg = {"dy_last": dy_last, "dy_u": dy_u, "dcat": dcat, "dy_s": dy_s, "dy_deep": dy_deep, "dy_d2": dy_d2,
-                 "dy_d1": dy_d1}      # gradient buffers by role (tests/debug_grads.py)
+                 "dy_d1": dy_d1}      # gradient buffers by role (tools/debug_grads.py)
         return ops
 
     # ------------------------------------------------------------------ run

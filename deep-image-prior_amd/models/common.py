@@ -73,8 +73,9 @@ class Swish(nn.Module):
 
 def act(act_fun='LeakyReLU'):
     """Activation factory: 'LeakyReLU' (slope 0.2, in place) | 'Swish' | 'ELU' | 'none', or a
-    module class to instantiate.  Only LeakyReLU has a gfx950 kernel; the others build but the
-    HIP engine refuses them."""
+    module class to instantiate (reference: models/common.py:76-92).  All four strings run on the
+    gfx950 engine (DipTransform.slope encodes them, csrc/dip_common.h: dip_act / dip_act_grad);
+    a module CLASS builds, but HipSkipNet raises for it -- it has no kernel."""
     if not isinstance(act_fun, str):
         return act_fun()
     table = {

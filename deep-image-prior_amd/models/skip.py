@@ -94,7 +94,7 @@ def skip(
         act_fun: 'LeakyReLU|Swish|ELU|none' or a module class
         pad: 'zero|reflection'
         upsample_mode: 'nearest|bilinear' (or a per-scale list)
-        downsample_mode: 'stride|avg|max|lanczos2' (or a per-scale list)
+        downsample_mode: 'stride|avg|max|lanczos2|lanczos3' (or a per-scale list)
     """
     assert len(num_channels_down) == len(num_channels_up) == len(num_channels_skip)
     n = len(num_channels_down)

@@ -1,6 +1,10 @@
 """CPU arms of the BASELINE.json configs[1] end-quality check, produced by the REAL reference.
 
-    python oracle/make_end_quality_golden.py <size> <iters> <threads>[:<perturb>[:<grad_noise>]] [...]
+    python oracle/make_end_quality_golden.py [--task sr|inpaint] <size> <iters> <threads>[:<perturb>[:<grad_noise>]] [...]
+
+--task sr / inpaint (BASELINE.json configs[2] / [3]): the super-resolution closure (super-resolution.ipynb:169-199: the
+loss goes through the reference's Downsampler, PSNR on the full-resolution output) and the masked closure
+(inpainting.ipynb:295-313, the 'kate' net) instead of the denoising one; file tests/golden/end_quality_<task>_<size>_<iters>.json.
 
 For every arm -- a thread count (= another summation order inside ATen's reductions, nothing else) and an
 optional one-ulp perturbation of ONE weight (tests/end_quality_cpu.perturb_one_weight) and an optional relative
@@ -30,6 +34,10 @@ import _refload  # noqa: E402
 
 
 def main():
+    task = "denoise"
+    if sys.argv[1] == "--task":
+        task = sys.argv[2]
+        del sys.argv[1:3]
     size, iters = int(sys.argv[1]), int(sys.argv[2])
     specs = []
     for t in sys.argv[3:] or [str(os.cpu_count())]:
@@ -39,25 +47,27 @@ def main():
     RM = _refload.load_ref_models()
     RU = _refload.load_ref_common_utils()
     import end_quality_cpu as E     # problem(), run_fit(): shared with the GPU arm
-    path = os.path.join(ROOT, "tests", "golden", f"end_quality_{size}_{iters}.json")
+    assert task in E.TASKS, task
+    path = os.path.join(ROOT, "tests", "golden", f"end_quality_{size}_{iters}.json" if task == "denoise" else
+                        f"end_quality_{task}_{size}_{iters}.json")
     arms = json.load(open(path))["cpu_arms"] if os.path.exists(path) else []
     for th, perturb, gnoise in specs:
         torch.set_num_threads(th)
         E.GRAD_NOISE = gnoise
-        torch.manual_seed(0)
-        net = RM.get_net(32, 'skip', 'reflection', skip_n33d=128, skip_n33u=128, skip_n11=4, num_scales=5,
-                         upsample_mode='bilinear')
+        net, z = E.build(size, task, skip_fn=RM.skip, get_net_fn=RM.get_net, get_noise_fn=RU.get_noise)
         E.perturb_one_weight(net.parameters(), perturb)
-        z = RU.get_noise(32, 'noise', (size, size))
-        clean, noisy = E.problem(size)
+        clean, noisy = E.problem(size, task)
+        down = None
+        if task == "sr":
+            down = RM.downsampler.Downsampler(n_planes=3, factor=E.SR_FACTOR, kernel_type='lanczos2', phase=0.5, preserve_size=True)
         res = E.run_fit(net, lambda c: RU.optimize('adam', RU.get_params('net', net, z), c, 0.01, iters),
-                        z, noisy, clean, iters, "cpu", params=list(net.parameters()))
+                        z, noisy, clean, iters, "cpu", params=list(net.parameters()), task=task, down=down)
         res["threads"], res["perturb"], res["grad_noise"] = th, perturb, gnoise
         print(json.dumps(res), flush=True)
         arms = json.load(open(path))["cpu_arms"] if os.path.exists(path) else arms     # (another generator may run)
         arms = [a for a in arms if (a["threads"], a.get("perturb", 0), a.get("grad_noise", 0.0)) != (th, perturb, gnoise)] + [res]
         with open(path, "w") as f:
-            json.dump({"size": size, "iters": iters, "sigma": E.SIGMA, "reg_noise_std": E.REG, "lr": 0.01,
+            json.dump({"task": task, "size": size, "iters": iters, "sigma": E.SIGMA, "reg_noise_std": E.REG_OF[task], "lr": 0.01,
                        "source": "real reference (/root/reference) on torch CPU fp32, oracle/make_end_quality_golden.py",
                        "cpu_arms": sorted(arms, key=lambda a: (a.get("grad_noise", 0.0), a.get("perturb", 0), a["threads"]))},
                       f, indent=1)

@@ -20,7 +20,7 @@ def pytest_configure(config):
 @pytest.fixture(autouse=True, scope="session")
 def _cpu_threads():
     """The oracle runs on the host: torch's CPU conv scaling collapses on many-core boxes (256
-    threads on the MI355X host: 60x slower than 16, tests/cpu_sweep.py), so cap it."""
+    threads on the MI355X host: 60x slower than 16, tools/cpu_sweep.py), so cap it."""
     import torch
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     yield

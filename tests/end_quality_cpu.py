@@ -32,47 +32,99 @@ REG = 1. / 30.
 TAIL = 20
 
 
-def problem(size=None):
-    """Clean image: smooth colour gradients + one step edge; noisy = clip(clean + N(0, sigma^2))."""
+TASKS = ("denoise", "sr", "inpaint")
+SR_FACTOR = 4
+REG_OF = {"denoise": REG, "sr": 0.03, "inpaint": 0.03}       # reg_noise_std of the three notebooks
+
+
+def problem(size=None, task="denoise"):
+    """Clean image: smooth colour gradients + one step edge.  Returns (clean, target):
+       denoise  target = clip(clean + N(0, sigma^2))                                        (denoising.ipynb)
+       sr       target = the x4 smaller image (4x4 box means of the clean one)               (super-resolution.ipynb: imgs['LR_np'])
+       inpaint  target = (clean, mask): mask = 0 on three bars and a dozen small squares     (inpainting.ipynb: img_mask)"""
     size = size or SIZE
     rng = np.random.RandomState(0)
     yy, xx = np.mgrid[0:size, 0:size] / float(size)
     clean = np.stack([0.5 + 0.4 * np.sin(6 * xx) * np.cos(4 * yy), 0.5 + 0.4 * np.cos(5 * xx + 2 * yy),
                       0.3 + 0.5 * (xx > 0.5)]).astype(np.float32)
-    noisy = np.clip(clean + rng.normal(scale=SIGMA, size=clean.shape), 0, 1).astype(np.float32)
-    return clean, noisy
+    if task == "denoise":
+        noisy = np.clip(clean + rng.normal(scale=SIGMA, size=clean.shape), 0, 1).astype(np.float32)
+        return clean, noisy
+    if task == "sr":
+        f = SR_FACTOR
+        lr = clean.reshape(3, size // f, f, size // f, f).mean(axis=(2, 4)).astype(np.float32)
+        return clean, lr
+    assert task == "inpaint", task
+    mask = np.ones((size, size), np.float32)
+    w = max(size // 32, 2)
+    mask[size // 5:size // 5 + w, :] = 0
+    mask[:, size // 3:size // 3 + w] = 0
+    for k in range(size):                                    # a diagonal bar
+        mask[k, max(0, min(size - 1, size - 1 - k)):max(0, min(size, size - 1 - k + w))] = 0
+    for _ in range(12):
+        y0, x0 = rng.randint(0, size - 2 * w, size=2)
+        mask[y0:y0 + 2 * w, x0:x0 + 2 * w] = 0
+    return clean, (clean, np.broadcast_to(mask, clean.shape).copy())
 
 
-def build(size=None):
-    """Default net + z exactly as the notebook builds them (torch.manual_seed(0))."""
+def build(size=None, task="denoise", skip_fn=None, get_net_fn=None, get_noise_fn=None):
+    """Net + z exactly as the notebooks build them (torch.manual_seed(0)): the default net for denoising and
+    super-resolution (denoising.ipynb:160-173, super-resolution.ipynb:133-140), the 'kate' net for inpainting
+    (inpainting.ipynb:150-164).  The constructors default to this package's; oracle/make_end_quality_golden.py passes the
+    REAL reference's."""
     size = size or SIZE
-    from models import get_net
-    from utils.common_utils import get_noise
+    if get_net_fn is None:
+        from models import get_net as get_net_fn
+    if skip_fn is None:
+        from models.skip import skip as skip_fn
+    if get_noise_fn is None:
+        from utils.common_utils import get_noise as get_noise_fn
     torch.manual_seed(0)
-    net = get_net(32, 'skip', 'reflection', skip_n33d=128, skip_n33u=128, skip_n11=4, num_scales=5,
-                  upsample_mode='bilinear')
-    z = get_noise(32, 'noise', (size, size))
+    if task == "inpaint":
+        net = skip_fn(32, 3, num_channels_down=[128] * 5, num_channels_up=[128] * 5, num_channels_skip=[128] * 5,
+                      filter_size_up=3, filter_size_down=3, upsample_mode='nearest', filter_skip_size=1,
+                      need_sigmoid=True, need_bias=True, pad='reflection', act_fun='LeakyReLU')
+    else:
+        net = get_net_fn(32, 'skip', 'reflection', skip_n33d=128, skip_n33u=128, skip_n11=4, num_scales=5,
+                         upsample_mode='bilinear')
+    z = get_noise_fn(32, 'noise', (size, size))
     return net, z
 
 
 GRAD_NOISE = float(os.environ.get("EQ_GRAD_NOISE", "0"))     # relative gradient perturbation (tools: noise-floor experiment)
 
 
-def run_fit(net_call, params_step, z, noisy, clean, iters, device, exp_weight=0.99, params=None):
+def run_fit(net_call, params_step, z, noisy, clean, iters, device, exp_weight=0.99, params=None, task="denoise", down=None):
     """The notebook closure with the reg-noise drawn from a host generator (same perturbations in
-    every arm).  net_call(x) -> out; params_step(closure) runs the optimisation loop."""
+    every arm).  net_call(x) -> out; params_step(closure) runs the optimisation loop.
+       denoise  loss = mse(out, noisy)                                  denoising.ipynb:204-221
+       sr       loss = mse(down(out_HR), img_LR), PSNR on out_HR        super-resolution.ipynb:169-199 (tv_weight = 0); `down` =
+                Downsampler(n_planes=3, factor=4, kernel_type='lanczos2', phase=0.5, preserve_size=True)
+       inpaint  loss = mse(out * mask, img * mask), PSNR on the whole image (holes included)   inpainting.ipynb:295-313
+    The EMA of the output (denoising.ipynb:213-217) is kept for all three as a second, less jittery read-out."""
     gen = torch.Generator().manual_seed(77)
     ngen = torch.Generator().manual_seed(78)
     zt = z.to(device)
-    tgt = torch.from_numpy(noisy)[None].to(device)
+    mask = None
+    if task == "inpaint":
+        img, m = noisy
+        tgt, mask = torch.from_numpy(img)[None].to(device), torch.from_numpy(m)[None].to(device)
+    else:
+        tgt = torch.from_numpy(noisy)[None].to(device)
     mse = torch.nn.MSELoss()
     st = {"i": 0, "avg": None, "loss": None, "tail": []}
+    reg = REG_OF[task]
 
     def closure():
-        noise = torch.randn(z.shape, generator=gen) * REG
+        noise = torch.randn(z.shape, generator=gen) * reg
         out = net_call(zt + noise.to(device))
         st["avg"] = out.detach() if st["avg"] is None else st["avg"] * exp_weight + out.detach() * (1 - exp_weight)
-        loss = mse(out, tgt)
+        if task == "sr":
+            loss = mse(down(out), tgt)
+        elif task == "inpaint":
+            loss = mse(out * mask, tgt * mask)
+        else:
+            loss = mse(out, tgt)
         loss.backward()
         if GRAD_NOISE > 0 and params is not None:     # diagnostic: a multiplicative roundoff-like error on every gradient element
             for p in params:

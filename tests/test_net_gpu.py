@@ -479,7 +479,7 @@ HIP_ARMS = [({}, 0),
             ({}, 1), ({}, 2)]
 
 
-def _hip_arms(size, iters, tmp_path, arms_spec=None):
+def _hip_arms(size, iters, tmp_path, arms_spec=None, task="denoise"):
     """The HIP fit once per environment in HIP_ARMS (each changes the summation order of some kernels and nothing
     else), every arm in a process of its own: the HIP-vs-HIP spread is the yard-stick next to the CPU-vs-CPU one."""
     import subprocess
@@ -488,7 +488,7 @@ def _hip_arms(size, iters, tmp_path, arms_spec=None):
     arms = []
     for k, (env, perturb) in enumerate(arms_spec or HIP_ARMS):
         out = str(tmp_path / f"hip_{k}.json")
-        r = subprocess.run([sys.executable, script, str(size), str(iters), out, str(perturb)], env=dict(os.environ, **env),
+        r = subprocess.run([sys.executable, script, str(size), str(iters), out, str(perturb), task], env=dict(os.environ, **env),
                            capture_output=True, text=True, timeout=3000)
         assert r.returncode == 0, r.stderr[-3000:]
         arms.append(json.load(open(out)))
@@ -567,6 +567,25 @@ def test_end_quality_baseline_config_256_1800(dev, tmp_path):
     assert gold["size"] == 256 and gold["iters"] == 1800 and len(gold["cpu_arms"]) >= 2
     hip = _hip_arms(256, 1800, tmp_path, HIP_ARMS[:4] + HIP_ARMS[4:5])      # 5 arms, ~1 minute each
     _compare_end_quality("end quality BASELINE configs[1]: default net 256x256, 1800 it", hip, gold["cpu_arms"])
+
+
+@pytest.mark.parametrize("task", ["sr", "inpaint"])
+def test_end_quality_sr_and_inpainting_128(dev, tmp_path, task):
+    """BASELINE.json configs[2] / [3] at 128x128, 600 iterations: the super-resolution closure (super-resolution.ipynb:169-199:
+    default net, loss through Downsampler(factor 4, lanczos2, phase 0.5, preserve_size), PSNR_HR on the full image) and the
+    masked closure (inpainting.ipynb:295-313: the 'kate' net -- 128 skip channels per scale, nearest up-sampling -- PSNR on the
+    whole image, holes included).  CPU arms = the REAL reference's skip / get_net / Downsampler / optimize on torch CPU fp32
+    (2 / 3 threads, one one-ulp weight perturbation), committed as tests/golden/end_quality_<task>_128_600.json by
+    oracle/make_end_quality_golden.py --task <task>; HIP arms run here (default engine, single-stream + no small-conv / ring
+    kernels, fp32-MFMA-only kernels, one one-ulp weight perturbation).  Same rule as the denoising arms
+    (_compare_end_quality: family means within 0.5 / 0.3 dB and 3 % loss, chaos-scaled outlier guard)."""
+    gold = json.load(open(os.path.join(GOLDEN, f"end_quality_{task}_128_600.json")))
+    assert gold["task"] == task and gold["size"] == 128 and gold["iters"] == 600 and len(gold["cpu_arms"]) >= 3
+    spec = [HIP_ARMS[0], ({"DIP_TWO_STREAMS": "0", "DIP_CONV_NO_SMALL": "1", "DIP_CONV_NO_RING": "1"}, 0),
+            ({"DIP_CONV_BF3": "0"}, 0), ({}, 1)]
+    hip = _hip_arms(128, 600, tmp_path, spec, task=task)
+    assert len(hip) >= 3
+    _compare_end_quality(f"end quality {task} 128x128, 600 it", hip, gold["cpu_arms"])
 
 
 def test_full_size_properties_512(dev):

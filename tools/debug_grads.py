@@ -3,7 +3,7 @@ backward kernels by recomputing them in fp64 from the engine's OWN buffers."""
 import os, sys
 import numpy as np
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repo root (this file lives in tests/)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repo root (this file lives in tools/: a developer diagnostic that checks the HIP path against the oracle, like the tests do)
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge
 ge.build()
