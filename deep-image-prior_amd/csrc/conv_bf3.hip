@@ -12,21 +12,19 @@
 // peak is 157.3, the LDS-DMA fp32 kernel reaches 119).
 //
 // Kernel: implicit GEMM, one workgroup (4 waves) = 8x16 output pixels x 128 output channels, a wave owns 64 x 64 =
-// 2 x 2 accumulators.  K is walked in units = (16-channel chunk, tap) = ONE K = 16 MFMA step: 12 ds_read_b128 (2 pixel
-// blocks + 2 channel blocks, 3 planes each) feed 36 MFMAs.
+// 2 x 2 accumulators.  K is walked in units = (16-channel chunk, tap) = ONE K = 16 MFMA step: 6 ds_read_b128 (A: 2 pixel
+// blocks x 3 planes) + 6 global_load_dwordx4 (B: 2 channel blocks x 3 planes) feed 36 MFMAs.
 //   * A (activations): the halo tile of a chunk (10 x 18 pixels x 16 channels) is loaded fp32 into registers one chunk
 //     ahead, put through the producer's BatchNorm + LeakyReLU, split into three bf16 planes and written to the OTHER
 //     of two LDS buffers ([plane][pixel][16 k] bf16 = 32 B per pixel; the two 16-B slots of a pixel are swapped
 //     with bit 3 of the pixel index, so the 16 lanes of a ds_read_b128 phase hit 16 distinct 4-bank groups);
-//   * B (weights): split once per iteration by dip_pack_weights_bf3 ([tap][chunk][plane][n][16 k] bf16) and copied
-//     global -> LDS by LDS-DMA two units ahead into one of three 12 KB buffers, the same swizzle applied on the source side;
-//   * one barrier per unit publishes the next B buffer (and, every ninth, the next A buffer); two workgroups per CU
-//     (76 KB LDS, <= 256 VGPRs) overlap each other's barriers and staging;
+//   * B (weights): split once per iteration by dip_pack_weights_bf3 ([tap][chunk][plane][n][16 k] bf16) and loaded from
+//     L2 straight into the MFMA operand registers, one unit ahead (see the comment on the kernel);
+//   * one barrier per CHUNK hands the A buffers over; two workgroups per CU (39 KB LDS, ~200 VGPRs);
 //   * epilogue: conv_epilogue.h (bias, store, BatchNorm partial statistics), shared with the fp32 kernels.
 // Everything else (stride 2, 1x1, 5x5 / 7x7, the low-resolution layers) stays on the fp32-MFMA kernels.
 #include "dip_common.h"
 #include "conv_epilogue.h"
-#include "lds_dma.h"
 #include <stdlib.h>
 
 namespace {
@@ -43,12 +41,9 @@ struct B3Cfg {
     static constexpr int WN = 2, WM = 2, MS = 2, NS = 2;
     static constexpr int A_PLANE = NPIX * 32;            // bytes: [pixel][16 bf16]
     static constexpr int A_BYTES = 3 * A_PLANE;
-    static constexpr int B_PLANE = 128 * 32;             // [n][16 bf16]
-    static constexpr int B_BYTES = 3 * B_PLANE;
     static constexpr int A_SLOTS = (NPIX * 4 + 255) / 256;      // float4 slots per thread and chunk (3)
     static constexpr int NPIX_PAD = (NPIX + 3) & ~3;
-    static constexpr int NBUF_B = 3;                      // weight buffers: the DMA of unit u + 2 is issued in unit u
-    static constexpr int LDS_BYTES = 2 * A_BYTES + NBUF_B * B_BYTES + NPIX_PAD * 4 + 2 * B3_TR_MAX * 4;
+    static constexpr int LDS_BYTES = 2 * A_BYTES + NPIX_PAD * 4 + 2 * B3_TR_MAX * 4;      // 39.4 KB
 };
 
 __device__ __forceinline__ int b3_map_src(int v, int n_in, int pad_mode) {
@@ -68,16 +63,28 @@ __device__ __forceinline__ void b3_split(float a, unsigned& h, unsigned& m, unsi
     l = __float_as_uint(r2) & 0xFFFF0000u;        // (<= 8 significand bits are left: the mask only drops zeros)
 }
 
-// NT = 9: all cross products (exact); NT = 6: without lo*lo, lo*mid, mid*lo (each < 2^-24 of the product)
+// NT = 9: all cross products (exact); NT = 6: without lo*lo, lo*mid, mid*lo (each < 2^-24 of the product).
+//
+// The B operand (weights) goes straight from L2 into registers, one unit ahead: no weight buffers in LDS, no LDS-DMA, and
+// ONE workgroup barrier per 16-channel chunk (9 units) -- the waves of a workgroup only meet where the A buffers change hands.
+// Round 4 started with the LDS-DMA form of the fp32 kernel (weights of a unit DMA'd two units ahead into one of three 12 KB
+// LDS buffers, one barrier per unit); per-workgroup wall-clock stamps and per-wave s_memtime sums showed a wave spending about
+// as long outside its MFMA burst (DMA issue, vmcnt wait, barrier, LDS-read latency: ~1000 cycles per unit) as in it (1152),
+// and the two waves that share a SIMD falling into step -- both in their bursts at half rate, then both outside with the
+// matrix pipe idle (counter utilisation 0.62; s_setprio by wave slot made one workgroup fast and the other slow, the sum
+// stayed).  This form: 540 -> 495 us on 128 -> 128 @ 512^2, 156 -> 132 us @ 256^2, +3.2 % per iteration.
+// A lane's B fragment is 16 contiguous bytes of the packed plane row of its column ([tap][chunk][plane][n][16 k]: lanes
+// 0..31 the first 8 k of 32 rows, lanes 32..63 the second 8 -- one contiguous KB per load instruction), 6 loads per unit;
+// the co-resident workgroup and the wave with the same column block read the same lines (vL1D / L2 hits).
+// A fragments are read from LDS one unit ahead as well (the A buffer of a chunk does not change while it is walked).
 template <int NT, int TR>
 __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(const DipConvDesc d, const int ntx, const int ntiles,
-                                                          const int CoutP, const int n_base, const int dbg) {
+                                                           const int CoutP, const int n_base) {
     using C = B3Cfg;
     constexpr int KK = 9;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Abuf = smem;
-    unsigned char* Bbuf = smem + 2 * C::A_BYTES;
-    int* srcoff = reinterpret_cast<int*>(Bbuf + C::NBUF_B * C::B_BYTES);
+    int* srcoff = reinterpret_cast<int*>(smem + 2 * C::A_BYTES);
     float* tra = reinterpret_cast<float*>(srcoff + C::NPIX_PAD);
     float* trb = tra + B3_TR_MAX;
 
@@ -98,10 +105,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(const DipConvDesc d, c
     if (TR) {
         for (int c = tid; c < d.Cin; c += 256) { tra[c] = d.tr.a[c]; trb[c] = d.tr.b[c]; }
     }
-
     const int nch = (d.Cin + B3_CCH - 1) / B3_CCH;
     const int nunits = nch * KK;
-    const unsigned short* w3 = reinterpret_cast<const unsigned short*>(d.wp3);
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -111,41 +116,48 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(const DipConvDesc d, c
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // LDS byte offsets of this lane's fragments (without plane / buffer / tap terms)
-    int a_pix[2];                       // halo pixel of (ms, lane) at tap (0, 0)
+    int a_pix[2];
 #pragma unroll
-    for (int ms = 0; ms < 2; ++ms) {
-        const int sub = wm * 2 + ms;
-        a_pix[ms] = (2 * sub + (l31 >> 4)) * C::HTW + (l31 & 15);
-    }
-    int b_off[2];
-#pragma unroll
-    for (int ns = 0; ns < 2; ++ns) {
-        const int nl = (wn * 2 + ns) * 32 + l31;
-        b_off[ns] = nl * 32 + ((half ^ ((nl >> 3) & 1)) << 4);
-    }
+    for (int ms = 0; ms < 2; ++ms) a_pix[ms] = (2 * (wm * 2 + ms) + (l31 >> 4)) * C::HTW + (l31 & 15);
 
+    // ---- A: as in conv_bf3_kernel (halo fp32 -> registers one chunk ahead -> transform, exact split, three bf16 planes) ----
     f32x4 av[C::A_SLOTS];
-    auto loadA = [&](int ch) {          // fp32 halo of chunk ch -> registers (global loads stay in flight)
-        const int cb = ch * B3_CCH;
 #pragma unroll
-        for (int i = 0; i < C::A_SLOTS; ++i) {
-            const int f = tid + i * 256;
-            const int hp = f >> 2, c = cb + (f & 3) * 4;
-            const int so = (hp < C::NPIX && c < d.Cin) ? srcoff[hp < C::NPIX ? hp : 0] : -1;
-            // unconditional load from a clamped address (storeA zeroes what is padding): no control flow around the load,
-            // and nothing here consumes the loaded registers, so the loads stay in flight under the MFMAs
-            av[i] = *reinterpret_cast<const f32x4*>(d.x + (size_t)(so >= 0 ? so : 0) * d.Cx + (so >= 0 ? c : 0));
+    for (int i = 0; i < C::A_SLOTS; ++i) av[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // halo loads of chunk `ch`, issued only when `on` (wave-uniform): the branch is INSIDE the asm statement, so that for the
+    // compiler the statement is unconditional straight-line code -- a compiler-visible branch around an asm load makes it
+    // merge the "loaded" and "not loaded" values of av[] behind the branch with register copies, i.e. it reads registers
+    // whose load is still in flight (seen in the ISA of an earlier form of this kernel)
+    auto loadA = [&](int ch, bool on) {
+        const int cb = ch * B3_CCH;
+        const float* src[C::A_SLOTS];
+#pragma unroll
+        for (int i = 0; i < C::A_SLOTS; ++i) src[i] = d.x;
+        if (on) {
+#pragma unroll
+            for (int i = 0; i < C::A_SLOTS; ++i) {
+                const int f = tid + i * 256;
+                const int hp = f >> 2, c = cb + (f & 3) * 4;
+                const int so = (hp < C::NPIX && c < d.Cin) ? srcoff[hp < C::NPIX ? hp : 0] : -1;
+                src[i] = d.x + (size_t)(so >= 0 ? so : 0) * d.Cx + (so >= 0 ? c : 0);     // clamped: storeA zeroes the padding
+            }
         }
+        const int on_s = __builtin_amdgcn_readfirstlane(on ? 1 : 0);
+        asm volatile("s_cmp_eq_u32 %6, 0\n\ts_cbranch_scc1 .Lb3r_noA_%=\n\t"
+                     "global_load_dwordx4 %0, %3, off\n\tglobal_load_dwordx4 %1, %4, off\n\tglobal_load_dwordx4 %2, %5, off\n"
+                     ".Lb3r_noA_%=:"
+                     : "+v"(av[0]), "+v"(av[1]), "+v"(av[2])
+                     : "v"(src[0]), "v"(src[1]), "v"(src[2]), "s"(on_s)
+                     : "scc");
     };
-    auto storeA = [&](int ch, int buf) {          // BatchNorm + activation, exact 3-way split, three bf16 planes
+    auto storeA = [&](int ch, int buf) {
         const int cb = ch * B3_CCH;
 #pragma unroll
         for (int i = 0; i < C::A_SLOTS; ++i) {
             const int f = tid + i * 256;
             const int hp = f >> 2, c4 = f & 3, c = cb + c4 * 4;
             if (hp < C::NPIX) {
-                const bool valid = c < d.Cin && srcoff[hp] >= 0;          // else: zero padding / channels past Cin
+                const bool valid = c < d.Cin && srcoff[hp] >= 0;
                 f32x4 o = av[i];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = valid ? o[e] : 0.f;
@@ -161,105 +173,131 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(const DipConvDesc d, c
 #pragma unroll
                 for (int e = 0; e < 4; ++e) b3_split(o[e], h[e], m[e], l[e]);
                 unsigned char* base = Abuf + buf * C::A_BYTES + hp * 32 + ((((c4 >> 1) ^ (hp >> 3)) & 1) << 4) + ((c4 & 1) << 3);
-                // two bf16 per dword: element e in the low half, e + 1 in the high half
                 *reinterpret_cast<u32x2*>(base) = u32x2{(h[0] >> 16) | h[1], (h[2] >> 16) | h[3]};
                 *reinterpret_cast<u32x2*>(base + C::A_PLANE) = u32x2{(m[0] >> 16) | m[1], (m[2] >> 16) | m[3]};
                 *reinterpret_cast<u32x2*>(base + 2 * C::A_PLANE) = u32x2{(l[0] >> 16) | l[1], (l[2] >> 16) | l[3]};
             }
         }
     };
-    // weight DMA of a unit: 3 planes x 128 n x 32 B = 12 pieces of 1 KB, three per wave; the per-lane part of the source
-    // offset never changes (piece -> plane, column, swizzled 16-B slot), the unit only moves a wave-uniform base
-    unsigned b_src[3];
+
+    // ---- B: two register sets (current unit, next unit in flight: a third set / two units ahead measured 2 % slower) of
+    // 2 column blocks x 3 planes; per-lane byte offset inside a plane, wave-uniform unit base ----
+    bf16x8 bq[2][2][3];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        const int piece = wave + 4 * q, p = piece >> 2, nb = piece & 3;
-        const int nl = nb * 32 + (lane >> 1);
-        const int slot = (lane & 1) ^ ((nl >> 3) & 1);
-        const int nn = min(n0 + nl, CoutP - 1);                  // columns past CoutP are never stored
-        b_src[q] = (unsigned)((((p * CoutP + nn) << 4) + (slot << 3)) * 2);       // bytes
+    for (int sidx = 0; sidx < 2; ++sidx)
+#pragma unroll
+        for (int ns = 0; ns < 2; ++ns)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bq[sidx][ns][p] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned b_voff[2];
+#pragma unroll
+    for (int ns = 0; ns < 2; ++ns) {
+        const int nn = min(n0 + (wn * 2 + ns) * 32 + l31, CoutP - 1);          // columns past CoutP are never stored
+        b_voff[ns] = (unsigned)(nn * 32 + half * 16);
     }
-    const unsigned b_lds0 = (unsigned)(size_t)(lptr_t)Bbuf;
-    auto dmaB = [&](int u, int buf) {
-        const int ch = u / KK, tap = u - ch * KK;
-        const unsigned char* ubase = reinterpret_cast<const unsigned char*>(w3) + (size_t)(tap * nch + ch) * 3 * CoutP * 32;
+    const unsigned char* w3 = reinterpret_cast<const unsigned char*>(d.wp3);
+    const size_t plane_bytes = (size_t)CoutP * 32;
+    typedef bf16x8 (&BSet)[2][3];
+    auto loadB = [&](BSet bs, int tapn, int chn) {
+        const unsigned char* ub = w3 + (size_t)(tapn * nch + chn) * 3 * plane_bytes;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const int piece = wave + 4 * q;
-            lds_dma16_s(ubase, b_src[q], b_lds0 + buf * C::B_BYTES + (piece >> 2) * C::B_PLANE + (piece & 3) * 1024);
+        for (int p = 0; p < 3; ++p) {
+            // wave-uniform base (SGPR pair) + 32-bit per-lane offset
+            const unsigned long long b64 = (unsigned long long)(ub + p * plane_bytes);
+            const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)b64);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(b64 >> 32));
+            const void* sb = (const void*)(((unsigned long long)hi << 32) | lo);
+#pragma unroll
+            for (int ns = 0; ns < 2; ++ns)
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(bs[ns][p]) : "v"(b_voff[ns]), "s"(sb));
         }
     };
-    auto compute = [&](int ky, int kx, int abuf, int bbuf) {
-        bf16x8 a[2][3], b[2][3];
+    // all B loads of the set have landed; keep3 (wave-uniform): the 3 halo loads issued after them may stay in flight.
+    // One unconditional statement with the choice inside (see loadA).
+    auto waitB = [&](BSet bs, bool keep3) {
+        const int k_s = __builtin_amdgcn_readfirstlane(keep3 ? 1 : 0);
+        asm volatile("s_cmp_eq_u32 %6, 0\n\ts_cbranch_scc1 .Lb3r_w0_%=\n\ts_waitcnt vmcnt(3)\n\ts_branch .Lb3r_we_%=\n"
+                     ".Lb3r_w0_%=:\n\ts_waitcnt vmcnt(0)\n.Lb3r_we_%=:"
+                     : "+v"(bs[0][0]), "+v"(bs[0][1]), "+v"(bs[0][2]), "+v"(bs[1][0]), "+v"(bs[1][1]), "+v"(bs[1][2])
+                     : "s"(k_s)
+                     : "scc");
+    };
+    // A fragments of a unit: 2 pixel blocks x 3 planes, read one unit ahead into the other register set (the A buffer of a
+    // chunk does not change while the chunk is walked, so this needs no synchronisation beyond the chunk boundary's)
+    typedef bf16x8 (&ASet)[2][3];
+    bf16x8 aq[2][2][3];
+    auto readA = [&](ASet as, int tapn, int abuf) {
+        const int ky = tapn / 3, kx = tapn - 3 * ky;
         const unsigned char* Ab = Abuf + abuf * C::A_BYTES;
-        const unsigned char* Bb = Bbuf + bbuf * C::B_BYTES;
 #pragma unroll
         for (int ms = 0; ms < 2; ++ms) {
             const int hp = a_pix[ms] + ky * C::HTW + kx;
             const unsigned char* pa = Ab + hp * 32 + (((half ^ (hp >> 3)) & 1) << 4);
 #pragma unroll
-            for (int p = 0; p < 3; ++p) a[ms][p] = *reinterpret_cast<const bf16x8*>(pa + p * C::A_PLANE);
+            for (int p = 0; p < 3; ++p) as[ms][p] = *reinterpret_cast<const bf16x8*>(pa + p * C::A_PLANE);
         }
+    };
+    auto compute = [&](BSet bs, ASet as) {
 #pragma unroll
-        for (int ns = 0; ns < 2; ++ns)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) b[ns][p] = *reinterpret_cast<const bf16x8*>(Bb + p * C::B_PLANE + b_off[ns]);
-        // smallest partial products first
-#pragma unroll
-        for (int s = 4; s >= 0; --s) {
-            if (NT == 6 && s > 2) continue;
+        for (int sm = 4; sm >= 0; --sm) {          // smallest partial products first
+            if (NT == 6 && sm > 2) continue;
 #pragma unroll
             for (int pa = 0; pa < 3; ++pa) {
-                const int pb = s - pa;
+                const int pb = sm - pa;
                 if (pb < 0 || pb > 2) continue;
 #pragma unroll
                 for (int ms = 0; ms < 2; ++ms)
 #pragma unroll
                     for (int ns = 0; ns < 2; ++ns)
-                        acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ms][pa], b[ns][pb], acc[ms][ns], 0, 0, 0);
+                        acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[ms][pa], bs[ns][pb], acc[ms][ns], 0, 0, 0);
             }
         }
     };
 
     // ---- prologue ----
     __syncthreads();                    // srcoff / tr tables
-    loadA(0);
-    dmaB(0, 0);
-    if (nunits > 1) dmaB(1, 1);
+    loadA(0, true);
+    loadB(bq[0], 0, 0);
+    asm volatile("s_waitcnt vmcnt(6)" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]));       // the halo (the 6 B loads are younger)
     storeA(0, 0);
-    dma_wait();
+    waitB(bq[0], false);
     __syncthreads();
+    readA(aq[0], 0, 0);
 
-    int ch = 0, tap = 0, bcur = 0;
-    for (int u = 0; u < nunits; ++u) {
+    int u = 0, ch = 0, tap = 0;
+    auto unit = [&](BSet cur, BSet nxt, ASet acur, ASet anxt) {
         const bool next_chunk = ch + 1 < nch;
-        // (the halo loads go first: hipcc guards the reuse of their registers with s_waitcnt vmcnt(0), which would also
-        // wait for the weight DMA if that were already in flight)
+        // the next chunk's halo (loaded at tap 0, landed by the end of tap 1: the B loads of tap 1 are younger and were waited
+        // for) goes to the other A buffer, last read a chunk ago (barrier at the end of tap 7)
+        if (tap == 4 && next_chunk) storeA(ch + 1, (ch + 1) & 1);
+        // next unit's weights (the last unit re-loads unit 0: never used, keeps the statement unconditional)
+        const bool more = u + 1 < nunits;
+        const bool wrap = tap == KK - 1;
+        const int tapn = more ? (wrap ? 0 : tap + 1) : 0, chn = more ? (wrap ? ch + 1 : ch) : 0;
+        // (issuing the six loads one by one between the groups of four MFMAs instead: no faster at 512^2, 5 % slower at 256^2;
+        // a third register set, i.e. two units ahead: 2 % slower)
+        loadB(nxt, tapn, chn);
         const bool ld = tap == 0 && next_chunk;
-        if (ld && !(dbg & 2)) loadA(ch + 1);                              // in flight under this chunk's first MFMAs
-        // the next chunk's halo goes to the other A buffer (last read a chunk ago) BEFORE this unit's DMA is issued: hipcc
-        // waits for the halo registers with vmcnt counts that do not know about the DMA pieces
-        if (tap == 4 && next_chunk && !(dbg & 2)) storeA(ch + 1, (ch + 1) & 1);
-        int bnext2 = bcur + 2;
-        if (bnext2 >= C::NBUF_B) bnext2 -= C::NBUF_B;
-        const bool dma2 = u + 2 < nunits && !(dbg & 1);
-        if (dma2) dmaB(u + 2, bnext2);                      // two units ahead: ~1 us to land
-        const int ky = tap / 3, kx = tap - 3 * ky;
-        if (!(dbg & 8)) compute(ky, kx, ch & 1, bcur);
-        if (u + 1 < nunits) {
-            // unit u + 1's weights have landed (loads retire in order: at most the 3 DMA pieces of unit u + 2 -- and the
-            // halo loads issued before them in this iteration -- may still be in flight)
-            if (!dma2) dma_wait();
-            else if (ld && !(dbg & 2)) dma_wait_keep(3 + C::A_SLOTS);
-            else dma_wait_keep(3);
-            if (!(dbg & 4)) __syncthreads();            // ... and everyone else's; A stores visible
-        }
+        loadA(ch + 1, ld);                                       // AFTER this unit's B loads: they can be waited for alone
+        readA(anxt, tapn, chn & 1);                              // next unit's A fragments, under this unit's MFMAs
+        compute(cur, acur);
+        __builtin_amdgcn_sched_barrier(0);          // (hipcc hoisted the wait to the 4th MFMA: a full L2 latency exposed per unit)
+        waitB(nxt, ld);
+        // A buffers change hands: the stores of tap 4 become visible before tap 8 reads the next chunk's first fragments, and
+        // every wave has issued (and, __syncthreads waits lgkmcnt(0), received) its last reads of the buffer that tap 4 of the
+        // next chunk overwrites
+        if (tap == KK - 2 && next_chunk) __syncthreads();
+        ++u;
         if (++tap == KK) { tap = 0; ++ch; }
-        if (++bcur == C::NBUF_B) bcur = 0;
+    };
+    while (u < nunits) {
+        unit(bq[0], bq[1], aq[0], aq[1]);
+        if (u < nunits) unit(bq[1], bq[0], aq[1], aq[0]);
     }
+    // the last unit's (unused) weight loads have been waited for (keep3 is false in the last chunk); nothing is in flight
 
     // ---- epilogue (conv_epilogue.h) ----
-    __syncthreads();                    // every wave is done with the staging buffers (the epilogue reuses them)
+    __syncthreads();
     const DipEpi epi = dip_epi_make(d, ty, tx, C::TH, C::TW);
     dip_conv_epilogue<C, 128>(d, acc, epi, n0, wn, wm, l31, half, tid, tile, CoutP, reinterpret_cast<float*>(smem));
 }
@@ -326,18 +364,13 @@ int bf3_launch(const DipConvDesc& d, int n_base, int ncols, hipStream_t st) {
     using C = B3Cfg;
     auto kern = conv_bf3_kernel<NT, TR>;
     static bool attr_set[16] = {};
-    int dev = 0;
-    hipGetDevice(&dev);
-    if (dev >= 0 && dev < 16 && !attr_set[dev]) {
+    if (dip_once_per_device(attr_set)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e != hipSuccess) { dip_set_error(hipGetErrorString(e)); return (int)e; }
-        attr_set[dev] = true;
     }
     const int ntx = dip_cdiv(d.Wout, C::TW), nty = dip_cdiv(d.Hout, C::TH);
     const int ntiles = ntx * nty;
-    static const int dbg = getenv("DIP_BF3_DEBUG") ? atoi(getenv("DIP_BF3_DEBUG")) : 0;      // timing experiments only
-    hipLaunchKernelGGL(kern, dim3(ntiles, dip_cdiv(ncols, 128)), dim3(256), C::LDS_BYTES, st, d, ntx, ntiles, dip_round_up(d.Cout, 32),
-                       n_base, dbg);
+    hipLaunchKernelGGL(kern, dim3(ntiles, dip_cdiv(ncols, 128)), dim3(256), C::LDS_BYTES, st, d, ntx, ntiles, dip_round_up(d.Cout, 32), n_base);
     DIP_CHECK_LAUNCH();
     return 0;
 }

@@ -287,14 +287,18 @@ int w3_launch(const DipWgradDesc& d, hipStream_t st) {
     int dev = 0;
     hipGetDevice(&dev);
     if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { dip_set_error(hipGetErrorString(e)); return (int)e; }
         attr_set[dev] = true;
     }
     const int ntx = dip_cdiv(d.Wout, C::TW), nty = dip_cdiv(d.Hout, C::TH);
     const int CinP = dip_round_up(d.Cin, 32), CoutP = dip_round_up(d.Cout, 32);
     const int nfull = ((d.Cin & 31) >= 1 && (d.Cin & 31) <= 4 && d.Cin > 32) ? (d.Cin >> 5) : dip_cdiv(d.Cin, 32);
-    hipLaunchKernelGGL(kern, dim3(d.nsplit, nfull, dip_cdiv(CoutP, 128)), dim3(256), C::LDS_BYTES, st, d, ntx, ntx * nty, CinP, CoutP);
+    // DIP_WGRAD_BF3_LDS=<bytes>: ask for more LDS than the kernel uses, so that fewer workgroups of this (bulk-stream) launch
+    // fit on a CU and the main chain's kernels find free slots next to it (experiment)
+    static const int lds_req = [] { const char* e = getenv("DIP_WGRAD_BF3_LDS"); return e ? atoi(e) : 0; }();
+    const int lds = lds_req > C::LDS_BYTES ? lds_req : C::LDS_BYTES;
+    hipLaunchKernelGGL(kern, dim3(d.nsplit, nfull, dip_cdiv(CoutP, 128)), dim3(256), lds, st, d, ntx, ntx * nty, CinP, CoutP);
     DIP_CHECK_LAUNCH();
     return 0;
 }
