@@ -508,6 +508,15 @@ def _compare_end_quality(tag, hip, cpu):
     print(f"{tag}: hip={hip}\n  cpu={cpu}")
     lmean = float(np.mean([c["loss"] for c in cpu]))
     thr = {"psnr_gt": 0.5, "psnr_gt_sm": 0.3, "loss": 0.03 * lmean}
+    # the 3 % rule presumes a final loss that is stable from run to run (denoising: 0.0089 +- 0.5 %).  The SR / inpainting fits
+    # end at ~1e-4, where the loss of ONE iteration is reg-noise jitter: the reference's own arms differ by 25 % there.  Where
+    # the CPU family itself is spread by more than the threshold, the family means are compared to within two standard
+    # errors instead (a systematic difference would still show; the spread is printed)
+    lc, lh = [c["loss"] for c in cpu], [h["loss"] for h in hip]
+    if max(lc) - min(lc) > thr["loss"]:
+        se = float(np.sqrt(np.var(lc, ddof=1) / len(lc) + (np.var(lh, ddof=1) / len(lh) if len(lh) > 1 else 0.0)))
+        thr["loss"] = max(thr["loss"], 2.0 * se)
+        print(f"  loss: CPU arms spread {100 * (max(lc) - min(lc)) / lmean:.1f} % > 3 %: comparing the family means within 2 standard errors = {thr['loss']:.3e}")
     for key, unit in (("psnr_gt", "dB"), ("psnr_gt_sm", "dB"), ("loss", "")):
         hv, cv = [h[key] for h in hip], [c[key] for c in cpu]
         sh, sc = max(hv) - min(hv), max(cv) - min(cv)
