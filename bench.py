@@ -89,18 +89,19 @@ def gather_floats(v: float):
 
 
 def gpu_sysfs_dir(dev_index):
-    """sysfs directory of HIP device `dev_index` of this process, found by its PCI address (hipDeviceGetPCIBusId) --
-    NOT by position among /sys/class/drm/card*: a container sees every card of the host there, while HIP enumerates only
-    the GPUs it was given (round 4: the `device` block and the power samples of earlier lines came from card0, another
-    tenant's GPU).  None when it cannot be determined."""
+    """sysfs directory of HIP device `dev_index` of this process, found by its PCI address (dip_device_pci_bus_id: the HIP
+    runtime libdip_hip.so itself runs on) -- NOT by position among /sys/class/drm/card*: a container sees every card of the
+    host there, while HIP enumerates only the GPUs it was given (round 4: the `device` block and the power samples of
+    earlier lines came from card0, another tenant's GPU).  None when it cannot be determined."""
     import ctypes
     try:
-        hip = ctypes.CDLL("libamdhip64.so")
+        import __graft_entry__ as ge
+        ge.add_to_path()
+        import dip_native
         buf = ctypes.create_string_buffer(64)
-        if hip.hipDeviceGetPCIBusId(buf, 64, int(dev_index)) != 0:
+        if dip_native.lib().dip_device_pci_bus_id(int(dev_index), buf, 64) != 0:
             return None
-        addr = buf.value.decode().strip().lower()
-        path = "/sys/bus/pci/devices/" + addr
+        path = "/sys/bus/pci/devices/" + buf.value.decode().strip().lower()
         return path if os.path.isdir(path) else None
     except Exception:
         return None

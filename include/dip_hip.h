@@ -40,6 +40,10 @@ extern "C" {
 
 int dip_abi_version(void);
 const char* dip_last_error(void);
+/* PCI address ("0000:d9:00.0", lower case hex) of HIP device `device`, for locating its sysfs directory
+ * (/sys/bus/pci/devices/<address>: hwmon power / clock sensors, numa_node).  No reference counterpart: bench.py's
+ * `device` / power blocks and its rank -> NUMA-node pinning use it.  buf: >= 13 bytes. */
+int dip_device_pci_bus_id(int device, char* buf, int len);
 
 
 /* Per-channel input transform fused into a consumer's loader:
