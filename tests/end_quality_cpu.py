@@ -112,7 +112,7 @@ def run_fit(net_call, params_step, z, noisy, clean, iters, device, exp_weight=0.
     else:
         tgt = torch.from_numpy(noisy)[None].to(device)
     mse = torch.nn.MSELoss()
-    st = {"i": 0, "avg": None, "loss": None, "tail": []}
+    st = {"i": 0, "avg": None, "loss": None, "tail": [], "ltail": []}
     reg = REG_OF[task]
 
     def closure():
@@ -134,12 +134,14 @@ def run_fit(net_call, params_step, z, noisy, clean, iters, device, exp_weight=0.
         st["loss"] = loss.detach()
         if st["i"] > iters - TAIL:              # single-iteration PSNR jitters by ~1 dB: average the tail
             st["tail"].append(O.psnr(clean, out.detach().cpu().numpy()[0]))
+            st["ltail"].append(float(loss.detach().item()))
         return loss
 
     t0 = time.time()
     params_step(closure)
+    # loss_tail: the SR / inpainting fits end at ~1e-4, where the loss of ONE iteration is reg-noise jitter (+-30 %)
     return {"psnr_gt": float(np.mean(st["tail"])), "psnr_gt_sm": O.psnr(clean, st["avg"].cpu().numpy()[0]),
-            "loss": float(st["loss"].item()), "sec": time.time() - t0}
+            "loss": float(st["loss"].item()), "loss_tail": float(np.mean(st["ltail"])), "sec": time.time() - t0}
 
 
 def perturb_one_weight(params, k):

@@ -506,6 +506,10 @@ def _compare_end_quality(tag, hip, cpu):
           which 6-7 arms of a family with a 0.8 dB spread meet only by chance -- round 4: one of seven arms at -0.36 dB).
     Both families and their spreads are printed."""
     print(f"{tag}: hip={hip}\n  cpu={cpu}")
+    if all("loss_tail" in a for a in hip + cpu):          # the mean over the last 20 iterations where every arm recorded it
+        hip = [dict(h, loss=h["loss_tail"]) for h in hip]
+        cpu = [dict(c, loss=c["loss_tail"]) for c in cpu]
+        print("  (loss = mean over the last 20 iterations)")
     lmean = float(np.mean([c["loss"] for c in cpu]))
     thr = {"psnr_gt": 0.5, "psnr_gt_sm": 0.3, "loss": 0.03 * lmean}
     # the 3 % rule presumes a final loss that is stable from run to run (denoising: 0.0089 +- 0.5 %).  The SR / inpainting fits
