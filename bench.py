@@ -878,6 +878,43 @@ def timed_run(fits, steps, warmup, use_graph, barrier):
     return t, graph is not None, note, ps.summary(t0, t1)
 
 
+def grouped_fits(config, images, dev):
+    """The same fits as one dip_group.GroupedFits (ONE launch list for all of them): fresh nets with the seeds of `images`."""
+    from dip_group import GroupedFits
+    fits = [Fit(config, img, dev, "fused") for img in images]
+    f0 = fits[0]
+    if f0.down is not None:
+        raise NotImplementedError("the SR closure (loss through the Downsampler) has no grouped form")
+    ema = config in ("default", "snail")
+    return GroupedFits([f.net for f in fits], [f.z for f in fits], [f.target for f in fits],
+                       masks=None if f0.mask is None else [f.mask for f in fits], reg_noise_std=f0.reg_std,
+                       seeds=[1234] * len(fits), lr=0.01, exp_weight=0.99 if ema else None, ema_init="first", device=dev)
+
+
+def timed_run_grouped(g, steps, warmup, use_graph, barrier):
+    """timed_run for a GroupedFits: W untimed grouped iterations (the hipGraph capture among them), then exactly K timed."""
+    import torch
+    with PowerSampler(torch.cuda.current_device()) as ps:
+        if use_graph:
+            g.capture(warmup=min(3, max(warmup, 1)))
+            rest = warmup - g.iterations
+            if rest > 0:
+                g.run(rest)
+        else:
+            g.step(warmup)
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        if use_graph:
+            g.run(steps)
+        else:
+            g.step(steps)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+    barrier()
+    return t1 - t0, ps.summary(t0, t1)
+
+
 def selftest_rank(args, rank, world, barrier):
     """DIP_BENCH_SELFTEST=1: the N-rank plumbing (spawn, rendezvous, barrier, max-over-ranks, per-rank
     gather, JSON) with a dummy CPU step instead of the GPU fit -- driven by tests/test_host.py."""
@@ -902,6 +939,9 @@ def main():
                     help="timed region: hipGraph replays, eager launches, or both (the faster one is reported)")
     ap.add_argument("--no-graph", action="store_true", help="same as --mode eager")
     ap.add_argument("--instances", type=int, default=1, help="independent fits per GPU, grouped into one hipGraph")
+    ap.add_argument("--group", default="both", choices=["both", "native", "graphs"],
+                    help="--instances B > 1: 'native' = ONE launch list for the B fits (dip_group.GroupedFits: every launch "
+                         "serves all instances), 'graphs' = B hipGraphs on B streams, 'both' = time both, report the faster")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-eager-line", action="store_true")
@@ -970,15 +1010,36 @@ def main():
         torch.cuda.synchronize()
         per_op = profile_ops(fits[0].engine)
     runs = []
-    for use_graph in modes:
-        t, graphed, note, power = timed_run(fits, args.steps, args.warmup, use_graph, barrier)
-        runs.append({"t": reduce_max_time(t), "mine": len(fits) * args.steps / t, "graphed": graphed, "note": note,
-                     "power": power})
+    native_ok = n_inst > 1 and args.closure == "fused" and args.config != "sr" and args.group != "graphs"
+    if not (native_ok and args.group == "native"):
+        for use_graph in modes:
+            t, graphed, note, power = timed_run(fits, args.steps, args.warmup, use_graph, barrier)
+            runs.append({"t": reduce_max_time(t), "mine": len(fits) * args.steps / t, "graphed": graphed, "note": note,
+                         "power": power, "form": "one hipGraph per fit on its own stream" if graphed else
+                         "eager launch lists, one fit after the other", "loss": float(fits[0].loss.item())})
+    grouped = None
+    if native_ok:
+        # the same fits through ONE launch list (csrc/dip_group.h): every kernel launch serves all n_inst instances
+        try:
+            for use_graph in modes:
+                grouped = grouped_fits(args.config, my_images, dev)
+                t, power = timed_run_grouped(grouped, args.steps, args.warmup, use_graph, barrier)
+                runs.append({"t": reduce_max_time(t), "mine": len(fits) * args.steps / t, "graphed": use_graph, "note": None,
+                             "power": power, "form": f"grouped: one launch list for the {n_inst} fits"
+                             + (", replayed as ONE hipGraph" if use_graph else ", eager launches"),
+                             "loss": float(grouped.losses[0].item()), "native_mask": int(grouped.lib.dip_group_native(-1))})
+        except Exception as e:
+            if args.group == "native" or world > 1:      # (all ranks must time the same forms: no silent per-rank divergence)
+                raise
+            runs.append({"t": float("inf"), "mine": 0.0, "graphed": False, "power": None, "loss": float("nan"),
+                         "note": f"grouped form failed: {type(e).__name__}: {e}", "form": "grouped (failed)"})
+            torch.cuda.synchronize()
     runs.sort(key=lambda r: r["t"])
     best = runs[0]
     tmax, graphed, note = best["t"], best["graphed"], best["note"]
     per_rank = gather_floats(best["mine"])
-    final_loss = float(fits[0].loss.item())
+    # (the per-fit forms keep training the same fits across the timed modes: their final loss is read at the end)
+    final_loss = best["loss"] if best["form"].startswith("grouped") else float(fits[0].loss.item())
     # every rank's first fit: rank r's image index is r * instances, i.e. "rank r == the solo fit with that seed" can be
     # checked bitwise across runs
     per_rank_loss = gather_floats(final_loss)
@@ -1048,10 +1109,16 @@ def main():
         }
         line["config"]["reported_mode"] = ("hipGraph replays" if graphed else "eager launches (main + side + bulk HIP stream)") + \
             " of the iteration with the fused closure (RegNoise + MSEHead + in-place EMA)"
+        if n_inst > 1:
+            line["config"]["reported_mode"] = best["form"] + "; fused closure (RegNoise + MSEHead + in-place EMA)"
+            line["config"]["grouped_native_families_mask"] = best.get("native_mask")
         if len(runs) > 1:
-            o = runs[1]
-            line["other_mode"] = {"hipgraph": o["graphed"], "it_s": round(world * len(fits) * args.steps / o["t"], 3),
-                                  "ms_per_step": round(1e3 * o["t"] / args.steps, 3)}
+            line["other_mode"] = [{"form": o["form"], "hipgraph": o["graphed"],
+                                   "it_s": round(world * len(fits) * args.steps / o["t"], 3) if o["t"] != float("inf") else None,
+                                   "ms_per_step": round(1e3 * o["t"] / args.steps, 3) if o["t"] != float("inf") else None,
+                                   "note": o.get("note")} for o in runs[1:]]
+            if len(runs) == 2:                   # (the single-fit line keeps its round-3 shape: one object)
+                line["other_mode"] = line["other_mode"][0]
         if note:
             line["config"]["note"] = note
         print(json.dumps(line), flush=True)

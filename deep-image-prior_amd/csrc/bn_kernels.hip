@@ -2,6 +2,7 @@
 // LeakyReLU backward and the adjoint of ReflectionPad2d.  All HBM-bound: float4 per lane, NHWC.
 #include "dip_common.h"
 #include "bn_ticket.h"
+#include "dip_group.h"
 #include <stdlib.h>
 
 namespace {
@@ -14,11 +15,18 @@ namespace {
 // followed by a fixed-order tree over the 256 rows (deterministic).  The first version walked the
 // partials twice with 4-byte loads, 64 rows per block: 32 dependent trips, 27 us at 512x512.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partials, int ntiles,
-                                                          int Cstride, int C, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, float eps, float momentum,
-                                                          float* state, int Cs, float* running_mean,
-                                                          float* running_var) {
+template <bool GRP = false>
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partials_, int ntiles,
+                                                          int Cstride, int C, const float* __restrict__ gamma_,
+                                                          const float* __restrict__ beta_, float eps, float momentum,
+                                                          float* state_, int Cs, float* running_mean_,
+                                                          float* running_var_, const DipGrpArg<GRP> grp) {
+    DIP_GRP_PTR(const float*, partials);
+    DIP_GRP_PTR(const float*, gamma);
+    DIP_GRP_PTR(const float*, beta);
+    DIP_GRP_PTR(float*, state);
+    DIP_GRP_PTR(float*, running_mean);
+    DIP_GRP_PTR(float*, running_var);
     __shared__ double sh[256][12];
     const int row = threadIdx.x;
     const int c0 = blockIdx.x * 4;
@@ -166,10 +174,17 @@ __device__ __forceinline__ void block_reduce_2(const RowLayout& L, f32x4 s1, f32
 // ------------------------------------------------------------------------------------------
 // backward phase 1: dz = du * lrelu'(a*y+b); partial sums S1 = sum dz, S2 = sum dz*xhat
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const DipGradSrc src, const float* __restrict__ y, int H,
-                                                           int W, int Cy, int C, const float* __restrict__ state,
-                                                           int Cs, float slope, float* dz, int Cdz, float* partials,
-                                                           int ppb /*pixels per block*/, const DipBnbFin fin) {
+template <bool GRP = false>
+__global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const DipGradSrc src_, const float* __restrict__ y_, int H,
+                                                           int W, int Cy, int C, const float* __restrict__ state_,
+                                                           int Cs, float slope, float* dz_, int Cdz, float* partials_,
+                                                           int ppb /*pixels per block*/, const DipBnbFin fin_, const DipGrpArg<GRP> grp) {
+    DIP_GRP_DESC(DipGradSrc, src);
+    DIP_GRP_PTR(const float*, y);
+    DIP_GRP_PTR(const float*, state);
+    DIP_GRP_PTR(float*, dz);
+    DIP_GRP_PTR(float*, partials);
+    DIP_GRP_DESC(DipBnbFin, fin);
     __shared__ __attribute__((aligned(16))) double shd[256 * 8];        // float tree, then the fp64 finalisation tree
     __shared__ unsigned flag;
     float* sh = reinterpret_cast<float*>(shd);
@@ -231,10 +246,16 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const DipGradSrc src,
 // ------------------------------------------------------------------------------------------
 // backward phase 2: reduce partials (fp64, fixed order) -> dgamma, dbeta, k1 = S1/N, k2 = S2/N
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nblk,
-                                                              const float* __restrict__ partials_lo, int nblk_lo,
-                                                              int c_lo, int Cs, int C, int npix, float* dgamma,
-                                                              float* dbeta, float* coef) {
+template <bool GRP = false>
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partials_, int nblk,
+                                                              const float* __restrict__ partials_lo_, int nblk_lo,
+                                                              int c_lo, int Cs, int C, int npix, float* dgamma_,
+                                                              float* dbeta_, float* coef_, const DipGrpArg<GRP> grp) {
+    DIP_GRP_PTR(const float*, partials);
+    DIP_GRP_PTR(const float*, partials_lo);
+    DIP_GRP_PTR(float*, dgamma);
+    DIP_GRP_PTR(float*, dbeta);
+    DIP_GRP_PTR(float*, coef);
     // block = 256 partial rows x 4 channels (16-byte loads), fp64, fixed-order tree
     __shared__ double sh[256][8];
     const int row = threadIdx.x;
@@ -271,9 +292,14 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 // ------------------------------------------------------------------------------------------
 // backward phase 3 (in place): dy = a * (dz - k1 - xhat * k2)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* dz, int Cdz, const float* __restrict__ y, int Cy,
-                                                           int npix, int C, const float* __restrict__ state, int Cs,
-                                                           const float* __restrict__ coef, int ppb) {
+template <bool GRP = false>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* dz_, int Cdz, const float* __restrict__ y_, int Cy,
+                                                           int npix, int C, const float* __restrict__ state_, int Cs,
+                                                           const float* __restrict__ coef_, int ppb, const DipGrpArg<GRP> grp) {
+    DIP_GRP_PTR(float*, dz);
+    DIP_GRP_PTR(const float*, y);
+    DIP_GRP_PTR(const float*, state);
+    DIP_GRP_PTR(const float*, coef);
     const RowLayout L = row_layout(C);
     if (!L.active) return;
     const int ch = L.cg * 4;
@@ -296,10 +322,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* dz, int Cdz, c
 // backward phase 3 from the gradient source (phase 1 ran with dz == NULL): the masked gradient is
 // recomputed instead of being written by phase 1 and re-read here -- 5 tensor passes per BatchNorm
 // instead of 6:  dy = a * (du * lrelu'(a*y+b) - k1 - xhat * k2)
-__global__ __launch_bounds__(256) void bn_bwd_apply_src_kernel(const DipGradSrc src, const float* __restrict__ y, int H,
-                                                               int W, int Cy, int C, const float* __restrict__ state,
-                                                               int Cs, float slope, const float* __restrict__ coef,
-                                                               float* __restrict__ dy, int Cdy, int ppb) {
+template <bool GRP = false>
+__global__ __launch_bounds__(256) void bn_bwd_apply_src_kernel(const DipGradSrc src_, const float* __restrict__ y_, int H,
+                                                               int W, int Cy, int C, const float* __restrict__ state_,
+                                                               int Cs, float slope, const float* __restrict__ coef_,
+                                                               float* __restrict__ dy_, int Cdy, int ppb, const DipGrpArg<GRP> grp) {
+    DIP_GRP_DESC(DipGradSrc, src);
+    DIP_GRP_PTR(const float*, y);
+    DIP_GRP_PTR(const float*, state);
+    DIP_GRP_PTR(const float*, coef);
+    DIP_GRP_PTR(float*, dy);
     const RowLayout L = row_layout(C);
     if (!L.active) return;
     const int ch = L.cg * 4;
@@ -382,8 +414,8 @@ __host__ int pixels_per_block(int npix, int C, int* nblk, bool apply = false) {
 extern "C" int dip_bn_finalize(const float* partials, int ntiles, int Cstride, int C, const float* gamma,
                                const float* beta, float eps, float momentum, float* state, int Cs,
                                float* running_mean, float* running_var, void* stream) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(dip_cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, partials,
-                       ntiles, Cstride, C, gamma, beta, eps, momentum, state, Cs, running_mean, running_var);
+    dip_launch_pair<DIP_FAM_BN>(bn_finalize_kernel<false>, bn_finalize_kernel<true>, dim3(dip_cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, partials,
+                                ntiles, Cstride, C, gamma, beta, eps, momentum, state, Cs, running_mean, running_var);
     DIP_CHECK_LAUNCH();
     return 0;
 }
@@ -409,8 +441,8 @@ extern "C" int dip_bn_bwd_stats_fin(const DipGradSrc* src, const float* y, int H
         if (C > 256 || nb > 256 || fin.ticket == nullptr || fin.C != C)
             DIP_FAIL("bn_bwd_stats_fin: needs <= 256 channels and rows (dip_fin_rows_ok), a ticket, C");
     }
-    hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *src, y, H, W, Cy, C,
-                       state, Cs, slope, dz, Cdz, partials, ppb, fin);
+    dip_launch_pair<DIP_FAM_BN>(bn_bwd_stats_kernel<false>, bn_bwd_stats_kernel<true>, dim3(nb), dim3(256), 0, (hipStream_t)stream, *src, y, H, W, Cy,
+                                C, state, Cs, slope, dz, Cdz, partials, ppb, fin);
     DIP_CHECK_LAUNCH();
     return 0;
 }
@@ -423,8 +455,8 @@ extern "C" int dip_bn_bwd_stats(const DipGradSrc* src, const float* y, int H, in
 
 extern "C" int dip_bn_bwd_finalize(const float* partials, int nblk, int Cs, int C, int npix, float* dgamma,
                                    float* dbeta, float* coef, void* stream) {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(dip_cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, partials,
-                       nblk, nullptr, 0, 0, Cs, C, npix, dgamma, dbeta, coef);
+    dip_launch_pair<DIP_FAM_BN>(bn_bwd_finalize_kernel<false>, bn_bwd_finalize_kernel<true>, dim3(dip_cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream,
+                                partials, nblk, (const float*)nullptr, 0, 0, Cs, C, npix, dgamma, dbeta, coef);
     DIP_CHECK_LAUNCH();
     return 0;
 }
@@ -432,8 +464,8 @@ extern "C" int dip_bn_bwd_finalize(const float* partials, int nblk, int Cs, int 
 extern "C" int dip_bn_bwd_finalize2(const float* partials, int nblk, const float* partials_lo, int nblk_lo, int c_lo,
                                     int Cs, int C, int npix, float* dgamma, float* dbeta, float* coef, void* stream) {
     if ((c_lo & 3) || (c_lo > 0 && partials_lo == nullptr)) DIP_FAIL("bn_bwd_finalize2: c_lo must be a multiple of 4");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(dip_cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, partials,
-                       nblk, partials_lo, nblk_lo, c_lo, Cs, C, npix, dgamma, dbeta, coef);
+    dip_launch_pair<DIP_FAM_BN>(bn_bwd_finalize_kernel<false>, bn_bwd_finalize_kernel<true>, dim3(dip_cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream,
+                                partials, nblk, partials_lo, nblk_lo, c_lo, Cs, C, npix, dgamma, dbeta, coef);
     DIP_CHECK_LAUNCH();
     return 0;
 }
@@ -442,8 +474,8 @@ extern "C" int dip_bn_bwd_apply(float* dz, int Cdz, const float* y, int Cy, int 
                                 int Cs, const float* coef, void* stream) {
     int nb;
     const int ppb = pixels_per_block(npix, C, &nb, true);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dz, Cdz, y, Cy, npix, C,
-                       state, Cs, coef, ppb);
+    dip_launch_pair<DIP_FAM_BN>(bn_bwd_apply_kernel<false>, bn_bwd_apply_kernel<true>, dim3(nb), dim3(256), 0, (hipStream_t)stream, dz, Cdz, y, Cy, npix,
+                                C, state, Cs, coef, ppb);
     DIP_CHECK_LAUNCH();
     return 0;
 }
@@ -454,8 +486,8 @@ extern "C" int dip_bn_bwd_apply_src(const DipGradSrc* src, const float* y, int H
     if (C > 1024) DIP_FAIL("bn_bwd_apply_src: C > 1024 unsupported");
     int nb;
     const int ppb = pixels_per_block(H * W, C, &nb, true);
-    hipLaunchKernelGGL(bn_bwd_apply_src_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *src, y, H, W, Cy, C,
-                       state, Cs, slope, coef, dy, Cdy, ppb);
+    dip_launch_pair<DIP_FAM_BN>(bn_bwd_apply_src_kernel<false>, bn_bwd_apply_src_kernel<true>, dim3(nb), dim3(256), 0, (hipStream_t)stream, *src, y, H,
+                                W, Cy, C, state, Cs, slope, coef, dy, Cdy, ppb);
     DIP_CHECK_LAUNCH();
     return 0;
 }
@@ -463,15 +495,13 @@ extern "C" int dip_bn_bwd_apply_src(const DipGradSrc* src, const float* y, int H
 extern "C" int dip_fold_to_nhwc(const DipGradSrc* src, int H, int W, int C, float* dst, int Cd, void* stream) {
     if ((Cd & 3) || (src->Cg & 3)) DIP_FAIL("fold_to_nhwc: channel strides must be multiples of 4");
     const long long n = (long long)H * W * ((C + 3) / 4);
-    hipLaunchKernelGGL(fold_to_nhwc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *src, H,
-                       W, C, dst, Cd);
+    dip_launch(fold_to_nhwc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *src, H, W, C, dst, Cd);
     DIP_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int dip_fold_to_nchw(const DipGradSrc* src, int H, int W, int C, float* dst, void* stream) {
-    hipLaunchKernelGGL(fold_to_nchw_kernel, dim3(dip_cdiv(H * W, 256)), dim3(256), 0, (hipStream_t)stream, *src, H,
-                       W, C, dst);
+    dip_launch(fold_to_nchw_kernel, dim3(dip_cdiv(H * W, 256)), dim3(256), 0, (hipStream_t)stream, *src, H, W, C, dst);
     DIP_CHECK_LAUNCH();
     return 0;
 }

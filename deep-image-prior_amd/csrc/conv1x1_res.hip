@@ -20,6 +20,7 @@
 // Domain (dip_conv1x1_res_eligible): ks 1, stride 1, Cin == 128, Cout <= 128, H % 8 == 0 and W % 16 == 0 (then the
 // 128-pixel tiles are as many as the 8x16 tiles the planner sized the statistics buffers for), >= 65536 pixels, one pass.
 #include "dip_common.h"
+#include "dip_group.h"
 #include "conv_epilogue.h"
 #include "lds_dma.h"
 #include <stdlib.h>
@@ -247,9 +248,9 @@ extern "C" int dip_conv1x1_res(const DipConvDesc* dp, void* stream) {
     const int grid = nmacro < 2 * ncu ? nmacro : 2 * ncu;          // two persistent workgroups per CU
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (d.tr.a != nullptr)
-        hipLaunchKernelGGL(conv1x1_res_kernel<true>, dim3(grid), dim3(256), R_LDS_BYTES, st, d, nmacro, CoutP);
+        dip_launch(conv1x1_res_kernel<true>, dim3(grid), dim3(256), R_LDS_BYTES, st, d, nmacro, CoutP);
     else
-        hipLaunchKernelGGL(conv1x1_res_kernel<false>, dim3(grid), dim3(256), R_LDS_BYTES, st, d, nmacro, CoutP);
+        dip_launch(conv1x1_res_kernel<false>, dim3(grid), dim3(256), R_LDS_BYTES, st, d, nmacro, CoutP);
     DIP_CHECK_LAUNCH();
     return 0;
 }

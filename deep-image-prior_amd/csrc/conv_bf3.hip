@@ -24,6 +24,7 @@
 //   * epilogue: conv_epilogue.h (bias, store, BatchNorm partial statistics), shared with the fp32 kernels.
 // Everything else (stride 2, 1x1, 5x5 / 7x7, the low-resolution layers) stays on the fp32-MFMA kernels.
 #include "dip_common.h"
+#include "dip_group.h"
 #include "conv_epilogue.h"
 #include <stdlib.h>
 
@@ -305,8 +306,12 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(const DipConvDesc d, c
 // ------------------------------------------------------------------------------------------------------------------
 // weights -> three bf16 planes, [tap][chunk][plane][n][16 k]; forward: k = input channel, n = output channel;
 // data gradient: k = output channel, n = input channel, flipped taps
-__global__ __launch_bounds__(256) void pack_weights_bf3_kernel(const float* __restrict__ params, unsigned short* __restrict__ out,
-                                                               const DipPackRec3* __restrict__ recs) {
+template <bool GRP = false>
+__global__ __launch_bounds__(256) void pack_weights_bf3_kernel(const float* __restrict__ params_, unsigned short* __restrict__ out_,
+                                                               const DipPackRec3* __restrict__ recs_, const DipGrpArg<GRP> grp) {
+    DIP_GRP_PTR(const float*, params);
+    DIP_GRP_PTR(unsigned short*, out);
+    DIP_GRP_PTR(const DipPackRec3*, recs);
     const DipPackRec3 r = recs[blockIdx.y];
     const int KK = r.KS * r.KS;
     const long long nf = r.fwd_off >= 0 ? (long long)KK * r.nchF * r.CoutP32 * 16 : 0;
@@ -370,7 +375,7 @@ int bf3_launch(const DipConvDesc& d, int n_base, int ncols, hipStream_t st) {
     }
     const int ntx = dip_cdiv(d.Wout, C::TW), nty = dip_cdiv(d.Hout, C::TH);
     const int ntiles = ntx * nty;
-    hipLaunchKernelGGL(kern, dim3(ntiles, dip_cdiv(ncols, 128)), dim3(256), C::LDS_BYTES, st, d, ntx, ntiles, dip_round_up(d.Cout, 32), n_base);
+    dip_launch(kern, dim3(ntiles, dip_cdiv(ncols, 128)), dim3(256), C::LDS_BYTES, st, d, ntx, ntiles, dip_round_up(d.Cout, 32), n_base);
     DIP_CHECK_LAUNCH();
     return 0;
 }
@@ -420,7 +425,7 @@ extern "C" int dip_pack_weights_bf3(const float* params, void* packed3, const Di
     long long gx = (max_elems + 256 * 8 - 1) / (256 * 8);
     if (gx < 1) gx = 1;
     if (gx > 512) gx = 512;
-    hipLaunchKernelGGL(pack_weights_bf3_kernel, dim3((unsigned)gx, nrec), dim3(256), 0, (hipStream_t)stream, params,
+    dip_launch_pair<DIP_FAM_MISC>(pack_weights_bf3_kernel<false>, pack_weights_bf3_kernel<true>, dim3((unsigned)gx, nrec), dim3(256), 0, (hipStream_t)stream, params,
                        reinterpret_cast<unsigned short*>(packed3), recs_dev);
     DIP_CHECK_LAUNCH();
     return 0;

@@ -27,6 +27,7 @@
 // splitk_finish_kernel sums the slices in a fixed order, adds the bias and emits the statistics.
 #include "dip_common.h"
 #include "conv_epilogue.h"
+#include "dip_group.h"
 #include <stdlib.h>
 
 namespace {
@@ -92,10 +93,12 @@ __device__ __forceinline__ void lds_dma16(const float* gsrc, float* lds_dst_wave
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-template <int KS, int S, int CCH, int BN, bool EXTRA>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const DipConvDesc d, const int ntx, const int ntiles,
+template <int KS, int S, int CCH, int BN, bool EXTRA, bool GRP = false>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const DipConvDesc d_, const int ntx, const int ntiles,
                                                             const int CoutP, const int n_base, const int ksplit,
-                                                            float* __restrict__ ws) {
+                                                            float* __restrict__ ws_, const DipGrpArg<GRP> grp) {
+    DIP_GRP_DESC(DipConvDesc, d);
+    DIP_GRP_PTR(float*, ws);
     using C = Cfg<KS, S, CCH, BN, EXTRA>;
     constexpr int BNB = C::BNB;
     constexpr int KK = KS * KS;
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const DipConvDesc d,
     else { nchunks = nfull + 1; last_cc = rem; }
     const int cin4 = d.Cin >> 2;
     const int nunits = nchunks * KK;
-    const int z = blockIdx.z;
+    const int z = dip_grp_z<GRP>(grp);
     const int u0 = (int)(((long long)z * nunits) / ksplit);
     const int u1 = (int)(((long long)(z + 1) * nunits) / ksplit);
 
@@ -332,8 +335,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const DipConvDesc d,
 
 // Sum the split-K slices (fixed order), add bias, store (honouring y_pitch / accumulate) and emit
 // {count, mean, M2} partials per block: thread (prow, cg) owns 4 channels of pixels prow, prow+rpi...
-__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ ws, int ksplit, DipConvDesc d,
-                                                            int CoutP, int ppb) {
+template <bool GRP = false>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ ws_, int ksplit, DipConvDesc d_,
+                                                            int CoutP, int ppb, const DipGrpArg<GRP> grp) {
+    DIP_GRP_PTR(const float*, ws);
+    DIP_GRP_DESC(DipConvDesc, d);
     __shared__ __attribute__((aligned(16))) float sh[256 * 12];
     const int nc4 = d.Cy >> 2;
     int rpi = 256 / nc4;
@@ -425,16 +431,16 @@ int launch(const DipConvDesc& d, hipStream_t st, int n_base, int grid_y, int ksp
     using C = Cfg<KS, S, CCH, BN, EXTRA>;
     static bool attr_set[16] = {};
     auto kern = conv_igemm_kernel<KS, S, CCH, BN, EXTRA>;
+    auto kern_g = conv_igemm_kernel<KS, S, CCH, BN, EXTRA, true>;        // grouped multi-instance form (dip_group.h)
     if (dip_once_per_device(attr_set)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        hipError_t e = dip_pair_lds_attr(kern, kern_g, C::LDS_BYTES);
         if (e != hipSuccess) { dip_set_error(hipGetErrorString(e)); return (int)e; }
     }
     const int ntx = dip_cdiv(d.Wout, C::TW), nty = dip_cdiv(d.Hout, C::TH);
     const int ntiles = ntx * nty;
     const int CoutP = dip_round_up(d.Cout, 32);
     dim3 grid(ntiles, grid_y, ksplit);
-    hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, st, d, ntx, ntiles, CoutP, n_base, ksplit, ws);
+    dip_launch_pair<DIP_FAM_CONV>(kern, kern_g, grid, dim3(256), C::LDS_BYTES, st, d, ntx, ntiles, CoutP, n_base, ksplit, ws);
     DIP_CHECK_LAUNCH();
     return 0;
 }
@@ -605,8 +611,8 @@ extern "C" int dip_conv_splitk_finish(const DipConvDesc* dp, void* stream) {
     if (d.ksplit <= 1 || d.ws == nullptr) DIP_FAIL("conv_splitk_finish: descriptor is not split-K");
     int nblk;
     const int ppb = finish_ppb(d.Hout * d.Wout, d.Cy, &nblk);
-    hipLaunchKernelGGL(splitk_finish_kernel, dim3(nblk), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), d.ws,
-                       d.ksplit, d, dip_round_up(d.Cout, 32), ppb);
+    dip_launch_pair<DIP_FAM_CONV>(splitk_finish_kernel<false>, splitk_finish_kernel<true>, dim3(nblk), dim3(256), 0,
+                                  reinterpret_cast<hipStream_t>(stream), (const float*)d.ws, d.ksplit, d, dip_round_up(d.Cout, 32), ppb);
     DIP_CHECK_LAUNCH();
     return 0;
 }

@@ -21,6 +21,7 @@
 #include "dip_common.h"
 #include "conv_epilogue.h"
 #include "lds_dma.h"
+#include "dip_group.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -94,10 +95,14 @@ __device__ unsigned g_trace[128 * 8];
 // filter over the sub-grid of that parity.  One workgroup walks the 4 sub-grids one after the other: K units =
 // (parity, channel chunk, sub-filter tap), 9 per chunk in total as for a stride-1 3x3, and each
 // (parity, chunk) pair has its own halo (gathered by the LDS-DMA with a pixel stride of 2).
-template <int KS, int BN, bool TR, int MODE = 0>
-__global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDesc d, const int ntx, const int ntiles,
+// GRP: grouped multi-instance launch (dip_group.h) -- gridDim.z = ksplit x instances, the descriptor shifted to this
+// workgroup's instance; GRP = false is the solo kernel, instruction for instruction what it was before the parameter existed.
+template <int KS, int BN, bool TR, int MODE = 0, bool GRP = false>
+__global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDesc d_, const int ntx, const int ntiles,
                                                                 const int CoutP, const int n_base, const int ksplit,
-                                                                float* __restrict__ ws) {
+                                                                float* __restrict__ ws_, const DipGrpArg<GRP> grp) {
+    DIP_GRP_DESC(DipConvDesc, d);
+    DIP_GRP_PTR(float*, ws);
     constexpr bool PH = (MODE == 1);
     constexpr bool SF = (MODE == 2);
     using C = DCfg<KS, BN, SF ? 4 : 1>;
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const DipConvDes
     const int nchunks = (d.Cin + CCH - 1) / CCH;
     const int last_cc = d.Cin - (nchunks - 1) * CCH;
     const int nunits = SF ? nchunks * d.ks * d.ks : nchunks * kkr;
-    const int z = blockIdx.z;
+    const int z = dip_grp_z<GRP>(grp);
     const int u0 = (int)(((long long)z * nunits) / ksplit);
     const int u1 = (int)(((long long)(z + 1) * nunits) / ksplit);
     // SF: units run parity-major: parity ph owns nchunks * taps(ph) consecutive units
@@ -676,8 +681,7 @@ int launch_tr(const DipConvDesc& d, hipStream_t st, int n_base, int grid_y, int 
     static bool attr_set[16] = {};
     auto kern = conv_igemm_dma_kernel<KS, BN, TR, MODE>;
     if (dip_once_per_device(attr_set)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        hipError_t e = dip_pair_lds_attr(kern, conv_igemm_dma_kernel<KS, BN, TR, MODE, true>, C::LDS_BYTES);
         if (e != hipSuccess) { dip_set_error(hipGetErrorString(e)); return (int)e; }
     }
     // phase mode tiles the (Hout+1)/2 x (Wout+1)/2 sub-grid of one parity, 4 workgroups per tile
@@ -685,7 +689,8 @@ int launch_tr(const DipConvDesc& d, hipStream_t st, int n_base, int grid_y, int 
     const int ntiles = ntx * nty;
     const int CoutP = dip_round_up(d.Cout, 32);
     dim3 grid(PH ? 4 * ntiles : ntiles, grid_y, ksplit);
-    hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, st, d, ntx, ntiles, CoutP, n_base, ksplit, ws);
+    dip_launch_pair<DIP_FAM_DMA>(kern, conv_igemm_dma_kernel<KS, BN, TR, MODE, true>, grid, dim3(256), C::LDS_BYTES, st, d, ntx, ntiles, CoutP, n_base,
+                                 ksplit, ws);
     DIP_CHECK_LAUNCH();
     return 0;
 }

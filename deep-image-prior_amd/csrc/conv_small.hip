@@ -26,6 +26,7 @@
 // Any stride-1/2 1x1 / 3x3 convolution or data gradient with reflection / zero / replication padding,
 // any activation, 1..160 output channels; the engine uses it below DIP_SMALL_MAX_PIXELS output pixels.
 #include "dip_common.h"
+#include "dip_group.h"
 #include <stdlib.h>
 
 namespace {
@@ -33,6 +34,8 @@ namespace {
 constexpr int SM_TR_MAX = 512;      // input channels whose BatchNorm coefficients are cached in LDS
 constexpr int SM_MAX_TAPS = 27;     // ring mode: up to 3 mirror sources x 9 taps per target pixel
 
+struct SmallGeom;
+template <class F> __host__ __device__ inline void dip_ptrs(SmallGeom&, F&) {}      // (dip_group.h: no pointers inside)
 struct SmallGeom {
     int ncls;                 // 1, or 4 output-parity classes (dil == 2: transposed stride-2 conv)
     int Hc[4], Wc[4];         // pixels of class c = (py, px): rows py, py+2, ..; columns px, px+2, ..
@@ -83,8 +86,9 @@ __device__ __forceinline__ void sm_wait(f32x4& a, f32x4& b) {
 
 // TR: 0 = no input transform, 1 = BatchNorm + LeakyReLU / identity (slope in (0, 1]), 2 = BatchNorm + Swish / ELU
 // One workgroup = one 32-pixel x 32-channel output tile; its NW waves split K and are summed through LDS.
-template <int TR, int NW, bool RING = false>
-__global__ __launch_bounds__(64 * NW) void conv_small_kernel(const DipConvDesc d, const SmallGeom g) {
+template <int TR, int NW, bool RING = false, bool GRP = false>
+__global__ __launch_bounds__(64 * NW) void conv_small_kernel(const DipConvDesc d_, const SmallGeom g, const DipGrpArg<GRP> grp) {
+    DIP_GRP_DESC(DipConvDesc, d);
     constexpr int SMAX = SmCfg<NW>::SMAX;
     constexpr int RPW = 16 / NW;                // accumulator registers a wave reduces across the K slices
     constexpr int NT = 64 * NW;
@@ -388,16 +392,14 @@ bool small_geom(const DipConvDesc& d, SmallGeom* g) {
 template <int TR, int NW, bool RING = false>
 int small_launch(const DipConvDesc& d, const SmallGeom& g, hipStream_t st) {
     auto kern = conv_small_kernel<TR, NW, RING>;
+    auto kern_g = conv_small_kernel<TR, NW, RING, true>;         // grouped multi-instance form (dip_group.h)
     constexpr int lds = NW * 16 * 64 * 4;
     static bool attr_set[16] = {};
-    int dev = 0;
-    hipGetDevice(&dev);
-    if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (dip_once_per_device(attr_set)) {
+        hipError_t e = dip_pair_lds_attr(kern, kern_g, lds);
         if (e != hipSuccess) { dip_set_error(hipGetErrorString(e)); return (int)e; }
-        attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(kern, dim3(g.ngroups, g.nblk), dim3(64 * NW), lds, st, d, g);
+    dip_launch_pair<DIP_FAM_SMALL>(kern, kern_g, dim3(g.ngroups, g.nblk), dim3(64 * NW), lds, st, d, g);
     DIP_CHECK_LAUNCH();
     return 0;
 }

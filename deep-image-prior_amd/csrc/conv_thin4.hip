@@ -16,6 +16,7 @@
 // read as broadcasts (through the scalar cache they missed on every group: 18 KB per workgroup walk
 // thrashes it, 85 us per workgroup instead of ~25).
 #include "dip_common.h"
+#include "dip_group.h"
 
 namespace {
 
@@ -28,8 +29,10 @@ __device__ __forceinline__ int t4_map_src(int v, int n_in, int reflect) {
     return (v < 0 || v >= n_in) ? -1 : v;
 }
 
-__global__ __launch_bounds__(256) void conv_thin4_kernel(const DipConvDesc d, const int ntx, const int CoutP,
-                                                        const int ncols) {
+template <bool GRP = false>
+__global__ __launch_bounds__(256) void conv_thin4_kernel(const DipConvDesc d_, const int ntx, const int CoutP,
+                                                        const int ncols, const DipGrpArg<GRP> grp) {
+    DIP_GRP_DESC(DipConvDesc, d);
     __shared__ __attribute__((aligned(16))) float halo[T4_NPIX * T4_PITCH];
     __shared__ int srcoff[T4_NPIX];
     __shared__ __attribute__((aligned(16))) float wsh[9 * 8 * 16];           // [tap][c4][n][c%4] of the current chunk
@@ -164,7 +167,8 @@ extern "C" int dip_conv_thin4(const DipConvDesc* dp, int ncols, void* stream) {
     if (d.bnb_y != nullptr && (d.bnb_partials_thin == nullptr || (d.bnb_Cy & 3) || (d.bnb_Cs & 3)))
         DIP_FAIL("conv_thin4: fused BatchNorm-backward partials need bnb_partials_thin and 4-aligned strides");
     const int ntx = dip_cdiv(d.Wout, T4_TW), nty = dip_cdiv(d.Hout, T4_TH);
-    hipLaunchKernelGGL(conv_thin4_kernel, dim3(ntx * nty), dim3(256), 0, st, d, ntx, dip_round_up(d.Cout, 32), ncols);
+    dip_launch_pair<DIP_FAM_THIN>(conv_thin4_kernel<false>, conv_thin4_kernel<true>, dim3(ntx * nty), dim3(256), 0, st, d, ntx,
+                                  dip_round_up(d.Cout, 32), ncols);
     DIP_CHECK_LAUNCH();
     return 0;
 }

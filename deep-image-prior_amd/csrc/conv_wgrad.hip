@@ -12,6 +12,7 @@
 // Each workgroup finally writes ONE partial slab; dip_wgrad_reduce sums the slabs in a fixed
 // order (deterministic, no float atomics) straight into the OIHW gradient arena.
 #include "dip_common.h"
+#include "dip_group.h"
 #include <stdlib.h>
 
 namespace {
@@ -39,10 +40,11 @@ __device__ __forceinline__ int wmap_src(int v, int n_in, int pad_mode) {
     return (v < 0 || v >= n_in) ? -1 : v;
 }
 
-template <int KS, int S, int NT, int CB, bool SLIDE = false>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d, const int ntx, const int ntiles,
+template <int KS, int S, int NT, int CB, bool SLIDE = false, bool GRP = false>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d_, const int ntx, const int ntiles,
                                                             const int CinP, const int CoutP, const int ragged_parts,
-                                                            const int kw, const int phase2_only) {
+                                                            const int kw, const int phase2_only, const DipGrpArg<GRP> grp) {
+    DIP_GRP_DESC(DipWgradDesc, d);
     using C = WCfg<KS, S, NT, CB>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Us = smem;
@@ -65,8 +67,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const DipWgradDesc d
     // and the slots go to the full chunks, instead of forming a lonely last round behind them.
     // (With ragged_parts > 0 there are no tail workgroups at all: see phase 2 below.)
     const int cchunk = ragged_parts > 0 ? (int)blockIdx.y : (int)((blockIdx.y + gridDim.y - 1) % gridDim.y);
-    const int group = blockIdx.z % C::NGROUPS;     // tap group
-    const int nblk = blockIdx.z / C::NGROUPS;      // 128 output channels
+    const int group = dip_grp_z<GRP>(grp) % C::NGROUPS;     // tap group
+    const int nblk = dip_grp_z<GRP>(grp) / C::NGROUPS;      // 128 output channels
     const int tap0 = group * NT;
     int c0 = cchunk * C::CW;
     const int o0 = nblk * 128;
@@ -427,9 +429,9 @@ int launch(const DipWgradDesc& d, hipStream_t st, int CinP_slab = 0) {
     using C = WCfg<KS, S, NT, CB>;
     static bool attr_set[16] = {};
     auto kern = conv_wgrad_kernel<KS, S, NT, CB, SLIDE>;
+    auto kern_g = conv_wgrad_kernel<KS, S, NT, CB, SLIDE, true>;         // grouped multi-instance form (dip_group.h)
     if (dip_once_per_device(attr_set)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        hipError_t e = dip_pair_lds_attr(kern, kern_g, C::LDS_BYTES);
         if (e != hipSuccess) { dip_set_error(hipGetErrorString(e)); return (int)e; }
     }
     const int ntx = dip_cdiv(d.Wout, C::TW), nty = dip_cdiv(d.Hout, C::TH);
@@ -452,8 +454,8 @@ int launch(const DipWgradDesc& d, hipStream_t st, int CinP_slab = 0) {
         return launch<KS, S, NT, CB, false>(d, st, CinP_slab);      // a packed tail chunk in phase 1: the one-loop kernel
     dim3 grid(d.nsplit / kw, ragged_parts > 0 ? ragged_parts : dip_cdiv(CinP, C::CW), C::NGROUPS * dip_cdiv(CoutP, 128));
     // CinP_slab: row count of the slabs when this launch covers only the leading channels of the layer
-    hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, st, d, ntx, ntiles, CinP_slab > 0 ? CinP_slab : CinP, CoutP,
-                       ragged_parts, kw, 0);
+    dip_launch_pair<DIP_FAM_WGRAD>(kern, kern_g, grid, dim3(256), C::LDS_BYTES, st, d, ntx, ntiles, CinP_slab > 0 ? CinP_slab : CinP, CoutP,
+                                   ragged_parts, kw, 0);
     DIP_CHECK_LAUNCH();
     return 0;
 }
@@ -464,20 +466,18 @@ int launch_tail(const DipWgradDesc& d, hipStream_t st) {
     using C = WCfg<3, 1, 9, 1>;
     static bool attr_set[16] = {};
     auto kern = conv_wgrad_kernel<3, 1, 9, 1, true>;
-    int dev = 0;
-    hipGetDevice(&dev);
-    if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    auto kern_g = conv_wgrad_kernel<3, 1, 9, 1, true, true>;
+    if (dip_once_per_device(attr_set)) {
+        hipError_t e = dip_pair_lds_attr(kern, kern_g, C::LDS_BYTES);
         if (e != hipSuccess) { dip_set_error(hipGetErrorString(e)); return (int)e; }
-        attr_set[dev] = true;
     }
     const int ntx = dip_cdiv(d.Wout, C::TW), nty = dip_cdiv(d.Hout, C::TH);
     const int CinP = dip_round_up(d.Cin, 32), CoutP = dip_round_up(d.Cout, 32);
     const int tail = d.Cin & 31, nfull = d.Cin >> 5;
     if (!(tail >= 1 && tail <= 4 && nfull >= 1 && nfull <= 8)) DIP_FAIL("conv_wgrad_tail: needs 1..8 full 32-channel chunks + a 1..4-channel tail");
     if (d.nsplit < 1 || d.nsplit > ntx * nty) DIP_FAIL("conv_wgrad_tail: nsplit out of range");
-    hipLaunchKernelGGL(kern, dim3(d.nsplit, nfull, dip_cdiv(CoutP, 128)), dim3(256), C::LDS_BYTES, st, d, ntx, ntx * nty, CinP, CoutP,
-                       nfull, 1, 1);
+    dip_launch_pair<DIP_FAM_WGRAD>(kern, kern_g, dim3(d.nsplit, nfull, dip_cdiv(CoutP, 128)), dim3(256), C::LDS_BYTES, st, d, ntx, ntx * nty, CinP,
+                                   CoutP, nfull, 1, 1);
     DIP_CHECK_LAUNCH();
     return 0;
 }
@@ -488,9 +488,10 @@ int launch_tail(const DipWgradDesc& d, hipStream_t st) {
 // output channels, walks its pixels, and the block tree-reduces over prow.  One slab per block,
 // same layout as the MFMA kernel's slabs, so dip_wgrad_reduce finishes it.
 // ------------------------------------------------------------------------------------------
-template <int NO>
-__global__ __launch_bounds__(256) void thin1x1_wgrad_kernel(const DipWgradDesc d, const int CinP, const int CoutP,
-                                                            const int ppb) {
+template <int NO, bool GRP = false>
+__global__ __launch_bounds__(256) void thin1x1_wgrad_kernel(const DipWgradDesc d_, const int CinP, const int CoutP,
+                                                            const int ppb, const DipGrpArg<GRP> grp) {
+    DIP_GRP_DESC(DipWgradDesc, d);
     constexpr int W = NO * 4 + NO;                  // per-thread accumulators: dW[o][4] + dbias[o]
     extern __shared__ __attribute__((aligned(16))) float sh[];
     const int nc4 = (d.Cin + 3) >> 2;
@@ -579,9 +580,10 @@ __global__ __launch_bounds__(256) void thin1x1_wgrad_kernel(const DipWgradDesc d
 // pixels (dy once, KS neighbouring x pixels of 16 bytes each), then the block tree-reduces over prow, one filter
 // column at a time, into one slab per block -- same slab layout as the MFMA kernel, dip_wgrad_reduce finishes it.
 // ------------------------------------------------------------------------------------------
-template <int KS>
-__global__ __launch_bounds__(256) void thin_cin_wgrad_kernel(const DipWgradDesc d, const int CinP, const int CoutP,
-                                                             const int ppb) {
+template <int KS, bool GRP = false>
+__global__ __launch_bounds__(256) void thin_cin_wgrad_kernel(const DipWgradDesc d_, const int CinP, const int CoutP,
+                                                             const int ppb, const DipGrpArg<GRP> grp) {
+    DIP_GRP_DESC(DipWgradDesc, d);
     __shared__ __attribute__((aligned(16))) float sh[256 * 16];
     const int nog = (d.Cout + 3) >> 2;                   // groups of 4 output channels (<= 64)
     const int rpi = 256 / nog;
@@ -713,10 +715,15 @@ bool is_thin(int ks, int Cin, int Cout) { return ks == 1 && Cout <= 8 && Cin <= 
 
 // block = 8 split-lanes x 32 consecutive outputs (o fastest -> 128-B coalesced slab reads); each
 // split-lane sums slabs sl, sl+8, ... then the 8 partials are added in a fixed order.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial,
-                                                           const float* __restrict__ bias_partial, int nsplit, int KK,
-                                                           int Cin, int Cout, int CinP, int CoutP, float* dw,
-                                                           float* dbias) {
+template <bool GRP = false>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial_,
+                                                           const float* __restrict__ bias_partial_, int nsplit, int KK,
+                                                           int Cin, int Cout, int CinP, int CoutP, float* dw_,
+                                                           float* dbias_, const DipGrpArg<GRP> grp) {
+    DIP_GRP_PTR(const float*, partial);
+    DIP_GRP_PTR(const float*, bias_partial);
+    DIP_GRP_PTR(float*, dw);
+    DIP_GRP_PTR(float*, dbias);
     __shared__ float sh[8][32];
     const int oi = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const int id = blockIdx.x * 32 + oi;
@@ -870,9 +877,11 @@ extern "C" int dip_conv_wgrad(const DipWgradDesc* dp, void* stream) {
         if (nblk != d.nsplit) DIP_FAIL("conv_wgrad: thin 1x1 path needs nsplit from dip_wgrad_plan");
         const int CinP = dip_round_up(d.Cin, 32), CoutP = dip_round_up(d.Cout, 32);
         if (d.Cout <= 4) {
-            hipLaunchKernelGGL(thin1x1_wgrad_kernel<4>, dim3(nblk), dim3(256), 256 * 20 * 4, st, d, CinP, CoutP, ppb);
+            dip_launch_pair<DIP_FAM_THIN>(thin1x1_wgrad_kernel<4>, thin1x1_wgrad_kernel<4, true>, dim3(nblk), dim3(256), 256 * 20 * 4, st, d, CinP,
+                                          CoutP, ppb);
         } else {
-            hipLaunchKernelGGL(thin1x1_wgrad_kernel<8>, dim3(nblk), dim3(256), 256 * 40 * 4, st, d, CinP, CoutP, ppb);
+            dip_launch_pair<DIP_FAM_THIN>(thin1x1_wgrad_kernel<8>, thin1x1_wgrad_kernel<8, true>, dim3(nblk), dim3(256), 256 * 40 * 4, st, d, CinP,
+                                          CoutP, ppb);
         }
         DIP_CHECK_LAUNCH();
         return 0;
@@ -884,9 +893,9 @@ extern "C" int dip_conv_wgrad(const DipWgradDesc* dp, void* stream) {
         if (d.Cx < 4) DIP_FAIL("conv_wgrad: channel stride of x must be >= 4");
         const int CinP = dip_round_up(d.Cin, 32), CoutP = dip_round_up(d.Cout, 32);
         const dim3 grid(nblk, d.ks);
-        if (d.ks == 3) hipLaunchKernelGGL(thin_cin_wgrad_kernel<3>, grid, dim3(256), 0, st, d, CinP, CoutP, ppb);
-        else if (d.ks == 5) hipLaunchKernelGGL(thin_cin_wgrad_kernel<5>, grid, dim3(256), 0, st, d, CinP, CoutP, ppb);
-        else hipLaunchKernelGGL(thin_cin_wgrad_kernel<7>, grid, dim3(256), 0, st, d, CinP, CoutP, ppb);
+        if (d.ks == 3) dip_launch_pair<DIP_FAM_THIN>(thin_cin_wgrad_kernel<3>, thin_cin_wgrad_kernel<3, true>, grid, dim3(256), 0, st, d, CinP, CoutP, ppb);
+        else if (d.ks == 5) dip_launch_pair<DIP_FAM_THIN>(thin_cin_wgrad_kernel<5>, thin_cin_wgrad_kernel<5, true>, grid, dim3(256), 0, st, d, CinP, CoutP, ppb);
+        else dip_launch_pair<DIP_FAM_THIN>(thin_cin_wgrad_kernel<7>, thin_cin_wgrad_kernel<7, true>, grid, dim3(256), 0, st, d, CinP, CoutP, ppb);
         DIP_CHECK_LAUNCH();
         return 0;
     }
@@ -917,8 +926,8 @@ extern "C" int dip_wgrad_reduce(const float* partial, const float* bias_partial,
     const int KK = ks * ks;
     const int CinP = dip_round_up(Cin, 32), CoutP = dip_round_up(Cout, 32);
     const int total = KK * Cin * Cout + (dbias ? Cout : 0);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dip_cdiv(total, 32)), dim3(256), 0, st, partial,
-                       dbias ? bias_partial : nullptr, nsplit, KK, Cin, Cout, CinP, CoutP, dw, dbias);
+    dip_launch_pair<DIP_FAM_WGRAD>(wgrad_reduce_kernel<false>, wgrad_reduce_kernel<true>, dim3(dip_cdiv(total, 32)), dim3(256), 0, st, partial,
+                                   dbias ? bias_partial : (const float*)nullptr, nsplit, KK, Cin, Cout, CinP, CoutP, dw, dbias);
     DIP_CHECK_LAUNCH();
     return 0;
 }

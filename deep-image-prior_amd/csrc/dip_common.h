@@ -12,6 +12,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define DIP_WAVE 64
 
 extern "C" void dip_set_error(const char* msg);
+// grouped execution (dip_group.h): 1 when a launch since the last call refused to run (a pointer outside the slab, ...);
+// the message is in dip_last_error()
+extern "C" int dip_group_take_fault(void);
 
 #define DIP_CHECK_LAUNCH()                                   \
     do {                                                     \
@@ -20,6 +23,7 @@ extern "C" void dip_set_error(const char* msg);
             dip_set_error(hipGetErrorString(e__));           \
             return (int)e__;                                 \
         }                                                    \
+        if (dip_group_take_fault()) return -1;               \
     } while (0)
 
 #define DIP_FAIL(msg)          \

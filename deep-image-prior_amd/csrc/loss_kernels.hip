@@ -11,6 +11,7 @@
 //    the Philox offset live in device memory, so one optimisation iteration is a STATIC launch list
 //    and can be replayed as a hipGraph (nothing changes on the host between iterations).
 #include "dip_common.h"
+#include "dip_group.h"
 #include <stdlib.h>
 
 namespace {
@@ -23,7 +24,9 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-
 // so after Cin K steps every lane holds the 4 outputs of its own pixel: no cross-lane reduction for the
 // conv, NCHW stores / target / mask loads are coalesced across the lanes, and the only reduction left
 // is the scalar loss: per-lane sums -> LDS tree -> one partial per block -> loss_reduce_kernel.
-__global__ __launch_bounds__(256) void loss_head_fwd_kernel(const DipLossHeadDesc d, const int ppb) {
+template <bool GRP = false>
+__global__ __launch_bounds__(256) void loss_head_fwd_kernel(const DipLossHeadDesc d_, const int ppb, const DipGrpArg<GRP> grp) {
+    DIP_GRP_DESC(DipLossHeadDesc, d);
     __shared__ float red[256];
     const int tid = threadIdx.x;
     const int oi = tid & 3;                                    // A row of this lane (only lanes 0..3 of a wave are read)
@@ -97,8 +100,9 @@ __global__ __launch_bounds__(256) void loss_head_fwd_kernel(const DipLossHeadDes
 // = one contiguous run per load instruction (the lane-per-pixel kernel above strides 4*Cu bytes between lanes and
 // ran at 1.8 TB/s) -- computes its 4 x Cout partial products, and an xor-butterfly over the NC4 lanes (fixed order)
 // leaves the sums in every lane; lane o of the group finishes output channel o.
-template <int NC4>
-__global__ __launch_bounds__(256) void loss_head_fwd_coal_kernel(const DipLossHeadDesc d, const int ppb) {
+template <int NC4, bool GRP = false>
+__global__ __launch_bounds__(256) void loss_head_fwd_coal_kernel(const DipLossHeadDesc d_, const int ppb, const DipGrpArg<GRP> grp) {
+    DIP_GRP_DESC(DipLossHeadDesc, d);
     __shared__ float red[256];
     constexpr int PW = 64 / NC4;                 // pixels per wave and step
     constexpr int PB = 4 * PW;                   // ... per block and step
@@ -176,8 +180,11 @@ __global__ __launch_bounds__(256) void loss_head_fwd_coal_kernel(const DipLossHe
 // "last-arriving block" ticket needs an agent-scope release fence in EVERY block, which on the multi-XCD
 // MI355X writes back / invalidates L2 each time (the ticketed version of this head took 110 us instead
 // of ~35: DESIGN.md, dead ends).
-__global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restrict__ partials, int n, double scale,
-                                                          float* __restrict__ loss) {
+template <bool GRP = false>
+__global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restrict__ partials_, int n, double scale,
+                                                          float* __restrict__ loss_, const DipGrpArg<GRP> grp) {
+    DIP_GRP_PTR(const float*, partials);
+    DIP_GRP_PTR(float*, loss);
     __shared__ double dred[256];
     const int tid = threadIdx.x;
     double s = 0.0;
@@ -192,8 +199,12 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restric
 }
 
 // dy[p][o] = gscale * 2/N * (out*m - t*m) * m * out*(1-out)       (NHWC, channel stride Cy; pad channels zero)
-__global__ __launch_bounds__(256) void loss_head_bwd_kernel(const DipLossHeadDesc d, const float* __restrict__ gscale,
-                                                            float* __restrict__ dy, const int Cy) {
+template <bool GRP = false>
+__global__ __launch_bounds__(256) void loss_head_bwd_kernel(const DipLossHeadDesc d_, const float* __restrict__ gscale_,
+                                                            float* __restrict__ dy_, const int Cy, const DipGrpArg<GRP> grp) {
+    DIP_GRP_DESC(DipLossHeadDesc, d);
+    DIP_GRP_PTR(const float*, gscale);
+    DIP_GRP_PTR(float*, dy);
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= d.HW) return;
     const float gs = gscale != nullptr ? *gscale : 1.f;
@@ -223,7 +234,9 @@ __global__ __launch_bounds__(256) void loss_head_bwd_kernel(const DipLossHeadDes
 }
 
 // ---------------------------------------------------------------- device-side iteration state
-__global__ void adam_tick_kernel(DipIterState* st, double lr, double beta1, double beta2) {
+template <bool GRP = false>
+__global__  void adam_tick_kernel(DipIterState* st_, double lr, double beta1, double beta2, const DipGrpArg<GRP> grp) {
+    DIP_GRP_PTR(DipIterState*, st);
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const unsigned long long step = st->step + 1ull;
     st->step = step;
@@ -234,7 +247,9 @@ __global__ void adam_tick_kernel(DipIterState* st, double lr, double beta1, doub
     st->bc2_sqrt = (float)sqrt(bc2);
 }
 
-__global__ void counter_add_kernel(unsigned long long* c, unsigned long long inc) {
+template <bool GRP = false>
+__global__  void counter_add_kernel(unsigned long long* c_, unsigned long long inc, const DipGrpArg<GRP> grp) {
+    DIP_GRP_PTR(unsigned long long*, c);
     if (threadIdx.x == 0 && blockIdx.x == 0) *c += inc;
 }
 
@@ -264,18 +279,18 @@ extern "C" int dip_loss_head_fwd(const DipLossHeadDesc* dp, void* stream) {
     static const bool no_coal = getenv("DIP_LOSS_HEAD_NO_COAL") != nullptr;
     hipStream_t st = (hipStream_t)stream;
     if (no_coal || nc4 > 32 || (nc4 & (nc4 - 1)) != 0 || (NC4_MIN_CHECK(d.Cout, nc4))) {
-        hipLaunchKernelGGL(loss_head_fwd_kernel, dim3(nblk), dim3(256), 0, st, d, ppb);
+        dip_launch_pair<DIP_FAM_LOSS>(loss_head_fwd_kernel<false>, loss_head_fwd_kernel<true>, dim3(nblk), dim3(256), 0, st, d, ppb);
     } else {
         switch (nc4) {
-            case 32: hipLaunchKernelGGL(loss_head_fwd_coal_kernel<32>, dim3(nblk), dim3(256), 0, st, d, ppb); break;
-            case 16: hipLaunchKernelGGL(loss_head_fwd_coal_kernel<16>, dim3(nblk), dim3(256), 0, st, d, ppb); break;
-            case 8: hipLaunchKernelGGL(loss_head_fwd_coal_kernel<8>, dim3(nblk), dim3(256), 0, st, d, ppb); break;
-            default: hipLaunchKernelGGL(loss_head_fwd_coal_kernel<4>, dim3(nblk), dim3(256), 0, st, d, ppb); break;
+            case 32: dip_launch_pair<DIP_FAM_LOSS>(loss_head_fwd_coal_kernel<32>, loss_head_fwd_coal_kernel<32, true>, dim3(nblk), dim3(256), 0, st, d, ppb); break;
+            case 16: dip_launch_pair<DIP_FAM_LOSS>(loss_head_fwd_coal_kernel<16>, loss_head_fwd_coal_kernel<16, true>, dim3(nblk), dim3(256), 0, st, d, ppb); break;
+            case 8: dip_launch_pair<DIP_FAM_LOSS>(loss_head_fwd_coal_kernel<8>, loss_head_fwd_coal_kernel<8, true>, dim3(nblk), dim3(256), 0, st, d, ppb); break;
+            default: dip_launch_pair<DIP_FAM_LOSS>(loss_head_fwd_coal_kernel<4>, loss_head_fwd_coal_kernel<4, true>, dim3(nblk), dim3(256), 0, st, d, ppb); break;
         }
     }
     DIP_CHECK_LAUNCH();
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, d.partials, nblk,
-                       1.0 / ((double)d.Cout * (double)d.HW), d.loss);
+    dip_launch_pair<DIP_FAM_LOSS>(loss_reduce_kernel<false>, loss_reduce_kernel<true>, dim3(1), dim3(256), 0, (hipStream_t)stream,
+                                  (const float*)d.partials, nblk, 1.0 / ((double)d.Cout * (double)d.HW), d.loss);
     DIP_CHECK_LAUNCH();
     return 0;
 }
@@ -283,21 +298,21 @@ extern "C" int dip_loss_head_fwd(const DipLossHeadDesc* dp, void* stream) {
 extern "C" int dip_loss_head_bwd(const DipLossHeadDesc* dp, const float* gscale, float* dy, int Cy, void* stream) {
     const DipLossHeadDesc& d = *dp;
     if (d.Cout < 1 || d.Cout > 4 || (Cy & 3) || Cy < d.Cout) DIP_FAIL("loss_head_bwd: bad channel counts");
-    hipLaunchKernelGGL(loss_head_bwd_kernel, dim3(dip_cdiv(d.HW, 256)), dim3(256), 0, (hipStream_t)stream, d, gscale,
-                       dy, Cy);
+    dip_launch_pair<DIP_FAM_LOSS>(loss_head_bwd_kernel<false>, loss_head_bwd_kernel<true>, dim3(dip_cdiv(d.HW, 256)), dim3(256), 0, (hipStream_t)stream,
+                                  d, gscale, dy, Cy);
     DIP_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int dip_adam_tick(DipIterState* st, double lr, double beta1, double beta2, void* stream) {
-    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, st, lr, beta1, beta2);
+    dip_launch_pair<DIP_FAM_LOSS>(adam_tick_kernel<false>, adam_tick_kernel<true>, dim3(1), dim3(1), 0, (hipStream_t)stream, st, lr, beta1, beta2);
     DIP_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int dip_counter_add(uint64_t* counter, uint64_t inc, void* stream) {
-    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream,
-                       reinterpret_cast<unsigned long long*>(counter), (unsigned long long)inc);
+    dip_launch_pair<DIP_FAM_LOSS>(counter_add_kernel<false>, counter_add_kernel<true>, dim3(1), dim3(1), 0, (hipStream_t)stream,
+                                  reinterpret_cast<unsigned long long*>(counter), (unsigned long long)inc);
     DIP_CHECK_LAUNCH();
     return 0;
 }

@@ -1,13 +1,17 @@
 // Boundary layout conversion, sigmoid head, weight repacking, fused Adam, Philox reg-noise and
 // the depth-wise Lanczos down-sampler.  All HBM/latency-bound helpers around the MFMA kernels.
 #include "dip_common.h"
+#include "dip_group.h"
 
 namespace {
 
 // ---------------------------------------------------------------- layout / head
 // tile transpose through LDS so both sides are coalesced: block handles 64 pixels x all channels
-__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst,
-                                                           int C, int HW, int Cs) {
+template <bool GRP = false>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src_, float* __restrict__ dst_,
+                                                           int C, int HW, int Cs, const DipGrpArg<GRP> grp) {
+    DIP_GRP_PTR(const float*, src);
+    DIP_GRP_PTR(float*, dst);
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= HW) return;
     // C is small at this boundary (<= 32 for every reference config); each lane walks the
@@ -24,8 +28,11 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
 // <= 32 channels (every notebook's net_input): transpose through LDS so that BOTH sides are coalesced -- the planes are
 // read 256 pixels at a time, the [256 pixels][Cs] block leaves as one contiguous run of 16-byte stores (the per-lane
 // walk above scatters its stores over 64 cache lines per instruction: 33 us for the 32 x 512^2 input, 2 TB/s)
-__global__ __launch_bounds__(256) void nchw_to_nhwc_lds_kernel(const float* __restrict__ src, float* __restrict__ dst,
-                                                               int C, int HW, int Cs) {
+template <bool GRP = false>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_lds_kernel(const float* __restrict__ src_, float* __restrict__ dst_,
+                                                               int C, int HW, int Cs, const DipGrpArg<GRP> grp) {
+    DIP_GRP_PTR(const float*, src);
+    DIP_GRP_PTR(float*, dst);
     __shared__ float t[256][33];
     const int p0 = blockIdx.x * 256, tid = threadIdx.x;
     const int np = min(256, HW - p0);
@@ -95,8 +102,12 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 }
 
 // ---------------------------------------------------------------- weight repack (one launch, all convs)
-__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ params, float* __restrict__ packed,
-                                                           const DipPackRec* __restrict__ recs) {
+template <bool GRP = false>
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ params_, float* __restrict__ packed_,
+                                                           const DipPackRec* __restrict__ recs_, const DipGrpArg<GRP> grp) {
+    DIP_GRP_PTR(const float*, params);
+    DIP_GRP_PTR(float*, packed);
+    DIP_GRP_PTR(const DipPackRec*, recs);
     const DipPackRec r = recs[blockIdx.y];
     const int KK = r.KS * r.KS;
     const int nf = KK * r.CinP4 * r.CoutP32;
@@ -138,11 +149,16 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
 //   p.addcdiv_(m, denom, -step_size)       -> p + ((-step_size)*m)/denom
 // __fmul_rn / __fadd_rn / __fdiv_rn keep hipcc from contracting them into other FMAs.
 // DEV: step_size / bc2_sqrt come from the DipIterState in device memory (graph-replayable).
-template <bool DEV>
-__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
-                                                   float* __restrict__ m, float* __restrict__ v, int64_t n, float w1,
+template <bool DEV, bool GRP = false>
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p_, const float* __restrict__ g_,
+                                                   float* __restrict__ m_, float* __restrict__ v_, int64_t n, float w1,
                                                    float beta2, float omb2, float step_size, float bc2_sqrt,
-                                                   float eps, const DipIterState* __restrict__ st) {
+                                                   float eps, const DipIterState* __restrict__ st_, const DipGrpArg<GRP> grp) {
+    DIP_GRP_PTR(float*, p);
+    DIP_GRP_PTR(const float*, g);
+    DIP_GRP_PTR(float*, m);
+    DIP_GRP_PTR(float*, v);
+    DIP_GRP_PTR(const DipIterState*, st);
     if constexpr (DEV) {
         step_size = st->step_size;
         bc2_sqrt = st->bc2_sqrt;
@@ -170,10 +186,16 @@ __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2])
     k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
 }
 
-__global__ __launch_bounds__(256) void noise_axpy_kernel(const float* __restrict__ z, float* __restrict__ out,
+// SEED_DEV: the seed, too, lives in device memory (offset_dev[1]): grouped fits with one stream per instance
+template <bool GRP = false, bool SEED_DEV = false>
+__global__ __launch_bounds__(256) void noise_axpy_kernel(const float* __restrict__ z_, float* __restrict__ out_,
                                                          int64_t n, float sigma, uint64_t seed, uint64_t offset,
-                                                         const uint64_t* __restrict__ offset_dev) {
+                                                         const uint64_t* __restrict__ offset_dev_, const DipGrpArg<GRP> grp) {
+    DIP_GRP_PTR(const float*, z);
+    DIP_GRP_PTR(float*, out);
+    DIP_GRP_PTR(const uint64_t*, offset_dev);
     if (offset_dev != nullptr) offset = *offset_dev;              // device-side stream position (graph replay)
+    if constexpr (SEED_DEV) seed = offset_dev[1];
     const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;   // one Philox block = 4 normals
     const int64_t i0 = q * 4;
     if (i0 >= n) return;
@@ -360,32 +382,29 @@ __global__ __launch_bounds__(256) void down_dense_bwd_weight_kernel(const float*
 
 extern "C" int dip_nchw_to_nhwc(const float* src, float* dst, int C, int HW, int Cs, void* stream) {
     if (Cs <= 32 && (Cs & 3) == 0 && C <= Cs) {
-        hipLaunchKernelGGL(nchw_to_nhwc_lds_kernel, dim3(dip_cdiv(HW, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, C,
-                           HW, Cs);
+        dip_launch_pair<DIP_FAM_MISC>(nchw_to_nhwc_lds_kernel<false>, nchw_to_nhwc_lds_kernel<true>, dim3(dip_cdiv(HW, 256)), dim3(256), 0,
+                                      (hipStream_t)stream, src, dst, C, HW, Cs);
         DIP_CHECK_LAUNCH();
         return 0;
     }
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(dip_cdiv(HW, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, C,
-                       HW, Cs);
+    dip_launch_pair<DIP_FAM_MISC>(nchw_to_nhwc_kernel<false>, nchw_to_nhwc_kernel<true>, dim3(dip_cdiv(HW, 256)), dim3(256), 0, (hipStream_t)stream,
+                                  src, dst, C, HW, Cs);
     DIP_CHECK_LAUNCH();
     return 0;
 }
 extern "C" int dip_nhwc_to_nchw(const float* src, float* dst, int C, int HW, int Cs, int accumulate, void* stream) {
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(dip_cdiv(HW, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, C,
-                       HW, Cs, accumulate);
+    dip_launch(nhwc_to_nchw_kernel, dim3(dip_cdiv(HW, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, C, HW, Cs, accumulate);
     DIP_CHECK_LAUNCH();
     return 0;
 }
 extern "C" int dip_head_fwd(const float* y, float* out, int C, int HW, int Cs, int sigmoid, void* stream) {
-    hipLaunchKernelGGL(head_fwd_kernel, dim3(dip_cdiv(HW, 256)), dim3(256), 0, (hipStream_t)stream, y, out, C, HW, Cs,
-                       sigmoid);
+    dip_launch(head_fwd_kernel, dim3(dip_cdiv(HW, 256)), dim3(256), 0, (hipStream_t)stream, y, out, C, HW, Cs, sigmoid);
     DIP_CHECK_LAUNCH();
     return 0;
 }
 extern "C" int dip_head_bwd(const float* gout, const float* out, float* dy, int C, int HW, int Cs, int sigmoid,
                             void* stream) {
-    hipLaunchKernelGGL(head_bwd_kernel, dim3(dip_cdiv(HW, 256)), dim3(256), 0, (hipStream_t)stream, gout, out, dy, C,
-                       HW, Cs, sigmoid);
+    dip_launch(head_bwd_kernel, dim3(dip_cdiv(HW, 256)), dim3(256), 0, (hipStream_t)stream, gout, out, dy, C, HW, Cs, sigmoid);
     DIP_CHECK_LAUNCH();
     return 0;
 }
@@ -396,8 +415,8 @@ extern "C" int dip_pack_weights(const float* params, float* packed, const DipPac
     int gx = dip_cdiv(max_elems, 256 * 4);
     if (gx < 1) gx = 1;
     if (gx > 256) gx = 256;
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(gx, nrec), dim3(256), 0, (hipStream_t)stream, params, packed,
-                       recs_dev);
+    dip_launch_pair<DIP_FAM_MISC>(pack_weights_kernel<false>, pack_weights_kernel<true>, dim3(gx, nrec), dim3(256), 0, (hipStream_t)stream, params,
+                                  packed, recs_dev);
     DIP_CHECK_LAUNCH();
     return 0;
 }
@@ -412,9 +431,9 @@ extern "C" int dip_adam_step(float* p, const float* g, float* m, float* v, int64
     const double bc2_sqrt = sqrt(bc2);
     int64_t blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(adam_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
-                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)step_size, (float)bc2_sqrt,
-                       (float)eps, (const DipIterState*)nullptr);
+    dip_launch_pair<DIP_FAM_LOSS>(adam_kernel<false>, adam_kernel<false, true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
+                                  n, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)step_size, (float)bc2_sqrt, (float)eps,
+                                  (const DipIterState*)nullptr);
     DIP_CHECK_LAUNCH();
     return 0;
 }
@@ -426,8 +445,8 @@ extern "C" int dip_adam_step_dev(float* p, const float* g, float* m, float* v, i
     if (st == nullptr) DIP_FAIL("adam_step_dev: iteration state is NULL");
     int64_t blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(adam_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
-                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), 0.f, 1.f, (float)eps, st);
+    dip_launch_pair<DIP_FAM_LOSS>(adam_kernel<true>, adam_kernel<true, true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
+                                  (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), 0.f, 1.f, (float)eps, st);
     DIP_CHECK_LAUNCH();
     return 0;
 }
@@ -436,8 +455,8 @@ extern "C" int dip_noise_axpy(const float* z, float* out, int64_t n, float sigma
                               void* stream) {
     if (n <= 0) return 0;
     const int64_t quads = (n + 3) / 4;
-    hipLaunchKernelGGL(noise_axpy_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, z,
-                       out, n, sigma, seed, offset, (const uint64_t*)nullptr);
+    dip_launch_pair<DIP_FAM_LOSS>(noise_axpy_kernel<false>, noise_axpy_kernel<true>, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0,
+                                  (hipStream_t)stream, z, out, n, sigma, seed, offset, (const uint64_t*)nullptr);
     DIP_CHECK_LAUNCH();
     return 0;
 }
@@ -449,16 +468,28 @@ extern "C" int dip_noise_axpy_dev(const float* z, float* out, int64_t n, float s
     if (n <= 0) return 0;
     if (offset_dev == nullptr) DIP_FAIL("noise_axpy_dev: offset pointer is NULL");
     const int64_t quads = (n + 3) / 4;
-    hipLaunchKernelGGL(noise_axpy_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, z,
-                       out, n, sigma, seed, (uint64_t)0, (const uint64_t*)offset_dev);
+    dip_launch_pair<DIP_FAM_LOSS>(noise_axpy_kernel<false>, noise_axpy_kernel<true>, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0,
+                                  (hipStream_t)stream, z, out, n, sigma, seed, (uint64_t)0, (const uint64_t*)offset_dev);
     DIP_CHECK_LAUNCH();
     return dip_counter_add(offset_dev, (uint64_t)quads, stream);
+}
+
+// the same with the seed in device memory next to the offset: state_dev = {offset, seed}.  Grouped fits (dip_group_begin)
+// give every instance a stream of its own this way -- a by-value seed would be shared by all of them.
+extern "C" int dip_noise_axpy_dev2(const float* z, float* out, int64_t n, float sigma, uint64_t* state_dev, void* stream) {
+    if (n <= 0) return 0;
+    if (state_dev == nullptr) DIP_FAIL("noise_axpy_dev2: state pointer is NULL");
+    const int64_t quads = (n + 3) / 4;
+    dip_launch_pair<DIP_FAM_LOSS>(noise_axpy_kernel<false, true>, noise_axpy_kernel<true, true>, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0,
+                                  (hipStream_t)stream, z, out, n, sigma, (uint64_t)0, (uint64_t)0, (const uint64_t*)state_dev);
+    DIP_CHECK_LAUNCH();
+    return dip_counter_add(state_dev, (uint64_t)quads, stream);
 }
 
 extern "C" int dip_lanczos_down_fwd(const float* x, const float* taps, float* y, int C, int H, int W, int k,
                                     int factor, int pad, void* stream) {
     const int Ho = (H + 2 * pad - k) / factor + 1, Wo = (W + 2 * pad - k) / factor + 1;
-    hipLaunchKernelGGL(lanczos_fwd_kernel, dim3(dip_cdiv(C * Ho * Wo, 256)), dim3(256), 0, (hipStream_t)stream, x,
+    dip_launch(lanczos_fwd_kernel, dim3(dip_cdiv(C * Ho * Wo, 256)), dim3(256), 0, (hipStream_t)stream, x,
                        taps, y, C, H, W, k, factor, pad, Ho, Wo);
     DIP_CHECK_LAUNCH();
     return 0;
@@ -466,7 +497,7 @@ extern "C" int dip_lanczos_down_fwd(const float* x, const float* taps, float* y,
 extern "C" int dip_lanczos_down_bwd(const float* gy, const float* taps, float* gx, int C, int H, int W, int k,
                                     int factor, int pad, void* stream) {
     const int Ho = (H + 2 * pad - k) / factor + 1, Wo = (W + 2 * pad - k) / factor + 1;
-    hipLaunchKernelGGL(lanczos_bwd_kernel, dim3(dip_cdiv(C * H * W, 256)), dim3(256), 0, (hipStream_t)stream, gy,
+    dip_launch(lanczos_bwd_kernel, dim3(dip_cdiv(C * H * W, 256)), dim3(256), 0, (hipStream_t)stream, gy,
                        taps, gx, C, H, W, k, factor, pad, Ho, Wo);
     DIP_CHECK_LAUNCH();
     return 0;
@@ -476,7 +507,7 @@ extern "C" int dip_down_dense_fwd(const float* x, const float* w, const float* b
                                   int factor, int pad, void* stream) {
     const int Ho = (H + 2 * pad - k) / factor + 1, Wo = (W + 2 * pad - k) / factor + 1;
     if (Ho < 1 || Wo < 1) DIP_FAIL("down_dense_fwd: empty output");
-    hipLaunchKernelGGL(down_dense_fwd_kernel, dim3(dip_cdiv(C * Ho * Wo, 256)), dim3(256), 0, (hipStream_t)stream, x, w,
+    dip_launch(down_dense_fwd_kernel, dim3(dip_cdiv(C * Ho * Wo, 256)), dim3(256), 0, (hipStream_t)stream, x, w,
                        bias, y, C, H, W, k, factor, pad, Ho, Wo);
     DIP_CHECK_LAUNCH();
     return 0;
@@ -484,7 +515,7 @@ extern "C" int dip_down_dense_fwd(const float* x, const float* w, const float* b
 extern "C" int dip_down_dense_bwd_data(const float* gy, const float* w, float* gx, int C, int H, int W, int k, int factor,
                                        int pad, void* stream) {
     const int Ho = (H + 2 * pad - k) / factor + 1, Wo = (W + 2 * pad - k) / factor + 1;
-    hipLaunchKernelGGL(down_dense_bwd_data_kernel, dim3(dip_cdiv(C * H * W, 256)), dim3(256), 0, (hipStream_t)stream, gy,
+    dip_launch(down_dense_bwd_data_kernel, dim3(dip_cdiv(C * H * W, 256)), dim3(256), 0, (hipStream_t)stream, gy,
                        w, gx, C, H, W, k, factor, pad, Ho, Wo);
     DIP_CHECK_LAUNCH();
     return 0;
@@ -492,7 +523,7 @@ extern "C" int dip_down_dense_bwd_data(const float* gy, const float* w, float* g
 extern "C" int dip_down_dense_bwd_weight(const float* gy, const float* x, float* dw, float* db, int C, int H, int W, int k,
                                          int factor, int pad, void* stream) {
     const int Ho = (H + 2 * pad - k) / factor + 1, Wo = (W + 2 * pad - k) / factor + 1;
-    hipLaunchKernelGGL(down_dense_bwd_weight_kernel, dim3(C * C * k * k + C), dim3(256), 0, (hipStream_t)stream, gy, x, dw,
+    dip_launch(down_dense_bwd_weight_kernel, dim3(C * C * k * k + C), dim3(256), 0, (hipStream_t)stream, gy, x, dw,
                        db, C, H, W, k, factor, pad, Ho, Wo);
     DIP_CHECK_LAUNCH();
     return 0;

@@ -11,6 +11,7 @@
 // arena against a device-resident snapshot.  Nothing synchronises; the host reads the records when
 // it wants to print.
 #include "dip_common.h"
+#include "dip_group.h"
 
 namespace {
 
@@ -112,10 +113,10 @@ extern "C" int dip_fit_monitor(const float* out, const float* noisy, const float
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (n <= 0 || out == nullptr || noisy == nullptr || out_avg == nullptr) DIP_FAIL("fit_monitor: bad arguments");
     const int nblk = dip_fit_monitor_nblk(n);
-    hipLaunchKernelGGL(fit_monitor_partials_kernel, dim3(nblk), dim3(256), 0, st, out, noisy, gt, out_avg, n, exp_weight,
+    dip_launch(fit_monitor_partials_kernel, dim3(nblk), dim3(256), 0, st, out, noisy, gt, out_avg, n, exp_weight,
                        first, partial);
     DIP_CHECK_LAUNCH();
-    hipLaunchKernelGGL(fit_monitor_finalize_kernel, dim3(1), dim3(64), 0, st, partial, nblk, n, gt != nullptr ? 1 : 0,
+    dip_launch(fit_monitor_finalize_kernel, dim3(1), dim3(64), 0, st, partial, nblk, n, gt != nullptr ? 1 : 0,
                        loss, record, state, check_backtrack, backtrack_db);
     DIP_CHECK_LAUNCH();
     return 0;
@@ -126,7 +127,7 @@ extern "C" int dip_arena_backtrack(float* params, float* snapshot, int64_t n, co
     if ((reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(snapshot)) & 15)
         DIP_FAIL("arena_backtrack: arenas must be 16-byte aligned");
     const int64_t quads = (n + 3) / 4;
-    hipLaunchKernelGGL(arena_backtrack_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0,
+    dip_launch(arena_backtrack_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), params, snapshot, n, state);
     DIP_CHECK_LAUNCH();
     return 0;

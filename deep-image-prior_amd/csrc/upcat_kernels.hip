@@ -2,6 +2,7 @@
 // statistics (forward), and the adjoint gather fused with LeakyReLU backward + BatchNorm backward
 // phase 1 (backward).  HBM-bound, float4 per lane, NHWC.
 #include "dip_common.h"
+#include "dip_group.h"
 #include "bn_ticket.h"
 #include <stdlib.h>
 
@@ -66,7 +67,10 @@ __device__ __forceinline__ void upcat_rows_out(const DipUpcatDesc& d, const DipB
 // transforms and loads per output instead of 4), the column blends are shared by the two output rows.  Scale-2
 // bilinear weights (align_corners = False): odd outputs (0.75, 0.25) on (i, i+1), even outputs (0.25, 0.75) on
 // (i-1, i), except output 0 = (1, 0) -- exactly upsample_bilinear2d's lambdas (bil_src above).
-__global__ __launch_bounds__(256) void upcat_fwd_kernel(const DipUpcatDesc d, int qpb, const DipBnFin fin) {
+template <bool GRP = false>
+__global__ __launch_bounds__(256) void upcat_fwd_kernel(const DipUpcatDesc d_, int qpb, const DipBnFin fin_, const DipGrpArg<GRP> grp) {
+    DIP_GRP_DESC(DipUpcatDesc, d);
+    DIP_GRP_DESC(DipBnFin, fin);
     __shared__ __attribute__((aligned(16))) double shd[DIP_TICKET_SH_DOUBLES];      // float trees, then the fp64 finalisation
     __shared__ unsigned flag;
     float* sh = reinterpret_cast<float*>(shd);
@@ -187,7 +191,10 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const DipUpcatDesc d, in
 // read at (r + os_y, c + os_x) of its [Hs][Ws] tensor, the deeper branch at the up-sampled coordinate (r + od_y, c + od_x)
 // of its [2*Hd][2*Wd] image (upsample_bilinear2d's own source-index rule, bil_src, or nearest).  Used only for the
 // geometries the 2x2-block kernel above does not cover (pooling nets / skip-less scales at non-divisible sizes).
-__global__ __launch_bounds__(256) void upcat_fwd_crop_kernel(const DipUpcatDesc d, int ppb, const DipBnFin fin) {
+template <bool GRP = false>
+__global__ __launch_bounds__(256) void upcat_fwd_crop_kernel(const DipUpcatDesc d_, int ppb, const DipBnFin fin_, const DipGrpArg<GRP> grp) {
+    DIP_GRP_DESC(DipUpcatDesc, d);
+    DIP_GRP_DESC(DipBnFin, fin);
     __shared__ __attribute__((aligned(16))) double shd[DIP_TICKET_SH_DOUBLES];
     __shared__ unsigned flag;
     float* sh = reinterpret_cast<float*>(shd);
@@ -257,12 +264,19 @@ __global__ __launch_bounds__(256) void upcat_fwd_crop_kernel(const DipUpcatDesc 
 // low-res pixel (i,j): du = sum over the <=4x4 high-res pixels whose interpolation touches it.  The deeper branch is
 // [Hl][Wl]; the gradient dcat is [H][W] and covers rows ody..ody+H-1, columns odx..odx+W-1 of the [2*Hl][2*Wl] up-sampled
 // image (Concat's centre crop; default geometry: Hl = (H+1)/2, offsets 0).
-__global__ __launch_bounds__(256) void upsample_bwd_stats_kernel(const float* __restrict__ dcat, int Cs_cat, int choff,
+template <bool GRP = false>
+__global__ __launch_bounds__(256) void upsample_bwd_stats_kernel(const float* __restrict__ dcat_, int Cs_cat, int choff,
                                                                  int H, int W, int Hl, int Wl, int ody, int odx, int mode,
-                                                                 const float* __restrict__ y,
-                                                                 int Cy, int C, const float* __restrict__ state, int Cs,
-                                                                 float slope, float* dz, int Cdz, float* partials,
-                                                                 int ppb, const DipBnbFin fin) {
+                                                                 const float* __restrict__ y_,
+                                                                 int Cy, int C, const float* __restrict__ state_, int Cs,
+                                                                 float slope, float* dz_, int Cdz, float* partials_,
+                                                                 int ppb, const DipBnbFin fin_, const DipGrpArg<GRP> grp) {
+    DIP_GRP_PTR(const float*, dcat);
+    DIP_GRP_PTR(const float*, y);
+    DIP_GRP_PTR(const float*, state);
+    DIP_GRP_PTR(float*, dz);
+    DIP_GRP_PTR(float*, partials);
+    DIP_GRP_DESC(DipBnbFin, fin);
     __shared__ __attribute__((aligned(16))) double shd[256 * 8];
     __shared__ unsigned flag;
     float* sh = reinterpret_cast<float*>(shd);
@@ -516,13 +530,14 @@ static int upcat_fwd_impl(const DipUpcatDesc* d, const DipBnFin* finp, void* str
         const bool dflt = g.Hs == g.H && g.Ws == g.W && g.os_y == 0 && g.os_x == 0 && g.Hd == (g.H + 1) / 2 &&
                           g.Wd == (g.W + 1) / 2 && g.od_y == 0 && g.od_x == 0;
         if (!dflt) {
-            hipLaunchKernelGGL(upcat_fwd_crop_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, g, ppb, fin);
+            dip_launch_pair<DIP_FAM_UPCAT>(upcat_fwd_crop_kernel<false>, upcat_fwd_crop_kernel<true>, dim3(nb), dim3(256), 0, (hipStream_t)stream, g, ppb,
+                                           fin);
             DIP_CHECK_LAUNCH();
             return 0;
         }
     }
     const int qpb = dip_cdiv(((d->H + 1) / 2) * ((d->W + 1) / 2), nb);       // 2x2 output blocks per workgroup
-    hipLaunchKernelGGL(upcat_fwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *d, qpb, fin);
+    dip_launch_pair<DIP_FAM_UPCAT>(upcat_fwd_kernel<false>, upcat_fwd_kernel<true>, dim3(nb), dim3(256), 0, (hipStream_t)stream, *d, qpb, fin);
     DIP_CHECK_LAUNCH();
     return 0;
 }
@@ -545,10 +560,10 @@ static int pool2_fwd(bool maxp, const float* x, int H, int W, int Cx, int C, flo
     const int ppb = pixels_per_block((H / 2) * (W / 2), C, &nb);
     if (stats != nullptr && nb != nblk) DIP_FAIL("pool2_fwd: nblk mismatch (use dip_upcat_nblk(H/2, W/2, C))");
     if (maxp)
-        hipLaunchKernelGGL(avgpool2_fwd_kernel<true>, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, W, Cx, C, y, H / 2,
+        dip_launch(avgpool2_fwd_kernel<true>, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, W, Cx, C, y, H / 2,
                            W / 2, Cy, stats, ppb);
     else
-        hipLaunchKernelGGL(avgpool2_fwd_kernel<false>, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, W, Cx, C, y, H / 2,
+        dip_launch(avgpool2_fwd_kernel<false>, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, W, Cx, C, y, H / 2,
                            W / 2, Cy, stats, ppb);
     DIP_CHECK_LAUNCH();
     return 0;
@@ -569,7 +584,7 @@ extern "C" int dip_maxpool2_bwd(const float* dy, const float* x, int H, int W, i
     if ((Cdx & 3) || (Cdy & 3) || (Cx & 3)) DIP_FAIL("maxpool2_bwd: channel strides must be multiples of 4");
     const long long n = (long long)(H / 2) * (W / 2) * ((C + 3) / 4);
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, x,
+    dip_launch(maxpool2_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, x,
                        W / 2, Cdy, Cx, C, dx, H, W, Cdx);
     DIP_CHECK_LAUNCH();
     return 0;
@@ -578,7 +593,7 @@ extern "C" int dip_maxpool2_bwd(const float* dy, const float* x, int H, int W, i
 extern "C" int dip_avgpool2_bwd(const float* dy, int H, int W, int Cdy, int C, float* dx, int Cdx, void* stream) {
     if ((Cdx & 3) || (Cdy & 3)) DIP_FAIL("avgpool2_bwd: channel strides must be multiples of 4");
     const long long n = (long long)H * W * ((C + 3) / 4);
-    hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, W / 2,
+    dip_launch(avgpool2_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, W / 2,
                        Cdy, C, dx, H, W, Cdx);
     DIP_CHECK_LAUNCH();
     return 0;
@@ -600,8 +615,8 @@ extern "C" int dip_upsample_bwd_stats_crop_fin(const float* dcat, int Cs_cat, in
         if (C > 256 || nb > FIN_MAX_ROWS || fin.ticket == nullptr || fin.C != C)
             DIP_FAIL("upsample_bwd_stats_fin: needs <= 256 channels and rows (dip_fin_rows_ok), a ticket, C");
     }
-    hipLaunchKernelGGL(upsample_bwd_stats_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dcat, Cs_cat, choff, H,
-                       W, Hd, Wd, od_y, od_x, mode, y, Cy, C, state, Cs, slope, dz, Cdz, partials, ppb, fin);
+    dip_launch_pair<DIP_FAM_UPCAT>(upsample_bwd_stats_kernel<false>, upsample_bwd_stats_kernel<true>, dim3(nb), dim3(256), 0, (hipStream_t)stream, dcat,
+                                   Cs_cat, choff, H, W, Hd, Wd, od_y, od_x, mode, y, Cy, C, state, Cs, slope, dz, Cdz, partials, ppb, fin);
     DIP_CHECK_LAUNCH();
     return 0;
 }

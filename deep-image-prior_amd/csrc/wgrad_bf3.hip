@@ -20,6 +20,7 @@
 // The <= 4-channel tail of a 132-channel layer stays on the fp32 kernel's (tap, channel)-packed phase 2
 // (dip_conv_wgrad_tail): 2 MFMAs per K step instead of 9 with 28 of 32 rows idle.
 #include "dip_common.h"
+#include "dip_group.h"
 #include <stdlib.h>
 
 namespace {
@@ -298,7 +299,7 @@ int w3_launch(const DipWgradDesc& d, hipStream_t st) {
     // fit on a CU and the main chain's kernels find free slots next to it (experiment)
     static const int lds_req = [] { const char* e = getenv("DIP_WGRAD_BF3_LDS"); return e ? atoi(e) : 0; }();
     const int lds = lds_req > C::LDS_BYTES ? lds_req : C::LDS_BYTES;
-    hipLaunchKernelGGL(kern, dim3(d.nsplit, nfull, dip_cdiv(CoutP, 128)), dim3(256), lds, st, d, ntx, ntx * nty, CinP, CoutP);
+    dip_launch(kern, dim3(d.nsplit, nfull, dip_cdiv(CoutP, 128)), dim3(256), lds, st, d, ntx, ntx * nty, CinP, CoutP);
     DIP_CHECK_LAUNCH();
     return 0;
 }

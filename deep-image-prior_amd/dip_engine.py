@@ -143,6 +143,10 @@ class SkipEngine:
         self.device = None
         self.shape_key = None
         self.lib = None
+        # device-memory source: None = torch's allocator; dip_group.Slab = every buffer of the fit (arenas, activations,
+        # scratch, tables) is carved from ONE slab, so that B identically laid out slabs run through one launch list
+        # (grouped multi-instance execution, csrc/dip_group.h)
+        self.slab = None
 
         # records in a fixed traversal order
         self.convs: List[ConvRec] = []
@@ -193,6 +197,20 @@ class SkipEngine:
             if s.ns % 4 or s.down_b.Cout % 4 or s.up.Cout % 4 or (s.up.Cin % 4):
                 raise NotImplementedError("dip-amd: internal channel counts must be multiples of 4")
 
+    # ------------------------------------------------------------------ device memory
+    def _dalloc(self, n, dtype=torch.float32, zero=False):
+        """n elements of device memory from the slab (when one is set) or from torch."""
+        if self.slab is not None:
+            return self.slab.alloc(int(n), dtype, zero)
+        return (torch.zeros if zero else torch.empty)(int(n), dtype=dtype, device=self.device)
+
+    def _dcopy(self, host_bytes):
+        """A host table (ctypes array) as a uint8 device tensor."""
+        src = torch.frombuffer(bytearray(host_bytes), dtype=torch.uint8)
+        t = self._dalloc(src.numel(), torch.uint8)
+        t.copy_(src)
+        return t
+
     # ------------------------------------------------------------------ arenas
     def _build_arenas(self, device):
         self.lib = N.lib()
@@ -204,8 +222,8 @@ class SkipEngine:
             slots.append(off)
             off += round_up(p.numel(), 4)
         self.n_arena = off
-        self.params = torch.zeros(off, dtype=torch.float32, device=device)
-        self.grads = torch.zeros(off, dtype=torch.float32, device=device)
+        self.params = self._dalloc(off, zero=True)
+        self.grads = self._dalloc(off, zero=True)
         self.slots = slots
         with torch.no_grad():
             for p, o in zip(params, slots):
@@ -218,8 +236,8 @@ class SkipEngine:
             r.b_off = pid[id(r.module.bias)] if r.module.bias is not None else -1
         # BatchNorm buffers arena
         nb = sum(2 * b.Cs for b in self.bns)
-        self.bnbuf = torch.zeros(max(nb, 4), dtype=torch.float32, device=device)
-        self.nbt = torch.zeros(max(len(self.bns), 1), dtype=torch.int64, device=device)
+        self.bnbuf = self._dalloc(max(nb, 4), zero=True)
+        self.nbt = self._dalloc(max(len(self.bns), 1), torch.int64, zero=True)
         o = 0
         with torch.no_grad():
             for k, b in enumerate(self.bns):
@@ -234,8 +252,8 @@ class SkipEngine:
                     self.nbt[k] = m.num_batches_tracked.to(device)
                     m._buffers["num_batches_tracked"] = self.nbt[k]
                 o += 2 * b.Cs
-                b.state = torch.zeros(4 * b.Cs, dtype=torch.float32, device=device)
-                b.coef = torch.zeros(2 * b.Cs, dtype=torch.float32, device=device)
+                b.state = self._dalloc(4 * b.Cs, zero=True)
+                b.coef = self._dalloc(2 * b.Cs, zero=True)
         # packed weights
         off = 0
         recs = (N.DipPackRec * len(self.convs))()
@@ -248,7 +266,7 @@ class SkipEngine:
             recs[k] = N.DipPackRec(r.w_off, r.fwd_off, r.dgrad_off, r.Cout, r.Cin, r.ks, round_up(r.Cin, 4),
                                    round_up(r.Cout, 32), round_up(r.Cout, 4), round_up(r.Cin, 32))
             max_elems = max(max_elems, r.fwd_elems + r.dgrad_elems)
-        self.packed = torch.zeros(off, dtype=torch.float32, device=device)
+        self.packed = self._dalloc(off, zero=True)
         # three-bf16-plane copies of the 3x3 stride-1 weights (bf16-pipe convolution), when the library has it switched on
         self.bf3 = bool(self.lib.dip_conv_bf3_terms())
         if self.bf3:
@@ -265,11 +283,10 @@ class SkipEngine:
                     off3 += 9 * nchD * 3 * CinP * 16
                     max3 = max(max3, 9 * 16 * (nchF * CoutP + nchD * CinP))
                 recs3[k] = N.DipPackRec3(r.w_off, r.fwd3_off, r.dgrad3_off, r.Cout, r.Cin, r.ks, nchF, CoutP, nchD, CinP)
-            self.packed3 = torch.zeros(max(off3, 8), dtype=torch.int16, device=device)
-            self.pack_recs3 = torch.frombuffer(bytearray(bytes(recs3)), dtype=torch.uint8).to(device)
+            self.packed3 = self._dalloc(max(off3, 8), torch.int16, zero=True)
+            self.pack_recs3 = self._dcopy(bytes(recs3))
             self.pack_max3 = max3
-        raw = bytes(recs)
-        self.pack_recs = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+        self.pack_recs = self._dcopy(bytes(recs))
         self.pack_max = max_elems
         self.shape_key = None
 
@@ -283,8 +300,8 @@ class SkipEngine:
         return True
 
     # ------------------------------------------------------------------ per-shape plan
-    def _new(self, *shape):
-        t = torch.empty(shape, dtype=torch.float32, device=self.device)
+    def _new(self, n):
+        t = self._dalloc(n)
         self._alloc.append(t)          # the launch descriptors hold raw pointers: keep every buffer alive
         return t
 
@@ -320,7 +337,7 @@ class SkipEngine:
                 self.bwd_scratch2 = self._new(self.bwdp2_need)
                 self.bwd_scratch3 = self._new(self.bwdp3_need)
                 # zero-initialised; every launch leaves its counters at zero
-                self.tickets = torch.zeros(self.ticket_need, dtype=torch.int32, device=self.device)
+                self.tickets = self._dalloc(self.ticket_need, torch.int32, zero=True)
                 self._alloc.append(self.tickets)
             self._ticket_off = 0
             self._fused_bnb = {}
@@ -978,6 +995,31 @@ class SkipEngine:
         side = self._fwd_side
         self._run_two_streams(ops, main, lambda n: 1 if n in side else 0, lambda n: n.startswith("upcat:"), "fwd")
 
+    def _launch_forward(self, x_ptr, main, with_out_conv=True):
+        """The static forward launch list on stream `main` (+ the side stream): weight repack, NCHW -> NHWC of the input
+        at x_ptr, every layer up to (with_out_conv: and including) the output conv.  Pointers only -- also what
+        dip_group.GroupedFits issues once for B instances."""
+        lib, stream = self.lib, main.cuda_stream
+        N.check(lib.dip_pack_weights(_ptr(self.params), _ptr(self.packed), self.pack_recs.data_ptr(),
+                                     len(self.convs), self.pack_max, stream), "pack_weights")
+        if self.bf3:
+            N.check(lib.dip_pack_weights_bf3(_ptr(self.params), self.packed3.data_ptr(), self.pack_recs3.data_ptr(),
+                                             len(self.convs), self.pack_max3, stream), "pack_weights_bf3")
+        N.check(lib.dip_nchw_to_nhwc(x_ptr, _ptr(self.x_nhwc), self.Cimg, self.H * self.W, round_up(self.Cimg, 4), stream),
+                "nchw_to_nhwc")
+        ops = self.fwd_ops if with_out_conv else self.fwd_ops[:-1]      # the last op is the output conv
+        if self.two_streams:
+            self._run_forward_two_streams(ops, main)
+        else:
+            self._run(ops, stream)
+
+    def _launch_backward(self, main):
+        """The static backward launch list (dy of the output conv already in self.dy_out)."""
+        if self.two_streams:
+            self._run_backward_two_streams(self.bwd_ops, main)
+        else:
+            self._run(self.bwd_ops, main.cuda_stream)
+
     def forward(self, x: torch.Tensor, head=None):
         """Runs the forward launch list.  head = None: returns the network output [1,C,H,W].
         head = a utils.loss_head.MSEHead: the output conv + sigmoid + (mask) + MSE run as ONE launch
@@ -1005,18 +1047,7 @@ class SkipEngine:
                 xs = xs.float()
             xs = xs.contiguous()
             self.fwd_id += 1
-            N.check(lib.dip_pack_weights(_ptr(self.params), _ptr(self.packed), self.pack_recs.data_ptr(),
-                                         len(self.convs), self.pack_max, stream), "pack_weights")
-            if self.bf3:
-                N.check(lib.dip_pack_weights_bf3(_ptr(self.params), self.packed3.data_ptr(), self.pack_recs3.data_ptr(),
-                                                 len(self.convs), self.pack_max3, stream), "pack_weights_bf3")
-            N.check(lib.dip_nchw_to_nhwc(xs.data_ptr(), _ptr(self.x_nhwc), Cimg, H * W, round_up(Cimg, 4), stream),
-                    "nchw_to_nhwc")
-            ops = self.fwd_ops if head is None else self.fwd_ops[:-1]      # the last op is the output conv
-            if self.two_streams:
-                self._run_forward_two_streams(ops, main)
-            else:
-                self._run(ops, stream)
+            self._launch_forward(xs.data_ptr(), main, head is None)
             Ho_, Wo_ = self.Hout, self.Wout
             out = torch.empty((1, self.n_out, Ho_, Wo_), dtype=torch.float32, device=dev)
             loss = None
@@ -1081,10 +1112,7 @@ class SkipEngine:
                 self._gloss_keep = gl
                 N.check(lib.dip_loss_head_bwd(C.byref(self._head_desc), gl.data_ptr(), _ptr(self.dy_out),
                                               round_up(self.n_out, 4), stream), "loss_head_bwd")
-            if self.two_streams:
-                self._run_backward_two_streams(self.bwd_ops, main)
-            else:
-                self._run(self.bwd_ops, stream)
+            self._launch_backward(main)
             gx = None
             if need_input_grad:
                 self._run(self.bwd_input_ops, stream)

@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdip_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 PAD_ZERO, PAD_REFLECT, PAD_REPLICATE = 0, 1, 2
 UP_NEAREST, UP_BILINEAR = 0, 1
@@ -183,7 +183,12 @@ _SIGS = {
     "dip_adam_step_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double,
                                     C.c_double, C.c_void_p, C.c_void_p]),
     "dip_noise_axpy_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "dip_noise_axpy_dev2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p]),
     "dip_counter_add": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
+    "dip_group_begin": (C.c_int, [C.c_int, C.c_longlong, C.c_void_p, C.c_longlong]),
+    "dip_group_end": (C.c_int, []),
+    "dip_group_size": (C.c_int, []),
+    "dip_group_native": (C.c_int, [C.c_int]),
     "dip_loss_head_nblk": (C.c_int, [C.c_int, C.c_int]),
     "dip_loss_head_fwd": (C.c_int, [C.POINTER(DipLossHeadDesc), C.c_void_p]),
     "dip_loss_head_bwd": (C.c_int, [C.POINTER(DipLossHeadDesc), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),

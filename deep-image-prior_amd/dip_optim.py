@@ -176,14 +176,20 @@ class GraphedIteration:
 
     @classmethod
     def group(cls, fits, warmup=3, device=None, single_graph=False):
-        """Grouped multi-instance execution: `fits` = [(optimizer, closure), ...] of INDEPENDENT nets
-        (own weights, own BatchNorm statistics, own Adam state).  Every fit is captured into its own
+        """Grouped multi-instance execution: `fits` = a dip_group.GroupedFits (B fits of one architecture with the
+        fused closure: ONE launch list, one hipGraph -- see that module), or [(optimizer, closure), ...] of INDEPENDENT nets
+        with arbitrary closures (own weights, own BatchNorm statistics, own Adam state).  In the second form every fit is captured into its own
         hipGraph on its own HIP stream and one run() step replays all of them, so the kernels of
         different instances overlap on the chip -- what fills an MI355X when one image (e.g. the
         384x256 snail net: 25 us of math per iteration) cannot.
         single_graph=True captures all fits as concurrent branches of ONE graph instead (one graph
         launch per iteration; cross-stream capture of this size is fragile in the HIP runtime, so it is
         opt-in)."""
+        import dip_group
+        if isinstance(fits, dip_group.GroupedFits):
+            # ONE launch list for all the fits (every kernel launch serves all instances, csrc/dip_group.h), captured as
+            # ONE hipGraph: the form for many small fits -- 1/B of the launches of the per-fit graphs below
+            return fits.capture(warmup)
         self = cls.__new__(cls)
         self.fits = list(fits)
         if single_graph or len(self.fits) == 1:

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DIP_ABI_VERSION 4
+#define DIP_ABI_VERSION 5
 
 #define DIP_PAD_ZERO 0
 #define DIP_PAD_REFLECT 1
@@ -45,6 +45,24 @@ const char* dip_last_error(void);
  * `device` / power blocks and its rank -> NUMA-node pinning use it.  buf: >= 13 bytes. */
 int dip_device_pci_bus_id(int device, char* buf, int len);
 
+
+/* ---------------------------------------------------------------- grouped execution --------- */
+/* B independent fits in ONE launch list: B copies of the skip-net of models/skip.py:45-100 --
+ * own weights, own BatchNorm statistics, own Adam state, own input and target -- with identical architecture and sizes.
+ * The caller carves EVERY buffer of a fit (arenas, activations, scratch, the DipPackRec tables, input, target, loss)
+ * from one slab per instance; the slabs are the rows of one [ninst][stride_bytes] allocation, laid out identically.  It
+ * builds the descriptors of instance 0 and issues the launch list once between dip_group_begin and dip_group_end: every
+ * launch of this library then serves all instances, instance b with each non-NULL pointer argument and descriptor field
+ * advanced by b * stride_bytes (base / row_bytes = slab of instance 0: a pointer outside it fails the call, rc -1).  Plans,
+ * tile walks and summation orders are those of a solo launch, so each instance's results are bit-identical to the same fit
+ * run on its own.  Kernels with a grouped form run B instances in one dispatch (gridDim.z x B); the others are dispatched B
+ * times by the library (csrc/dip_group.h).  Host-side state: one launching thread; hipGraph-capturable like a solo list.
+ * dip_group_native: bit mask of the kernel families whose one-dispatch form is in use (default all; DIP_GROUP_NATIVE);
+ * mask < 0 only queries.  Returns the previous mask.  dip_group_size: instances of the open group (1: none). */
+int dip_group_begin(int ninst, long long stride_bytes, const void* base, long long row_bytes);
+int dip_group_end(void);
+int dip_group_size(void);
+int dip_group_native(int mask);
 
 /* Per-channel input transform fused into a consumer's loader:
  *   u = act(t),  t = a[c]*x + b[c];  act = max(t, slope*t) for slope in (0, 1] (slope = 1 -> affine
@@ -429,6 +447,9 @@ int dip_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, d
 /* dip_noise_axpy whose Philox offset lives at *offset_dev and is advanced by ceil(n/4) afterwards. */
 int dip_noise_axpy_dev(const float* z, float* out, int64_t n, float sigma, uint64_t seed, uint64_t* offset_dev,
                        void* stream);
+/* dip_noise_axpy_dev with the seed in device memory too: state_dev = {offset, seed} (two uint64).  In a group every
+ * instance reads its own pair, i.e. draws its own stream. */
+int dip_noise_axpy_dev2(const float* z, float* out, int64_t n, float sigma, uint64_t* state_dev, void* stream);
 /* *counter += inc (one thread; ordering by the stream). */
 int dip_counter_add(uint64_t* counter, uint64_t inc, void* stream);
 

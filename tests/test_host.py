@@ -23,7 +23,7 @@ def test_cabi_exports_every_declared_symbol(built):
     L = ctypes.CDLL(dip_native.LIB_PATH)
     for name in declared:
         assert hasattr(L, name), name
-    assert built.dip_abi_version() == dip_native.ABI_VERSION == 4
+    assert built.dip_abi_version() == dip_native.ABI_VERSION == 5
     # struct layouts agree with the header's field order (sizes on LP64)
     assert ctypes.sizeof(dip_native.DipTransform) == 24
     assert ctypes.sizeof(dip_native.DipGradSrc) == 40     # + the crop window of round 3
@@ -261,6 +261,91 @@ def test_no_silent_fallback():
             % os.path.join(ROOT, "deep-image-prior_amd"))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert "LOUD" in r.stdout and "no fallback" in r.stdout
+
+
+def test_grouped_fits_slab_layout_on_host_memory(built):
+    """dip_group.GroupedFits builds its memory model without a GPU (the dry mode of this test only: nothing can be
+    launched): one slab per instance, identically laid out, every pointer of the launch list inside instance 0's slab
+    (what the library checks per grouped launch), parameters / BatchNorm buffers of every net moved into their rows
+    unchanged, per-instance views strided by the slab size."""
+    from models.skip import skip
+    from dip_group import GroupedFits
+
+    def small(seed):
+        torch.manual_seed(seed)
+        return skip(8, 3, num_channels_down=[16, 32, 32], num_channels_up=[16, 32, 32], num_channels_skip=[4, 0, 4],
+                    upsample_mode="bilinear", need_sigmoid=True, need_bias=True, pad="reflection")
+
+    B = 3
+    nets = [small(k) for k in range(B)]
+    with torch.no_grad():
+        for b, n in enumerate(nets):                          # distinguishable BatchNorm buffers
+            for m in n.modules():
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.running_mean.add_(b + 1.0)
+                    m.num_batches_tracked.add_(7 * b)
+    ref = [{k: v.clone() for k, v in n.state_dict().items()} for n in nets]
+    zs = [torch.rand(1, 8, 36, 52) * 0.1 for _ in range(B)]
+    ts = [torch.rand(1, 3, 36, 52) for _ in range(B)]
+    ms = [(torch.rand(1, 1, 36, 52) > 0.3).float() for _ in range(B)]
+    g = GroupedFits(nets, zs, ts, masks=ms, reg_noise_std=1 / 30., seeds=[5, 6, 7], exp_weight=0.99, device="cpu",
+                    _dry_cpu=True)
+    assert g.stride % 256 == 0 and g.mem.data_ptr() % 256 == 0 and g.mem.numel() == B * g.stride
+    assert g.pointers_outside_row0() == []
+    ex = g._row0_extra
+    for b, n in enumerate(nets):
+        lo = g.mem.data_ptr() + b * g.stride
+        sd = n.state_dict()
+        assert list(sd) == list(ref[b])
+        for k in ref[b]:
+            assert torch.equal(sd[k], ref[b][k]), (b, k)
+            assert lo <= sd[k].data_ptr() < lo + g.stride, (b, k)        # parameters AND buffers live in row b
+        assert [p.data_ptr() - lo for p in n.parameters()] == [p.data_ptr() - g.mem.data_ptr() for p in nets[0].parameters()]
+        assert torch.equal(g._inst(ex["saved"], b).view(zs[b].shape), zs[b])
+        assert torch.equal(g._inst(ex["target"], b).view(ts[b].shape), ts[b])
+        assert torch.equal(g._inst(ex["mask"], b).view(ms[b].shape), ms[b])
+        assert g._inst(ex["rng"], b).tolist() == [0, 5 + b] and g._inst(ex["gl"], b).item() == 1.0
+        # descriptor tables are replicated: the grouped weight-packing kernel reads the table of its own instance
+        assert torch.equal(g._inst(g.eng.pack_recs, b), g.eng.pack_recs)
+    assert g.losses.shape == (B,) and g.losses.stride() == (g.stride // 4,)
+    assert g.out.shape == (B, 3, 36, 52) and g.out.stride() == (g.stride // 4, 36 * 52, 52, 1)
+    assert g.out[1].data_ptr() == g._inst(ex["out"], 1).data_ptr()
+    assert g._nbt_all[2].data_ptr() == g._inst(g.eng.nbt, 2).data_ptr()
+    assert g._nbt_all[:, 0].tolist() == [0, 7, 14]
+    with pytest.raises(RuntimeError, match="dry"):
+        g.step()
+    with pytest.raises(RuntimeError, match="MI355X"):
+        GroupedFits([small(0)], zs[:1], ts[:1], device="cpu")
+    with pytest.raises(ValueError, match="architecture"):
+        GroupedFits([small(0), skip(8, 3, [16, 32], [16, 32], [4, 4])], zs[:2], ts[:2], device="cpu", _dry_cpu=True)
+    with pytest.raises(ValueError, match="net output"):        # without skips an odd size comes out larger than it went in
+        GroupedFits([skip(8, 3, [16, 16], [16, 16], [0, 0], pad="reflection")], [torch.rand(1, 8, 18, 18)],
+                    [torch.rand(1, 3, 18, 18)], device="cpu", _dry_cpu=True)
+
+
+def test_group_protocol_host_state(built):
+    """dip_group_begin / dip_group_end / dip_group_native are host-side state (csrc/dip_core.hip): checked without a GPU."""
+    L = built
+    assert L.dip_group_size() == 1
+    buf = (ctypes.c_char * 4096)()
+    base = (ctypes.addressof(buf) + 255) & ~255
+    prev = L.dip_group_native(-1)
+    try:
+        assert L.dip_group_begin(0, 1024, base, 512) != 0 and b"instances" in L.dip_last_error()
+        assert L.dip_group_begin(2, 1024, None, 512) != 0
+        assert L.dip_group_begin(2, 256, base, 512) != 0 and b"overlap" in L.dip_last_error()      # stride < row
+        assert L.dip_group_begin(2, 1000, base, 512) != 0                                           # unaligned stride
+        assert L.dip_group_begin(2, 1024, base + 8, 512) != 0                                       # unaligned base
+        assert L.dip_group_size() == 1
+        assert L.dip_group_begin(3, 1024, base, 512) == 0 and L.dip_group_size() == 3
+        assert L.dip_group_begin(2, 1024, base, 512) != 0 and b"already open" in L.dip_last_error()
+        assert L.dip_group_end() == 0 and L.dip_group_size() == 1
+        assert L.dip_group_begin(1, 0, base, 512) == 0           # one instance: stride is irrelevant
+        assert L.dip_group_end() == 0
+        assert L.dip_group_native(0x15) == prev and L.dip_group_native(-1) == 0x15
+    finally:
+        L.dip_group_end()
+        L.dip_group_native(prev)
 
 
 def test_fused_adam_grouping_cpu_logic():
