@@ -323,6 +323,75 @@ def test_grouped_fits_slab_layout_on_host_memory(built):
                     [torch.rand(1, 3, 18, 18)], device="cpu", _dry_cpu=True)
 
 
+def test_grouped_iteration_issues_its_launch_list_without_a_gpu(built):
+    """The host side of one grouped iteration end to end, without a GPU: every launch of the list goes through the real
+    C ABI (argument marshalling, dispatch, the slab range check) and fails at hipLaunchKernel with "no ROCm-capable device"
+    (rc 100), which this test -- and only this test -- tolerates; anything else (a bad argument, a refused launch, a Python
+    error) fails it.  In a subprocess: it patches torch.cuda's stream accessors."""
+    code = r"""
+import sys, contextlib, torch
+sys.path.insert(0, %r)
+import dip_native as N
+from models.skip import skip
+import dip_group as G
+seen = []
+real = N.check
+def check(rc, what=""):
+    seen.append((what, rc))
+    if rc not in (0, 100):
+        real(rc, what)
+N.check = check
+class FakeStream:
+    cuda_stream = None
+torch.cuda.current_stream = lambda d=None: FakeStream()
+torch.cuda.device = lambda d: contextlib.nullcontext()
+torch.cuda.is_current_stream_capturing = lambda: False
+def net(seed):
+    torch.manual_seed(seed)
+    return skip(8, 3, num_channels_down=[16, 32, 32], num_channels_up=[16, 32, 32], num_channels_skip=[4, 4, 4],
+                upsample_mode="bilinear", need_sigmoid=True, need_bias=True, pad="reflection")
+B = 3
+g = G.GroupedFits([net(k) for k in range(B)], [torch.rand(1, 8, 32, 64) * 0.1 for _ in range(B)],
+                  [torch.rand(1, 3, 32, 64) for _ in range(B)], masks=[torch.ones(1, 1, 32, 64)] * B, reg_noise_std=1 / 30.,
+                  exp_weight=0.99, device="cpu", _dry_cpu=True)
+g._dry = False                      # (launches are attempted from here on)
+g.step(2)
+failed = [w for w, rc in seen if rc == 100]
+for must in ("noise_axpy_dev2", "pack_weights", "nchw_to_nhwc", "loss_head_fwd", "loss_head_bwd", "adam_tick", "adam_step_dev"):
+    assert failed.count(must) == 2, (must, failed.count(must))
+eng = g.eng
+names = [n for _, _, n in eng.fwd_ops[:-1] + eng.bwd_ops]
+assert all(failed.count(n) == 2 * names.count(n) for n in set(names)), "an op of the launch list was not issued"
+assert N.lib().dip_group_size() == 1 and g.iterations == 2
+assert g._nbt_all.unique().tolist() == [2]
+print("WALK_OK", len(failed))
+""" % os.path.join(ROOT, "deep-image-prior_amd")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, DIP_TWO_STREAMS="0"))
+    assert "WALK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_group_pointer_lists_cover_every_descriptor_pointer():
+    """csrc/dip_group.h names the pointer fields of every descriptor struct ONCE (dip_ptrs); a grouped launch shifts exactly
+    those.  A pointer field missing there would be read at instance 0's address by every instance: compare the lists with
+    the struct definitions of the binding (which test_cabi_exports_every_declared_symbol ties to include/dip_hip.h)."""
+    import dip_native as N
+    src = open(os.path.join(ROOT, "deep-image-prior_amd", "csrc", "dip_group.h")).read()
+    lists = {}
+    for m in re.finditer(r"dip_ptrs\((Dip\w+)& (\w+), F& f\) \{(.*?)\n?\}", src, re.S):
+        name, var, body = m.groups()
+        fields = re.findall(r"\bf\(%s\.(\w+)\)" % var, body) + re.findall(r"dip_ptrs\(%s\.(\w+), f\)" % var, body)
+        lists[name] = sorted(fields)
+    structs = {n: getattr(N, n) for n in ("DipTransform", "DipConvDesc", "DipWgradDesc", "DipGradSrc", "DipBnFin", "DipBnbFin",
+                                          "DipUpcatDesc", "DipLossHeadDesc")}
+    for name, st in structs.items():
+        want = sorted(f for f, t in st._fields_ if t is ctypes.c_void_p or (isinstance(t, type) and issubclass(t, ctypes.Structure)))
+        assert lists.get(name) == want, (name, lists.get(name), want)
+    # structs without pointers must not appear as launch arguments unless they say so (SmallGeom does, in conv_small.hip)
+    for name in ("DipPackRec", "DipPackRec3", "DipIterState"):
+        assert not any(t is ctypes.c_void_p for _, t in getattr(N, name)._fields_)
+
+
 def test_group_protocol_host_state(built):
     """dip_group_begin / dip_group_end / dip_group_native are host-side state (csrc/dip_core.hip): checked without a GPU."""
     L = built
