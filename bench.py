@@ -1046,6 +1046,8 @@ def main():
 
     if rank == 0:
         eng = fits[0].engine
+        if not hasattr(eng, "fwd_ops") and grouped is not None:
+            eng = grouped.eng                  # --group native without the per-launch profile: the per-fit nets never ran
         rl = rw = rh = r3 = None
         if not args.no_roofline:
             rl, rw = roofline(eng, per_op, with_pmc=(args.config == "default"))

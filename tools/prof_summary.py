@@ -22,7 +22,7 @@ if setup_only:
           "the launches of one steady-state iteration")
 print()
 print("# per launch geometry of the MFMA kernels (grid in workgroups)")
-for pat in ("conv_igemm_dma_kernel", "conv_igemm_kernel", "conv_wgrad_kernel"):
+for pat in ("conv_igemm_dma_kernel", "conv_igemm_kernel", "conv_wgrad_kernel", "conv_small_kernel", "conv_bf3_kernel", "wgrad_bf3_kernel"):
     for r in cur.execute("select name, grid_x/workgroup_x, grid_y, grid_z, count(*), avg(end-start)/1e3, min(end-start)/1e3, max(end-start)/1e3 "
                          "from kernels where name like ? group by 1,2,3,4 order by 6 desc", ("%" + pat + "%",)):
         n = re.sub(r"\(anonymous namespace\)::|\(Dip.*", "", r[0]).replace("void ", "")
@@ -31,4 +31,7 @@ for pat in ("conv_igemm_dma_kernel", "conv_igemm_kernel", "conv_wgrad_kernel"):
 print()
 print("# dominant kernel of bench.py's roofline object: conv_igemm_dma_kernel<3, 128, *> (both transform variants)")
 r = cur.execute("select count(*), sum(end-start)/1e3, avg(end-start)/1e3 from kernels where name like '%conv_igemm_dma_kernel<3, 128,%'").fetchone()
-print(f"launches={r[0]} ({r[0]/steps:.1f}/step)  total={r[1]/1e3:.2f} ms ({r[1]/steps/1e3:.3f} ms/step)  avg launch={r[2]:.1f} us")
+if r[0]:
+    print(f"launches={r[0]} ({r[0]/steps:.1f}/step)  total={r[1]/1e3:.2f} ms ({r[1]/steps/1e3:.3f} ms/step)  avg launch={r[2]:.1f} us")
+else:
+    print("(not launched in this run)")
