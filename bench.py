@@ -719,7 +719,7 @@ def roofline(eng, per_op_ms, with_pmc=True):
           "algorithmic_gflop_per_launch": round(tot_f / 1e9 / max(n, 1), 2),
           "algorithmic_bytes_per_launch": round(alg_bytes / max(n, 1)),
           "splitk_finish_ms_per_step_not_included": round(fin_ms, 3),
-          "measured_mfma_ceiling_tflops": 151.9 if not terms else 238.0,   # tools/ubench/mfma_peak.hip / bf16x9.hip (2 WG/CU)
+          "measured_mfma_ceiling_tflops": 151.9 if not terms else round(238.0 * 9 / terms, 1),   # tools/ubench/mfma_peak.hip / bf16x9.hip (2 WG/CU)
           "all_conv_launches": {"gflop_per_step": round(all_f / 1e9, 1), "ms_per_step_serial": round(all_ms, 3),
                                 "tflops": round(all_f / (all_ms * 1e-3) / 1e12, 2) if all_ms > 0 else None}}
     try:        # matrix-pipe utilisation from the committed counter pass (tools/pmc_mfma.py; another run than this line)
@@ -1099,8 +1099,12 @@ def main():
                        "kernel_launches_per_iteration": n_launch, "final_loss": round(final_loss, 6),
                        "arithmetic": ("fp32 tensors, fp32 accumulation everywhere.  3x3 stride-1 layers with >= 256 tiles: each fp32 "
                                       f"operand split EXACTLY into three bf16 terms, {terms} of the 9 cross products (each exact in "
-                                      "fp32) summed in fp32 on v_mfma_f32_32x32x16_bf16 -- per-op error vs fp64 <= the fp32 MFMA's "
-                                      "(tests/test_bf3_gpu.py); all other layers: v_mfma_f32_32x32x2_f32") if terms else
+                                      "fp32) summed in fp32 on v_mfma_f32_32x32x16_bf16"
+                                      + ("" if terms == 9 else " (8: all but lo x lo, which is < 2^-32 of a product = 2^-8 of the "
+                                         "rounding error of one fp32 accumulation step; DIP_CONV_BF3=9 adds it back)" if terms == 8
+                                         else " (6: the six largest)")
+                                      + " -- per-op error vs fp64 <= the fp32 MFMA's (tests/test_bf3_gpu.py); all other layers: "
+                                        "v_mfma_f32_32x32x2_f32") if terms else
                                      "fp32 everywhere (v_mfma_f32_32x32x2_f32)"},
             "per_rank_it_s": [round(v, 3) for v in per_rank],
             "per_rank_final_loss": [round(v, 6) for v in per_rank_loss],

@@ -64,7 +64,8 @@ __device__ __forceinline__ void b3_split(float a, unsigned& h, unsigned& m, unsi
     l = __float_as_uint(r2) & 0xFFFF0000u;        // (<= 8 significand bits are left: the mask only drops zeros)
 }
 
-// NT = 9: all cross products (exact); NT = 6: without lo*lo, lo*mid, mid*lo (each < 2^-24 of the product).
+// NT = 9: all cross products (exact); NT = 8: without lo*lo (< 2^-32 of the product: 2^-8 of the rounding error of ONE fp32
+// accumulation step, so the sum is as accurate as with it); NT = 6: also without lo*mid, mid*lo (each < 2^-24 of the product).
 //
 // The B operand (weights) goes straight from L2 into registers, one unit ahead: no weight buffers in LDS, no LDS-DMA, and
 // ONE workgroup barrier per 16-channel chunk (9 units) -- the waves of a workgroup only meet where the A buffers change hands.
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(const DipConvDesc d, c
     auto compute = [&](BSet bs, ASet as) {
 #pragma unroll
         for (int sm = 4; sm >= 0; --sm) {          // smallest partial products first
-            if (NT == 6 && sm > 2) continue;
+            if ((NT == 6 && sm > 2) || (NT == 8 && sm > 3)) continue;
 #pragma unroll
             for (int pa = 0; pa < 3; ++pa) {
                 const int pb = sm - pa;
@@ -354,12 +355,14 @@ __global__ __launch_bounds__(256) void pack_weights_bf3_kernel(const float* __re
 int g_bf3_override = -1;             // dip_conv_bf3_set_terms
 
 int bf3_terms() {
-    // default: all nine cross products (exact); DIP_CONV_BF3=0: the fp32-MFMA kernels; =6: the six largest products
+    // default: eight cross products -- all but lo x lo, which is < 2^-32 of a product (2^-8 of the rounding error of one fp32
+    // accumulation step: measured error vs fp64 identical to the nine-product form, tests/test_bf3_gpu.py; +2.6 % per iteration);
+    // DIP_CONV_BF3=9: all nine (every product exact); =0: the fp32-MFMA kernels; =6: the six largest products
     static const int v = [] {
         const char* e = getenv("DIP_CONV_BF3");
-        if (e == nullptr) return 9;
+        if (e == nullptr) return 8;
         const int t = atoi(e);
-        return t == 6 ? 6 : (t == 0 ? 0 : 9);
+        return t == 6 ? 6 : (t == 9 ? 9 : (t == 0 ? 0 : 8));
     }();
     return g_bf3_override >= 0 ? g_bf3_override : v;
 }
@@ -406,15 +409,20 @@ extern "C" int dip_conv_bf3_cols(const DipConvDesc* dp, int n_base, int ncols, v
         if (tr == 1) return bf3_launch<6, 1>(d, n_base, ncols, st);
         return bf3_launch<6, 2>(d, n_base, ncols, st);
     }
+    if (nt == 8) {
+        if (tr == 0) return bf3_launch<8, 0>(d, n_base, ncols, st);
+        if (tr == 1) return bf3_launch<8, 1>(d, n_base, ncols, st);
+        return bf3_launch<8, 2>(d, n_base, ncols, st);
+    }
     if (tr == 0) return bf3_launch<9, 0>(d, n_base, ncols, st);
     if (tr == 1) return bf3_launch<9, 1>(d, n_base, ncols, st);
     return bf3_launch<9, 2>(d, n_base, ncols, st);
 }
 
 extern "C" int dip_conv_bf3_terms(void) { return bf3_terms(); }
-// 0 / 6 / 9: overrides DIP_CONV_BF3 for this process (tests, A/B runs inside one process); -1: back to the environment
+// 0 / 6 / 8 / 9: overrides DIP_CONV_BF3 for this process (tests, A/B runs inside one process); -1: back to the environment
 extern "C" int dip_conv_bf3_set_terms(int terms) {
-    if (terms != -1 && terms != 0 && terms != 6 && terms != 9) DIP_FAIL("conv_bf3_set_terms: 0, 6, 9 or -1");
+    if (terms != -1 && terms != 0 && terms != 6 && terms != 8 && terms != 9) DIP_FAIL("conv_bf3_set_terms: 0, 6, 8, 9 or -1");
     g_bf3_override = terms;
     return 0;
 }

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf3_kernel(const DipWgradDesc d,
                         const int t = ky * 3 + kx;
 #pragma unroll
                         for (int sm = 4; sm >= 0; --sm) {               // smallest partial products first
-                            if (NT == 6 && sm > 2) continue;
+                            if ((NT == 6 && sm > 2) || (NT == 8 && sm > 3)) continue;
 #pragma unroll
                             for (int pa = 0; pa < 3; ++pa) {
                                 const int pb = sm - pa;
@@ -332,6 +332,7 @@ extern "C" int dip_wgrad_bf3(const DipWgradDesc* dp, void* stream) {
     const int tr = d.tr.a == nullptr ? 0 : (d.tr.slope > 0.f ? 1 : 2);
     int rc;
     if (nt == 6) rc = tr == 0 ? w3_launch<6, 0>(d, st) : (tr == 1 ? w3_launch<6, 1>(d, st) : w3_launch<6, 2>(d, st));
+    else if (nt == 8) rc = tr == 0 ? w3_launch<8, 0>(d, st) : (tr == 1 ? w3_launch<8, 1>(d, st) : w3_launch<8, 2>(d, st));
     else rc = tr == 0 ? w3_launch<9, 0>(d, st) : (tr == 1 ? w3_launch<9, 1>(d, st) : w3_launch<9, 2>(d, st));
     if (rc) return rc;
     // the <= 4-channel tail of a 132-channel layer: the fp32 kernel's (tap, channel)-packed phase 2 on its own

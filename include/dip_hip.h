@@ -253,7 +253,7 @@ int dip_conv_dgrad_ring_ok(const DipConvDesc* d);
 int dip_conv_bf3_eligible(const DipConvDesc* d);
 int dip_conv_bf3_cols(const DipConvDesc* d, int n_base, int ncols, void* stream);
 int dip_conv_bf3_terms(void);
-/* overrides DIP_CONV_BF3 for this process: 0 (off), 6, 9; -1 = back to the environment */
+/* overrides DIP_CONV_BF3 for this process: 0 (off), 6, 8 (without lo x lo: < 2^-32 of a product), 9; -1 = back to the environment */
 int dip_conv_bf3_set_terms(int terms);
 /* second half of a split-K dispatch (d->ksplit > 1): fixed-order sum of the workspace slices, bias,
  * store, BatchNorm partials.  dip_conv_igemm calls it itself; exported for per-kernel timing. */

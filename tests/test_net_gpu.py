@@ -288,11 +288,12 @@ AB_SWITCH_SETS = [
     dict(DIP_TWO_STREAMS="0"),
     dict(DIP_DEFER_WGRAD="-1", DIP_SIDE_MIN_PIXELS="16384"),
     dict(DIP_BNB_FUSE="1", DIP_DEFER_WGRAD="0"),
-    # round 4: fp32-MFMA convolutions instead of the bf16-pipe ones; six instead of nine partial products; the round-3
+    # round 4: fp32-MFMA convolutions instead of the bf16-pipe ones; six instead of eight partial products; the round-3
     # low-resolution path (split-K kernels, padded-domain data gradients); in-launch (ticket) finalisations
     dict(DIP_CONV_BF3="0"),
     dict(DIP_CONV_BF3="6", DIP_TICKET_FIN="1"),
     dict(DIP_CONV_NO_SMALL="1", DIP_CONV_NO_RING="1"),
+    dict(DIP_CONV_BF3="9"),               # all nine partial products (the default leaves lo x lo out)
 ]
 
 
