@@ -736,7 +736,7 @@ def roofline(eng, per_op_ms, with_pmc=True):
             # utilisation x (clock the kernel ran at) / 2.4 (every executed MFMA of these launches is algorithmic work)
             rl["frac_from_pmc"] = round(util * ghz / 2.4, 4)
             rl["mfma_util_pmc_source"] = ("profiles/r04_rocprofv3_pmc_MFMA.txt (a counter pass of the same code; same box and call as this "
-                                          "line when tools/gpu_round4.sh produced both): utilisation = SQ_VALU_MFMA_BUSY_CYCLES / "
+                                          "line when tools/gpu_round4.sh / gpu_round4_final.sh produced both): utilisation = SQ_VALU_MFMA_BUSY_CYCLES / "
                                           "(128 x GRBM_GUI_ACTIVE), clock = GRBM_GUI_ACTIVE / (8 x duration), units calibrated on the "
                                           "pure-MFMA loops of tools/ubench in the same call; frac_from_pmc = utilisation x clock / 2.4 GHz "
                                           f"is the counter-derived value of `frac`: the matrix pipes of this kernel are busy {100 * util:.0f} % "
