@@ -9,8 +9,9 @@ of the same kernel.
 
 The step count lives in device memory (DipIterState, advanced by dip_adam_tick), so `step()` is a
 static launch sequence: `GraphedIteration` captures {zero_grad(); closure(); step()} into one
-hipGraph and replays it, and `GraphedIteration.group([...])` captures several independent fits as
-concurrent branches of ONE graph (grouped multi-instance execution for small images).
+hipGraph and replays it.  Several independent fits: `GraphedIteration.group(dip_group.GroupedFits(...))`
+captures ONE launch list that serves all of them (every kernel launch covers all instances), and
+`GraphedIteration.group([(optimizer, closure), ...])` -- arbitrary closures -- one graph per fit on its own stream.
 """
 from __future__ import annotations
 
