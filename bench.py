@@ -1,7 +1,7 @@
 """Benchmark of the deep-image-prior hot path on MI355X.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--config default|sr|kate|library|snail]
-                  [--closure fused|notebook] [--no-graph] [--instances B]
+                  [--closure fused|notebook] [--no-graph] [--instances B [--group both|native|graphs]]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one optimisation iteration (reg-noise perturbation, skip-net forward, MSE, backward,
@@ -24,6 +24,11 @@ or as K replays of the iteration captured into a hipGraph (dip_optim.GraphedIter
 `--mode auto` (default) times K steps each way and reports the faster as `value`, the other under
 "other_mode".  `--closure notebook --mode eager` times the notebook's own torch closure; the default
 line reports that figure too (`eager_notebook`) from a short extra run.
+
+`--instances B` (> 1): B independent fits per GPU, timed as ONE launch list that serves all of them
+(dip_group.GroupedFits: every kernel launch covers the B instances) and as one hipGraph per
+fit on its own stream; the faster is `value`, the others go to "other_mode".  The default line carries a
+short run of that form as `grouped_batch_of_4` (4 fits of the headline configuration on the GPU).
 
 The JSON line also carries
   roofline       : the dominant kernel (3x3 stride-1 implicit-GEMM conv, 128-wide N block: forward
@@ -1084,6 +1089,29 @@ def main():
                                  "what": "DIP_CONV_BF3=0: every convolution on v_mfma_f32_32x32x2_f32 (the round-3 arithmetic), eager launches"}
             except Exception as e:          # the headline does not depend on it
                 fp32_only = {"error": str(e)[:200]}
+        # a BATCH of independent fits on this GPU through ONE launch list (dip_group.GroupedFits): 4 images of
+        # the headline configuration, in a process of its own; reported next to the headline, never as it
+        batch4 = None
+        if world == 1 and n_inst == 1 and args.config == "default" and not args.no_eager_line \
+                and os.environ.get("DIP_BENCH_CHILD") is None:
+            import subprocess
+            cmd = [sys.executable, os.path.abspath(__file__), "--instances", "4", "--group", "native", "--mode", "eager",
+                   "--steps", str(max(10, min(args.steps, 30))), "--warmup", "5", "--no-cpu-baseline", "--no-roofline",
+                   "--no-eager-line"]
+            try:
+                r = subprocess.run(cmd, env=dict(os.environ, DIP_BENCH_CHILD="1"), capture_output=True, text=True, timeout=300)
+                ln = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+                if ln:
+                    o = json.loads(ln[-1])
+                    batch4 = {"images_per_gpu": 4, "it_s": o["value"], "ms_per_grouped_iteration": o["ms_per_step"],
+                              "steps": o["steps"], "form": o["config"].get("reported_mode"),
+                              "what": "4 independent 512x512 fits of the headline configuration on this GPU, every kernel launch "
+                                      "serving all four (each fit bit-identical to its solo run, tests/test_group_gpu.py); it_s = all "
+                                      "four fits' iterations / s"}
+                else:
+                    batch4 = {"error": (r.stderr.strip().splitlines() or ["no line"])[-1][:200]}
+            except Exception as e:          # the headline does not depend on it
+                batch4 = {"error": str(e)[:200]}
         cb = None if (args.no_cpu_baseline or world > 1 or args.config != "default") else cpu_baseline()
         its = world * len(fits) * args.steps / tmax
         n_launch = count_kernels(eng)
@@ -1110,7 +1138,8 @@ def main():
             "per_rank_final_loss": [round(v, 6) for v in per_rank_loss],
             "timed_region_power": best.get("power"),
             "roofline": rl, "roofline_wgrad": rw, "roofline_conv3x3_all": r3, "roofline_hbm": rh,
-            "cpu_baseline": cb, "eager_notebook": eager, "fp32_mfma_only": fp32_only, "device": device_info(local),
+            "cpu_baseline": cb, "eager_notebook": eager, "fp32_mfma_only": fp32_only, "grouped_batch_of_4": batch4,
+            "device": device_info(local),
             "host_affinity_rank0": affinity,
         }
         line["config"]["reported_mode"] = ("hipGraph replays" if graphed else "eager launches (main + side + bulk HIP stream)") + \
