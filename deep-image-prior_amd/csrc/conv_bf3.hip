@@ -9,7 +9,8 @@
 // matrix-pipe time, with NO loss of precision -- the only roundings are those of the fp32 accumulation, as in the
 // fp32 MFMA's own fmaf chain.  Measured (tools/ubench/bf16x9.hip, K = 1152): rel-L2 error against fp64 5.3e-7 for this
 // scheme, 6.1e-7 for v_mfma_f32_32x32x2_f32; the inner loop below sustains 235-247 TFLOP/s fp32-equivalent (the fp32 MFMA
-// peak is 157.3, the LDS-DMA fp32 kernel reaches 119).
+// peak is 157.3, the LDS-DMA fp32 kernel reaches 119).  The default (NT = 8) leaves a3 * b3 out: below 2^-32 of a * b, 2^-8 of
+// the rounding error of one accumulation step (see bf3_terms() below).
 //
 // Kernel: implicit GEMM, one workgroup (4 waves) = 8x16 output pixels x 128 output channels, a wave owns 64 x 64 =
 // 2 x 2 accumulators.  K is walked in units = (16-channel chunk, tap) = ONE K = 16 MFMA step: 6 ds_read_b128 (A: 2 pixel

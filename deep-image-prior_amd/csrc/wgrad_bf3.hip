@@ -1,5 +1,6 @@
 // Weight gradient of the 3x3 stride-1 convolutions on the bf16 matrix pipe (the arithmetic of conv_bf3.hip: every fp32
-// operand split exactly into three bf16 terms, all nine cross products -- each exact in fp32 -- accumulated in fp32).
+// operand split exactly into three bf16 terms, the cross products -- each exact in fp32 -- accumulated in fp32: eight of the
+// nine by default, lo x lo (< 2^-32 of a product) left out; NT = 9 sums them all).
 //
 //   dW[tap][c][o] = sum_p  u[p + tap][c] * dy[p][o]            (u = transform(x), as in the forward)
 //

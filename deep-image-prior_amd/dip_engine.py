@@ -136,8 +136,8 @@ class SkipEngine:
         # (the write-through stores, the ticket and the L2-bypassing row loads are three dependent memory round trips at
         # the end of the producer: -1.5 % end to end) -- opt-in
         self.ticket_fin = os.environ.get("DIP_TICKET_FIN") == "1"
-        # bf16 matrix pipe for the big 3x3 layers (csrc/conv_bf3.hip: fp32 operands as three exact bf16 terms, all nine
-        # cross products accumulated in fp32): the library decides per descriptor (DIP_CONV_BF3=9 | 6), the engine only
+        # bf16 matrix pipe for the big 3x3 layers (csrc/conv_bf3.hip: fp32 operands as three exact bf16 terms, the
+        # cross products accumulated in fp32): the library decides per descriptor (DIP_CONV_BF3=8 | 9 | 6 | 0), the engine only
         # keeps the split weight planes up to date
         self.bf3 = False
         self.device = None

@@ -186,10 +186,10 @@ typedef struct DipConvDesc {
     float bnb_slope;
     /* Optional: the same weights as three bf16 planes (DipPackRec3).  When set, dip_conv_igemm runs the 3x3 stride-1 layers
      * with >= 256 tiles on the bf16 matrix pipe: every fp32 operand split EXACTLY into three bf16 terms (8 + 8 + 8
-     * significand bits), all nine cross products -- each exact in fp32 -- accumulated in fp32 by
-     * v_mfma_f32_32x32x16_bf16: the same roundings as an fp32 fmaf chain (measured error vs fp64 below the fp32 MFMA's),
-     * 0.56 of its matrix-pipe time (conv_bf3.hip).  DIP_CONV_BF3=0: fp32 MFMA everywhere; =6: without the three smallest
-     * products (each < 2^-24 of a*b; 0.38 of the time).  NULL: fp32 MFMA. */
+     * significand bits), the cross products -- each exact in fp32 -- accumulated in fp32 by v_mfma_f32_32x32x16_bf16: the
+     * same roundings as an fp32 fmaf chain (measured error vs fp64 below the fp32 MFMA's).  Default: eight of the nine
+     * (lo x lo, < 2^-32 of a*b, is left out; half the fp32 matrix-pipe time, conv_bf3.hip); DIP_CONV_BF3=9: all nine;
+     * =0: fp32 MFMA everywhere; =6: without the three smallest products (each < 2^-24 of a*b).  NULL: fp32 MFMA. */
     const void* wp3;
 } DipConvDesc;
 int dip_conv_igemm(const DipConvDesc* d, void* stream);

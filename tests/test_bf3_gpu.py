@@ -1,4 +1,4 @@
-"""The bf16-matrix-pipe convolution (csrc/conv_bf3.hip: every fp32 operand split exactly into three bf16 terms, all nine
+"""The bf16-matrix-pipe convolution (csrc/conv_bf3.hip: every fp32 operand split exactly into three bf16 terms, the
 cross products accumulated in fp32 by v_mfma_f32_32x32x16_bf16) against a torch-CPU fp64 evaluation of nn.ReflectionPad2d +
 nn.Conv2d (models/common.py:114-124 of the reference) and its autograd data gradient (terms = 8: without the lo x lo product,
 < 2^-32 of a product; terms = 6: the six largest) -- with the SAME per-op criterion as
