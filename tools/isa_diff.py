@@ -4,8 +4,10 @@
     python tools/isa_diff.py old.s new.s
 
 Compares the instruction streams function by function (labels renumbered, comments and assembler directives dropped) and
-prints the kernels that differ or exist on one side only.  Used in round 4 to show that splitting every kernel into a
-`Body::run` + `__global__` wrapper (csrc/dip_group.h: grouped multi-instance launches) left the solo kernels' ISA untouched.
+prints the kernels that differ or exist on one side only.  Used in round 4 to show what the `bool GRP` template parameter
+(csrc/dip_group.h: grouped multi-instance launches; GRP = true kernels are new and skipped here) did to the solo kernels:
+127 of 143 instruction streams identical, the other 16 (streaming / helper kernels whose pointers lost `__restrict__` on
+the way through DIP_GRP_PTR) differ by <= 5 instructions of scheduling.
 """
 import re
 import sys
