@@ -130,17 +130,21 @@ class GroupedFits:
         # --- the slab: a measuring build, the allocation, the real build into row 0
         with self._devctx():
             slab = Slab(device)
-            self._build_row0(slab, Cimg, H, W, t0, m0)
-            self.stride = slab.off                                   # a multiple of 256 by construction
-            del self._x, self._row0_extra
-            self._raw = torch.zeros(B * self.stride + _ALIGN, dtype=torch.uint8, device=device)
-            o = (-self._raw.data_ptr()) % _ALIGN                      # (the device allocator aligns to >= 256 anyway)
-            self.mem = self._raw[o:o + B * self.stride]
-            slab.bind(self.mem[:self.stride])
-            self._build_row0(slab, Cimg, H, W, t0, m0)
-            if slab.off != self.stride:
-                raise RuntimeError("dip-amd GroupedFits: the slab build is not reproducible")
-            eng.slab = None                                          # a later re-plan of nets[0] uses torch's allocator
+            try:
+                self._build_row0(slab, Cimg, H, W, t0, m0)
+                self.stride = slab.off                               # a multiple of 256 by construction
+                del self._x, self._row0_extra
+                self._raw = torch.zeros(B * self.stride + _ALIGN, dtype=torch.uint8, device=device)
+                o = (-self._raw.data_ptr()) % _ALIGN                  # (the device allocator aligns to >= 256 anyway)
+                self.mem = self._raw[o:o + B * self.stride]
+                slab.bind(self.mem[:self.stride])
+                self._build_row0(slab, Cimg, H, W, t0, m0)
+                if slab.off != self.stride:
+                    raise RuntimeError("dip-amd GroupedFits: the slab build is not reproducible")
+            finally:
+                eng.slab = None            # whatever happened: a later (re-)plan of nets[0] uses torch's allocator
+                if not hasattr(self, "mem") or slab.buf is None or slab.off != getattr(self, "stride", -1):
+                    eng.device = None      # ... and a half-built engine state is rebuilt by the next forward
             # --- rows 1..B-1: a copy of row 0 (descriptor tables, constants, zeroed state), then what is the instance's own
             rows = self.mem.view(B, self.stride)
             if B > 1:

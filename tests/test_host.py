@@ -318,9 +318,11 @@ def test_grouped_fits_slab_layout_on_host_memory(built):
         GroupedFits([small(0)], zs[:1], ts[:1], device="cpu")
     with pytest.raises(ValueError, match="architecture"):
         GroupedFits([small(0), skip(8, 3, [16, 32], [16, 32], [4, 4])], zs[:2], ts[:2], device="cpu", _dry_cpu=True)
+    odd = skip(8, 3, [16, 16], [16, 16], [0, 0], pad="reflection")
     with pytest.raises(ValueError, match="net output"):        # without skips an odd size comes out larger than it went in
-        GroupedFits([skip(8, 3, [16, 16], [16, 16], [0, 0], pad="reflection")], [torch.rand(1, 8, 18, 18)],
-                    [torch.rand(1, 3, 18, 18)], device="cpu", _dry_cpu=True)
+        GroupedFits([odd], [torch.rand(1, 8, 18, 18)], [torch.rand(1, 3, 18, 18)], device="cpu", _dry_cpu=True)
+    eng = odd.__dict__["_dip_engine"]
+    assert eng.slab is None and eng.device is None             # a failed construction leaves no allocator / half-built state behind
 
 
 def test_grouped_iteration_issues_its_launch_list_without_a_gpu(built):
