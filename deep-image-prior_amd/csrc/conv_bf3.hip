@@ -37,10 +37,15 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 constexpr int B3_TR_MAX = 512;
 constexpr int B3_CCH = 16;
 
+// BN_ = 128: the form of the big layers (a wave owns 64 pixels x 64 columns).  BN_ = 64: the same tile with 32 columns per wave,
+// i.e. two workgroups per pixel tile -- for layers with < 256 tiles, which 128-column workgroups cannot spread over 256 CUs
+// (round-5 candidate, DESIGN.md section 7 item 0: only reachable with DIP_CONV_BF3_N64=1, not yet run on hardware)
+template <int BN_ = 128>
 struct B3Cfg {
     static constexpr int TH = 8, TW = 16, KS = 3;
     static constexpr int HTH = TH - 1 + KS, HTW = TW - 1 + KS, NPIX = HTH * HTW;      // 10 x 18 = 180
-    static constexpr int WN = 2, WM = 2, MS = 2, NS = 2;
+    static constexpr int BN = BN_;
+    static constexpr int WN = 2, WM = 2, MS = 2, NS = BN_ / 64;
     static constexpr int A_PLANE = NPIX * 32;            // bytes: [pixel][16 bf16]
     static constexpr int A_BYTES = 3 * A_PLANE;
     static constexpr int A_SLOTS = (NPIX * 4 + 255) / 256;      // float4 slots per thread and chunk (3)
@@ -80,11 +85,12 @@ __device__ __forceinline__ void b3_split(float a, unsigned& h, unsigned& m, unsi
 // 0..31 the first 8 k of 32 rows, lanes 32..63 the second 8 -- one contiguous KB per load instruction), 6 loads per unit;
 // the co-resident workgroup and the wave with the same column block read the same lines (vL1D / L2 hits).
 // A fragments are read from LDS one unit ahead as well (the A buffer of a chunk does not change while it is walked).
-template <int NT, int TR>
+template <int NT, int TR, int BN = 128>
 __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(const DipConvDesc d, const int ntx, const int ntiles,
                                                            const int CoutP, const int n_base) {
-    using C = B3Cfg;
+    using C = B3Cfg<BN>;
     constexpr int KK = 9;
+    constexpr int NS = C::NS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Abuf = smem;
     int* srcoff = reinterpret_cast<int*>(smem + 2 * C::A_BYTES);
@@ -96,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(const DipConvDesc d, c
     const int wn = wave & 1, wm = wave >> 1;
     const int tile = dip_xcd_remap(blockIdx.x, ntiles);
     const int ty = tile / ntx, tx = tile - ty * ntx;
-    const int n0 = n_base + blockIdx.y * 128;
+    const int n0 = n_base + blockIdx.y * BN;
 
     for (int hp = tid; hp < C::NPIX; hp += 256) {
         const int hr = hp / C::HTW, hc = hp - hr * C::HTW;
@@ -111,11 +117,11 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(const DipConvDesc d, c
     const int nch = (d.Cin + B3_CCH - 1) / B3_CCH;
     const int nunits = nch * KK;
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NS];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NS; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -185,22 +191,22 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(const DipConvDesc d, c
 
     // ---- B: two register sets (current unit, next unit in flight: a third set / two units ahead measured 2 % slower) of
     // 2 column blocks x 3 planes; per-lane byte offset inside a plane, wave-uniform unit base ----
-    bf16x8 bq[2][2][3];
+    bf16x8 bq[2][NS][3];
 #pragma unroll
     for (int sidx = 0; sidx < 2; ++sidx)
 #pragma unroll
-        for (int ns = 0; ns < 2; ++ns)
+        for (int ns = 0; ns < NS; ++ns)
 #pragma unroll
             for (int p = 0; p < 3; ++p) bq[sidx][ns][p] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned b_voff[2];
+    unsigned b_voff[NS];
 #pragma unroll
-    for (int ns = 0; ns < 2; ++ns) {
-        const int nn = min(n0 + (wn * 2 + ns) * 32 + l31, CoutP - 1);          // columns past CoutP are never stored
+    for (int ns = 0; ns < NS; ++ns) {
+        const int nn = min(n0 + (wn * NS + ns) * 32 + l31, CoutP - 1);          // columns past CoutP are never stored
         b_voff[ns] = (unsigned)(nn * 32 + half * 16);
     }
     const unsigned char* w3 = reinterpret_cast<const unsigned char*>(d.wp3);
     const size_t plane_bytes = (size_t)CoutP * 32;
-    typedef bf16x8 (&BSet)[2][3];
+    typedef bf16x8 (&BSet)[NS][3];
     auto loadB = [&](BSet bs, int tapn, int chn) {
         const unsigned char* ub = w3 + (size_t)(tapn * nch + chn) * 3 * plane_bytes;
 #pragma unroll
@@ -211,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(const DipConvDesc d, c
             const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(b64 >> 32));
             const void* sb = (const void*)(((unsigned long long)hi << 32) | lo);
 #pragma unroll
-            for (int ns = 0; ns < 2; ++ns)
+            for (int ns = 0; ns < NS; ++ns)
                 asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(bs[ns][p]) : "v"(b_voff[ns]), "s"(sb));
         }
     };
@@ -219,11 +225,19 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(const DipConvDesc d, c
     // One unconditional statement with the choice inside (see loadA).
     auto waitB = [&](BSet bs, bool keep3) {
         const int k_s = __builtin_amdgcn_readfirstlane(keep3 ? 1 : 0);
-        asm volatile("s_cmp_eq_u32 %6, 0\n\ts_cbranch_scc1 .Lb3r_w0_%=\n\ts_waitcnt vmcnt(3)\n\ts_branch .Lb3r_we_%=\n"
-                     ".Lb3r_w0_%=:\n\ts_waitcnt vmcnt(0)\n.Lb3r_we_%=:"
-                     : "+v"(bs[0][0]), "+v"(bs[0][1]), "+v"(bs[0][2]), "+v"(bs[1][0]), "+v"(bs[1][1]), "+v"(bs[1][2])
-                     : "s"(k_s)
-                     : "scc");
+        if constexpr (NS == 2) {
+            asm volatile("s_cmp_eq_u32 %6, 0\n\ts_cbranch_scc1 .Lb3r_w0_%=\n\ts_waitcnt vmcnt(3)\n\ts_branch .Lb3r_we_%=\n"
+                         ".Lb3r_w0_%=:\n\ts_waitcnt vmcnt(0)\n.Lb3r_we_%=:"
+                         : "+v"(bs[0][0]), "+v"(bs[0][1]), "+v"(bs[0][2]), "+v"(bs[1][0]), "+v"(bs[1][1]), "+v"(bs[1][2])
+                         : "s"(k_s)
+                         : "scc");
+        } else {
+            asm volatile("s_cmp_eq_u32 %3, 0\n\ts_cbranch_scc1 .Lb3r_w0_%=\n\ts_waitcnt vmcnt(3)\n\ts_branch .Lb3r_we_%=\n"
+                         ".Lb3r_w0_%=:\n\ts_waitcnt vmcnt(0)\n.Lb3r_we_%=:"
+                         : "+v"(bs[0][0]), "+v"(bs[0][1]), "+v"(bs[0][2])
+                         : "s"(k_s)
+                         : "scc");
+        }
     };
     // A fragments of a unit: 2 pixel blocks x 3 planes, read one unit ahead into the other register set (the A buffer of a
     // chunk does not change while the chunk is walked, so this needs no synchronisation beyond the chunk boundary's)
@@ -251,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(const DipConvDesc d, c
 #pragma unroll
                 for (int ms = 0; ms < 2; ++ms)
 #pragma unroll
-                    for (int ns = 0; ns < 2; ++ns)
+                    for (int ns = 0; ns < NS; ++ns)
                         acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[ms][pa], bs[ns][pb], acc[ms][ns], 0, 0, 0);
             }
         }
@@ -261,7 +275,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(const DipConvDesc d, c
     __syncthreads();                    // srcoff / tr tables
     loadA(0, true);
     loadB(bq[0], 0, 0);
-    asm volatile("s_waitcnt vmcnt(6)" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]));       // the halo (the 6 B loads are younger)
+    if constexpr (NS == 2) asm volatile("s_waitcnt vmcnt(6)" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]));       // the halo (the 6 B loads are younger)
+    else asm volatile("s_waitcnt vmcnt(3)" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]));                          // (3 B loads)
     storeA(0, 0);
     waitB(bq[0], false);
     __syncthreads();
@@ -302,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(const DipConvDesc d, c
     // ---- epilogue (conv_epilogue.h) ----
     __syncthreads();
     const DipEpi epi = dip_epi_make(d, ty, tx, C::TH, C::TW);
-    dip_conv_epilogue<C, 128>(d, acc, epi, n0, wn, wm, l31, half, tid, tile, CoutP, reinterpret_cast<float*>(smem));
+    dip_conv_epilogue<C, BN>(d, acc, epi, n0, wn, wm, l31, half, tid, tile, CoutP, reinterpret_cast<float*>(smem));
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -368,10 +383,18 @@ int bf3_terms() {
     return g_bf3_override >= 0 ? g_bf3_override : v;
 }
 
-template <int NT, int TR>
-int bf3_launch(const DipConvDesc& d, int n_base, int ncols, hipStream_t st) {
-    using C = B3Cfg;
-    auto kern = conv_bf3_kernel<NT, TR>;
+// DIP_CONV_BF3_N64=1 (experiment, default off): layers with 96..255 tiles run the 64-column form of
+// the kernel -- two workgroups per pixel tile -- instead of the fp32 split-K kernels
+bool bf3_n64() {
+    static const bool v = getenv("DIP_CONV_BF3_N64") != nullptr;
+    return v;
+}
+constexpr int B3_N64_MIN_TILES = 96;
+
+template <int NT, int TR, int BN>
+int bf3_launch_bn(const DipConvDesc& d, int n_base, int ncols, hipStream_t st) {
+    using C = B3Cfg<BN>;
+    auto kern = conv_bf3_kernel<NT, TR, BN>;
     static bool attr_set[16] = {};
     if (dip_once_per_device(attr_set)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
@@ -379,9 +402,15 @@ int bf3_launch(const DipConvDesc& d, int n_base, int ncols, hipStream_t st) {
     }
     const int ntx = dip_cdiv(d.Wout, C::TW), nty = dip_cdiv(d.Hout, C::TH);
     const int ntiles = ntx * nty;
-    dip_launch(kern, dim3(ntiles, dip_cdiv(ncols, 128)), dim3(256), C::LDS_BYTES, st, d, ntx, ntiles, dip_round_up(d.Cout, 32), n_base);
+    dip_launch(kern, dim3(ntiles, dip_cdiv(ncols, BN)), dim3(256), C::LDS_BYTES, st, d, ntx, ntiles, dip_round_up(d.Cout, 32), n_base);
     DIP_CHECK_LAUNCH();
     return 0;
+}
+
+template <int NT, int TR>
+int bf3_launch(const DipConvDesc& d, int n_base, int ncols, hipStream_t st) {
+    if (bf3_n64() && dip_cdiv(d.Wout, 16) * dip_cdiv(d.Hout, 8) < 256) return bf3_launch_bn<NT, TR, 64>(d, n_base, ncols, st);
+    return bf3_launch_bn<NT, TR, 128>(d, n_base, ncols, st);
 }
 
 }  // namespace
@@ -395,7 +424,13 @@ extern "C" int dip_conv_bf3_eligible(const DipConvDesc* dp) {
     if ((d.Cin & 3) || (d.Cx & 3) || (d.Cy & 3) || d.Cin > d.Cx || d.Cin < 16) return 0;
     if (d.tr.a != nullptr && d.Cin > B3_TR_MAX) return 0;
     if (d.Cout < 128 || d.bnb_y != nullptr) return 0;
-    return dip_cdiv(d.Wout, 16) * dip_cdiv(d.Hout, 8) >= 256 ? 1 : 0;
+    return dip_cdiv(d.Wout, 16) * dip_cdiv(d.Hout, 8) >= (bf3_n64() ? B3_N64_MIN_TILES : 256) ? 1 : 0;
+}
+
+// 1 when DIP_CONV_BF3_N64 asks the planner (dip_conv_plan) for a one-pass plan of a 3x3 stride-1 layer with `ntiles` tiles:
+// it will run on the 64-column form of the bf16-pipe kernel
+extern "C" int dip_conv_bf3_n64_plan(int ntiles, int Cin, int Cout) {
+    return bf3_n64() && bf3_terms() != 0 && ntiles >= B3_N64_MIN_TILES && ntiles < 256 && Cout >= 128 && Cin >= 16 ? 1 : 0;
 }
 
 // columns [n_base, n_base + ncols) of `d` (ncols a multiple of 128, or the rest of the row of blocks)

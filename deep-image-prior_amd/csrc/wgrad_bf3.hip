@@ -322,7 +322,9 @@ extern "C" int dip_wgrad_bf3_eligible(const DipWgradDesc* dp) {
     if (tail >= 1 && tail <= 4 && (d.Cin >> 5) > 8) return 0;            // (dip_conv_wgrad_tail shares the tail among <= 8 chunks)
     const int ntiles = dip_cdiv(d.Wout, 16) * dip_cdiv(d.Hout, 2);
     if (d.nsplit < 1 || d.nsplit > dip_cdiv(d.Wout, 16) * dip_cdiv(d.Hout, 4)) return 0;
-    return ntiles >= 2048 ? 1 : 0;
+    // (DIP_WGRAD_BF3_MIN_TILES: experiment knob for the 128^2 layers; default = the measured crossover)
+    static const int min_tiles = [] { const char* e = getenv("DIP_WGRAD_BF3_MIN_TILES"); return e && atoi(e) > 0 ? atoi(e) : 2048; }();
+    return ntiles >= min_tiles ? 1 : 0;
 }
 
 extern "C" int dip_wgrad_bf3(const DipWgradDesc* dp, void* stream) {

@@ -4,6 +4,8 @@ nn.Conv2d (models/common.py:114-124 of the reference) and its autograd data grad
 < 2^-32 of a product; terms = 6: the six largest) -- with the SAME per-op criterion as
 the fp32-MFMA kernels (error vs fp64 <= 2 x the error of torch's own fp32 CPU kernel): the scheme is fp32-accurate, not a
 reduced-precision mode.  Also asserted: its error is no larger than 1.5 x the fp32-MFMA kernel's own on the same inputs."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -84,6 +86,47 @@ def test_eight_products_are_as_accurate_as_nine(dev):
     # in 2^8 per step, by one ulp of the running sum): far below the scheme's own distance to fp64, which does not move
     assert d89 <= 0.5 * e9, (d89, e9)
     assert abs(e8 - e9) <= 0.03 * e9, (e8, e9)
+
+
+N64_CASES = [
+    # Cin, Cout, pad, H, W, transform   (96..255 tiles of 8 x 16 pixels: the 64-column form, two workgroups per pixel tile)
+    (128, 128, REFLECT, 128, 128, True),      # the 128^2 layers of the default net
+    (132, 128, REFLECT, 128, 128, True),
+    (128, 160, REFLECT, 96, 128, False),      # 96 tiles; 2.5 column blocks of 64
+    (32, 128, ZERO, 100, 120, False),         # ragged tiles
+]
+
+
+@pytest.mark.skipif(os.environ.get("DIP_CONV_BF3_N64") is None,
+                    reason="the 64-column form of the bf16-pipe kernel is an experiment (DESIGN.md 7, item 0): set DIP_CONV_BF3_N64=1")
+@pytest.mark.parametrize("case", N64_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_bf3_n64_forward_dgrad(dev, case):
+    """conv_bf3_kernel<*, *, 64> (DIP_CONV_BF3_N64=1: layers with 96..255 tiles) under the criteria of the 128-column form."""
+    Cin, Cout, pad, Hh, Ww, use_tr = case
+    assert 96 <= N.lib().dip_conv_ntiles(Hh, Ww) < 256
+    x, w, b, a, bb = _mk((Cin, Cout, 3, 1, pad, Hh, Ww, use_tr))
+    slope = 0.2
+    ref64 = _ref_conv(_apply_tr(x, a, bb, slope, torch.float64), w, b, 1, pad, torch.float64)
+    ref32 = _ref_conv(_apply_tr(x, a, bb, slope, torch.float32), w, b, 1, pad, torch.float32)
+    tr = (a.to(dev), bb.to(dev), slope) if use_tr else (None, None, 1.0)
+    y, stats = H.conv_bf3(x.to(dev), w.to(dev), b.to(dev), pad, tr, terms=8)
+    _check("conv_bf3_n64", y, ref64, ref32)
+    st = stats.cpu().double().numpy()
+    n = st[:, 0, :Cout]; m = st[:, 1, :Cout]
+    r = ref64[0].reshape(Cout, -1)
+    assert np.allclose(n.sum(0), r.shape[1])
+    assert np.allclose((n * m).sum(0) / n.sum(0), r.mean(1).numpy(), rtol=1e-5, atol=1e-5 * float(r.std()))
+    if Cin < 128:               # (the data gradient has Cin columns: the bf16 pipe takes >= 128)
+        return
+    res = {}
+    for dt in (torch.float64, torch.float32):
+        xx = x.to(dt).requires_grad_(True)
+        yy = _ref_conv(xx, w, None, 1, pad, dt)
+        dy = torch.randn(yy.shape, generator=torch.Generator().manual_seed(7))
+        (yy * dy.to(dt)).sum().backward()
+        res[dt] = xx.grad
+    gx = H.conv_bf3(dy.to(dev), w.to(dev), None, pad, terms=8, dgrad_of=(Hh, Ww))
+    _check("conv_bf3_n64_dgrad", gx, res[torch.float64], res[torch.float32])
 
 
 def test_split_is_exact(dev):
