@@ -1112,6 +1112,15 @@ def main():
                     batch4 = {"error": (r.stderr.strip().splitlines() or ["no line"])[-1][:200]}
             except Exception as e:          # the headline does not depend on it
                 batch4 = {"error": str(e)[:200]}
+        # BASELINE.md section 4's own protocol next to the driver's short one: 50 warm-up + 300 timed iterations of the
+        # reported mode, power / clock samples of that region (the driver's 20 steps = 0.1 s end before PPT has settled)
+        sustained = None
+        if world == 1 and n_inst == 1 and not args.no_eager_line and os.environ.get("DIP_BENCH_CHILD") is None \
+                and not best["form"].startswith("grouped"):
+            ts, sg, _, spower = timed_run(fits, 300, 50, graphed, lambda: None)
+            sustained = {"it_s": round(len(fits) * 300 / ts, 3), "ms_per_step": round(1e3 * ts / 300, 3), "steps": 300,
+                         "warmup": 50, "hipgraph": sg, "power": spower,
+                         "what": "BASELINE.md section 4 protocol: 50 warm-up + 300 timed iterations, same fit, same mode"}
         cb = None if (args.no_cpu_baseline or world > 1 or args.config != "default") else cpu_baseline()
         its = world * len(fits) * args.steps / tmax
         n_launch = count_kernels(eng)
@@ -1138,6 +1147,7 @@ def main():
             "per_rank_final_loss": [round(v, 6) for v in per_rank_loss],
             "timed_region_power": best.get("power"),
             "roofline": rl, "roofline_wgrad": rw, "roofline_conv3x3_all": r3, "roofline_hbm": rh,
+            "sustained": sustained, "build_id": _N.lib().dip_build_id().decode(),
             "cpu_baseline": cb, "eager_notebook": eager, "fp32_mfma_only": fp32_only, "grouped_batch_of_4": batch4,
             "device": device_info(local),
             "host_affinity_rank0": affinity,

@@ -14,6 +14,16 @@ extern "C" void dip_set_error(const char* msg) {
 extern "C" const char* dip_last_error(void) { return g_err; }
 extern "C" int dip_abi_version(void) { return DIP_ABI_VERSION; }
 
+// sha256 (first 16 hex digits) over the library's sources -- every csrc/*.hip, csrc/*.h and include/dip_hip.h, names and
+// contents in sorted order -- handed in by the one build recipe (__graft_entry__.py: -DDIP_BUILD_ID=...).  build() rebuilds
+// when the id in the binary differs from the id of the sources on disk (not on mtimes), and bench.py prints it in its JSON
+// line: a record of a run names the sources that produced the binary that ran.
+#ifndef DIP_BUILD_ID
+#define DIP_BUILD_ID "unknown"
+#endif
+static const char g_build_id[] = "DIP_BUILD_ID=" DIP_BUILD_ID;
+extern "C" const char* dip_build_id(void) { return g_build_id + 13; }
+
 // PCI address ("0000:d9:00.0") of HIP device `device` as THIS library's HIP runtime enumerates it: what a host-side
 // monitor needs to find the GPU's sysfs directory (/sys/bus/pci/devices/<address>: hwmon power / clocks, numa_node) --
 // the position among /sys/class/drm/card* says nothing in a container that sees every card of the host.

@@ -586,13 +586,16 @@ class SkipEngine:
                     (_ptr(self.wg_scratch), _ptr(self.wgb_scratch) if has_b else None, nsplit, r.ks, r.Cin, r.Cout,
                      _ptr(self.grads, r.w_off), _ptr(self.grads, r.b_off) if has_b else None), "wgred:" + r.name))
 
-    def _emit_dgrad(self, r: ConvRec, x: Act, dy, ops, accumulate_into=None, fuse_bn=False):
+    def _emit_dgrad(self, r: ConvRec, x: Act, dy, ops, accumulate_into=None, fuse_bn=False, need_pad=0):
         """Data gradient of conv r wrt its input x.  Returns a DipGradSrc-describing tuple
         (buf, pad, fold).  accumulate_into = (buf, pad): add the gradient into an existing (padded)
         gradient buffer of the same input (skip-branch conv next to down_a).
         fuse_bn: x is consumed by this conv only, so the launch's output is the complete gradient wrt x's BatchNorm
         (+activation) output: phase 1 of that BatchNorm's backward rides in the launch's epilogue (DipConvDesc.bnb_*)
-        when the launch is a one-pass one, and _emit_bn_act_bwd skips its statistics pass (self._fused_bnb)."""
+        when the launch is a one-pass one, and _emit_bn_act_bwd skips its statistics pass (self._fused_bnb).
+        need_pad: a later accumulate_into launch (the scale's skip conv, filter_skip_size > 1 with reflection /
+        replication padding) needs this gradient buffer on a domain padded by at least that much, so the interior +
+        ring form (pad 0) must not be chosen."""
         Ho = (x.H + 2 * r.P - r.ks) // r.stride + 1
         Wo = (x.W + 2 * r.P - r.ks) // r.stride + 1
         reflect = r.pad_mode in (N.PAD_REFLECT, N.PAD_REPLICATE) and r.P > 0      # gradient on the PADDED domain, folded later
@@ -621,7 +624,7 @@ class SkipEngine:
             ops.append((self.lib.dip_conv_small if small else self.lib.dip_conv_igemm, (C.byref(d),), "dgrad+:" + r.name))
             return accumulate_into
         ring = False
-        if reflect and r.pad_mode == N.PAD_REFLECT and r.ks == 3 and r.stride == 1 and self.use_small:
+        if reflect and r.pad_mode == N.PAD_REFLECT and r.ks == 3 and r.stride == 1 and self.use_small and need_pad == 0:
             # interior domain + a frame launch instead of the padded domain (dip_conv_dgrad_ring): no lonely second round
             # of tiles at 256^2 (561 -> 512), and the gradient buffer needs no fold
             di = N.DipConvDesc(None, Ho, Wo, round_up(r.Cout, 4), round_up(r.Cout, 4), N.DipTransform(None, None, 1.0), None,
@@ -863,7 +866,9 @@ class SkipEngine:
             dy_d1 = dy_full
         self._emit_wgrad(s.down_a, xin, dy_d1, ops, scale=i)
         tgt = ops if i > 0 else self.bwd_input_ops
-        g = self._emit_dgrad(s.down_a, xin, dy_d1, tgt)
+        sk = s.skip_conv if s.ns else None
+        sk_pad = sk.P if (sk is not None and sk.P > 0 and sk.pad_mode in (N.PAD_REFLECT, N.PAD_REPLICATE)) else 0
+        g = self._emit_dgrad(s.down_a, xin, dy_d1, tgt, need_pad=sk_pad)
         if s.ns:
             g = self._emit_dgrad(s.skip_conv, xin, dy_s, tgt, accumulate_into=g)
         s.gin = g

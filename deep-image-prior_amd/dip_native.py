@@ -97,6 +97,7 @@ class DipLossHeadDesc(C.Structure):
 
 _SIGS = {
     "dip_abi_version": (C.c_int, []),
+    "dip_build_id": (C.c_char_p, []),
     "dip_last_error": (C.c_char_p, []),
     "dip_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "dip_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),

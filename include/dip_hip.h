@@ -39,6 +39,10 @@ extern "C" {
 #define DIP_UP_BILINEAR 1
 
 int dip_abi_version(void);
+/* First 16 hex digits of the sha256 over the sources this binary was built from (csrc/*.hip, csrc/*.h, this header; see
+ * __graft_entry__.source_id()); "unknown" for a build outside the recipe.  No reference counterpart: provenance of a
+ * measured binary (VERDICT r04 next #9c). */
+const char* dip_build_id(void);
 const char* dip_last_error(void);
 /* PCI address ("0000:d9:00.0", lower case hex) of HIP device `device`, for locating its sysfs directory
  * (/sys/bus/pci/devices/<address>: hwmon power / clock sensors, numa_node).  No reference counterpart: bench.py's

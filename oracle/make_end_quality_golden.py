@@ -1,6 +1,6 @@
 """CPU arms of the BASELINE.json configs[1] end-quality check, produced by the REAL reference.
 
-    python oracle/make_end_quality_golden.py [--task sr|inpaint] <size> <iters> <threads>[:<perturb>[:<grad_noise>]] [...]
+    python oracle/make_end_quality_golden.py [--task sr|inpaint] [--reg0] <size> <iters> <threads>[:<perturb>[:<grad_noise>]] [...]
 
 --task sr / inpaint (BASELINE.json configs[2] / [3]): the super-resolution closure (super-resolution.ipynb:169-199: the
 loss goes through the reference's Downsampler, PSNR on the full-resolution output) and the masked closure
@@ -38,6 +38,10 @@ def main():
     if sys.argv[1] == "--task":
         task = sys.argv[2]
         del sys.argv[1:3]
+    reg0 = False
+    if sys.argv[1] == "--reg0":               # bisect arms: the same fits without the reg-noise path (file ..._reg0.json)
+        reg0 = True
+        del sys.argv[1]
     size, iters = int(sys.argv[1]), int(sys.argv[2])
     specs = []
     for t in sys.argv[3:] or [str(os.cpu_count())]:
@@ -48,8 +52,10 @@ def main():
     RU = _refload.load_ref_common_utils()
     import end_quality_cpu as E     # problem(), run_fit(): shared with the GPU arm
     assert task in E.TASKS, task
-    path = os.path.join(ROOT, "tests", "golden", f"end_quality_{size}_{iters}.json" if task == "denoise" else
-                        f"end_quality_{task}_{size}_{iters}.json")
+    if reg0:
+        E.REG_SCALE = 0.0
+    path = os.path.join(ROOT, "tests", "golden", (f"end_quality_{size}_{iters}" if task == "denoise" else
+                        f"end_quality_{task}_{size}_{iters}") + ("_reg0" if reg0 else "") + ".json")
     arms = json.load(open(path))["cpu_arms"] if os.path.exists(path) else []
     for th, perturb, gnoise in specs:
         torch.set_num_threads(th)

@@ -92,6 +92,10 @@ def build(size=None, task="denoise", skip_fn=None, get_net_fn=None, get_noise_fn
 
 
 GRAD_NOISE = float(os.environ.get("EQ_GRAD_NOISE", "0"))     # relative gradient perturbation (tools: noise-floor experiment)
+REG_SCALE = float(os.environ.get("EQ_REG_SCALE", "1"))       # bisect arms: 0 = the fit without the reg-noise path
+DEVICE_NOISE = os.environ.get("EQ_DEVICE_NOISE", "0") == "1"  # reg-noise from the DEVICE generator (HIP-vs-HIP arms at 512^2: a host
+#                                                               draw + copy of 33.5 MB per iteration would dominate the fit)
+CURVE_EVERY = 50                                             # loss(t): mean over each window of 50 iterations
 
 
 def run_fit(net_call, params_step, z, noisy, clean, iters, device, exp_weight=0.99, params=None, task="denoise", down=None):
@@ -112,11 +116,16 @@ def run_fit(net_call, params_step, z, noisy, clean, iters, device, exp_weight=0.
     else:
         tgt = torch.from_numpy(noisy)[None].to(device)
     mse = torch.nn.MSELoss()
-    st = {"i": 0, "avg": None, "loss": None, "tail": [], "ltail": []}
-    reg = REG_OF[task]
+    st = {"i": 0, "avg": None, "loss": None, "tail": [], "ltail": [], "curve": []}
+    reg = REG_OF[task] * REG_SCALE
+
+    dgen = torch.Generator(device=device).manual_seed(77) if (DEVICE_NOISE and str(device) != "cpu") else None
 
     def closure():
-        noise = torch.randn(z.shape, generator=gen) * reg
+        if dgen is not None:
+            noise = torch.randn(z.shape, generator=dgen, device=device) * reg
+        else:
+            noise = torch.randn(z.shape, generator=gen) * reg
         out = net_call(zt + noise.to(device))
         st["avg"] = out.detach() if st["avg"] is None else st["avg"] * exp_weight + out.detach() * (1 - exp_weight)
         if task == "sr":
@@ -132,6 +141,7 @@ def run_fit(net_call, params_step, z, noisy, clean, iters, device, exp_weight=0.
                     p.grad.mul_(1.0 + GRAD_NOISE * torch.randn(p.grad.shape, generator=ngen).to(p.grad.device))
         st["i"] += 1
         st["loss"] = loss.detach()
+        st["curve"].append(st["loss"])          # device scalars, read back once after the fit (no per-iteration sync)
         if st["i"] > iters - TAIL:              # single-iteration PSNR jitters by ~1 dB: average the tail
             st["tail"].append(O.psnr(clean, out.detach().cpu().numpy()[0]))
             st["ltail"].append(float(loss.detach().item()))
@@ -140,8 +150,12 @@ def run_fit(net_call, params_step, z, noisy, clean, iters, device, exp_weight=0.
     t0 = time.time()
     params_step(closure)
     # loss_tail: the SR / inpainting fits end at ~1e-4, where the loss of ONE iteration is reg-noise jitter (+-30 %)
+    sec = time.time() - t0
+    lc = torch.stack([c.reshape(()) for c in st["curve"]]).double().cpu().numpy()
+    curve = [float(lc[k:k + CURVE_EVERY].mean()) for k in range(0, len(lc) - CURVE_EVERY + 1, CURVE_EVERY)]
     return {"psnr_gt": float(np.mean(st["tail"])), "psnr_gt_sm": O.psnr(clean, st["avg"].cpu().numpy()[0]),
-            "loss": float(st["loss"].item()), "loss_tail": float(np.mean(st["ltail"])), "sec": time.time() - t0}
+            "loss": float(st["loss"].item()), "loss_tail": float(np.mean(st["ltail"])),
+            "loss_last100": float(lc[-100:].mean()), "loss_curve": curve, "reg_scale": REG_SCALE, "sec": sec}
 
 
 def perturb_one_weight(params, k):

@@ -325,6 +325,24 @@ def test_grouped_fits_slab_layout_on_host_memory(built):
     assert eng.slab is None and eng.device is None             # a failed construction leaves no allocator / half-built state behind
 
 
+def test_padded_skip_conv_next_to_a_stride1_down_conv_builds(built):
+    """skip(..., filter_skip_size=3, pad='reflection') with a stride-1 down conv (downsample_mode
+    avg / max / lanczos2) at a size where down_a's data gradient would take the interior + ring form (pad 0): the skip
+    conv's gradient is accumulated into down_a's buffer on the PADDED domain, so the ring form must not be chosen there
+    (dip_engine._emit_dgrad need_pad).  Dry build of the launch list on host memory (nothing is launched); the gradients of
+    this configuration are checked on the GPU by tests/test_net_gpu.py::test_golden_reference_vectors[net_tiny_skip3]."""
+    from models.skip import skip
+    from dip_group import GroupedFits
+    for mode in ("avg", "max", "lanczos2", "stride"):
+        torch.manual_seed(0)
+        net = skip(8, 3, [16, 32], [16, 32], [4, 4], filter_skip_size=3, downsample_mode=mode, pad="reflection",
+                   upsample_mode="bilinear")
+        g = GroupedFits([net], [torch.rand(1, 8, 128, 128)], [torch.rand(1, 3, 128, 128)], device="cpu", _dry_cpu=True)
+        names = [op[2] for op in g.engine.bwd_ops] if hasattr(g, "engine") else []
+        assert g.pointers_outside_row0() == []
+        del g, names
+
+
 def test_grouped_iteration_issues_its_launch_list_without_a_gpu(built):
     """The host side of one grouped iteration end to end, without a GPU: every launch of the list goes through the real
     C ABI (argument marshalling, dispatch, the slab range check) and fails at hipLaunchKernel with "no ROCm-capable device"

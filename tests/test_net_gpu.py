@@ -242,6 +242,42 @@ def test_against_oracle_fresh_seed(dev, hw, mode, nskip, down):
     assert psnr >= 100.0 and rel <= 1e-5 and worst <= 1.0, (psnr, rel, worst, wk)
 
 
+@pytest.mark.parametrize("down", ["avg", "stride"])
+def test_reflected_3x3_skip_conv_next_to_down_a_128(dev, down):
+    """filter_skip_size = 3 with reflection padding at 128x128 -- the size at which down_a's data
+    gradient would take the interior + ring form; the skip conv's gradient is accumulated on the padded domain
+    (dip_engine._emit_dgrad need_pad).  models/skip.py:47-57 of the reference; all gradients against the oracle."""
+    from models.skip import skip
+    torch.manual_seed(321)
+    hw = (128, 128)
+    kw = dict(num_channels_down=[32, 64], num_channels_up=[32, 64], num_channels_skip=[4, 8], filter_skip_size=3,
+              upsample_mode="bilinear", downsample_mode=down, need_sigmoid=True, need_bias=True, pad="reflection")
+    net = skip(16, 3, **kw)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()
+          if not k.endswith(("running_mean", "running_var", "num_batches_tracked"))}
+    z = torch.rand(1, 16, *hw) * 0.1
+    target = torch.rand(1, 3, *hw)
+    spec = O.SkipSpec(16, 3, [32, 64], [32, 64], [4, 8], filter_skip_size=3, pad="reflection", upsample_mode="bilinear",
+                      downsample_mode=down)
+    lf = lambda o_, dt: torch.nn.functional.mse_loss(o_, target.to(dt))
+    zrec = {}
+    _, _, g64n = _oracle_grads(spec, sd, z, lf, torch.float64, zrec=zrec)
+    oo, lo, g32 = _oracle_grads(spec, sd, z, lf, torch.float32)
+    net = net.to(dev)
+    out = net(z.to(dev))
+    loss = torch.nn.functional.mse_loss(out, target.to(dev))
+    loss.backward()
+    torch.cuda.synchronize()
+    import hipops
+    hmasks = hipops.lrelu_masks(net, spec)
+    _, _, g64 = _oracle_grads(spec, sd, z, lf, torch.float64, hmasks)
+    psnr = _psnr(out.detach().cpu().numpy(), oo.numpy())
+    rel = abs(loss.item() - lo) / lo
+    worst, wk = _grad_report({k: p.grad for k, p in net.named_parameters()}, g64, g32, g64n, spec, sd, masks=hmasks, zrec=zrec)
+    print(f"skip3 {down} 128x128: PSNR {psnr:.1f} dB, loss rel {rel:.2e}, grad err/tol {worst:.2f} ({wk})")
+    assert psnr >= 100.0 and rel <= 1e-5 and worst <= 1.0, (psnr, rel, worst, wk)
+
+
 def test_fused_batchnorm_backward_statistics_engine_path(dev):
     """Opt-in engine path (DIP_BNB_FUSE=1 / SkipEngine.fuse_bnb): BatchNorm-backward statistics computed in the
     epilogue of the data-gradient launches (DipConvDesc.bnb_*: LDS-DMA conv kernel, conv_thin4 for the 4 thin columns
@@ -480,20 +516,26 @@ HIP_ARMS = [({}, 0),
             ({}, 1), ({}, 2)]
 
 
-def _hip_arms(size, iters, tmp_path, arms_spec=None, task="denoise"):
+def _hip_arms(size, iters, tmp_path, arms_spec=None, task="denoise", family="hip", extra_env=None):
     """The HIP fit once per environment in HIP_ARMS (each changes the summation order of some kernels and nothing
-    else), every arm in a process of its own: the HIP-vs-HIP spread is the yard-stick next to the CPU-vs-CPU one."""
+    else), every arm in a process of its own: the HIP-vs-HIP spread is the yard-stick next to the CPU-vs-CPU one.
+    Up to DIP_EQ_PAR (default 4) arms share the GPU at a time: the fits are bitwise deterministic functions of the code
+    and the environment (fixed-order reductions, no float atomics), so co-scheduling changes their wall time only."""
     import subprocess
     import sys
+    from concurrent.futures import ThreadPoolExecutor
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "end_quality_hip.py")
-    arms = []
-    for k, (env, perturb) in enumerate(arms_spec or HIP_ARMS):
-        out = str(tmp_path / f"hip_{k}.json")
-        r = subprocess.run([sys.executable, script, str(size), str(iters), out, str(perturb), task], env=dict(os.environ, **env),
-                           capture_output=True, text=True, timeout=3000)
+
+    def one(job):
+        k, (env, perturb) = job
+        out = str(tmp_path / f"{family}_{task}_{k}.json")
+        r = subprocess.run([sys.executable, script, str(size), str(iters), out, str(perturb), task, family],
+                           env=dict(os.environ, **env, **(extra_env or {})), capture_output=True, text=True, timeout=3000)
         assert r.returncode == 0, r.stderr[-3000:]
-        arms.append(json.load(open(out)))
-    return arms
+        return json.load(open(out))
+
+    with ThreadPoolExecutor(max_workers=int(os.environ.get("DIP_EQ_PAR", "4"))) as ex:
+        return list(ex.map(one, enumerate(arms_spec or HIP_ARMS)))
 
 
 def _compare_end_quality(tag, hip, cpu):
