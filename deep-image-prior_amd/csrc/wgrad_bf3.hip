@@ -60,8 +60,8 @@ __device__ __forceinline__ void w3_split(float a, unsigned& h, unsigned& m, unsi
 }
 
 template <int NT, int TR>
-__global__ __launch_bounds__(256, 2) void wgrad_bf3_kernel(const DipWgradDesc d, const int ntx, const int ntiles, const int CinP,
-                                                           const int CoutP) {
+__global__ __launch_bounds__(256, 2) void wgrad_bf3_v1_kernel(const DipWgradDesc d, const int ntx, const int ntiles, const int CinP,
+                                                              const int CoutP) {
     using C = W3Cfg;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Us = smem;                               // [3][32 c][208 B]
@@ -282,9 +282,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf3_kernel(const DipWgradDesc d,
 }
 
 template <int NT, int TR>
-int w3_launch(const DipWgradDesc& d, hipStream_t st) {
+int w3_launch_v1(const DipWgradDesc& d, hipStream_t st) {
     using C = W3Cfg;
-    auto kern = wgrad_bf3_kernel<NT, TR>;
+    auto kern = wgrad_bf3_v1_kernel<NT, TR>;
     static bool attr_set[16] = {};
     int dev = 0;
     hipGetDevice(&dev);
@@ -301,6 +301,290 @@ int w3_launch(const DipWgradDesc& d, hipStream_t st) {
     static const int lds_req = [] { const char* e = getenv("DIP_WGRAD_BF3_LDS"); return e ? atoi(e) : 0; }();
     const int lds = lds_req > C::LDS_BYTES ? lds_req : C::LDS_BYTES;
     dip_launch(kern, dim3(d.nsplit, nfull, dip_cdiv(CoutP, 128)), dim3(256), lds, st, d, ntx, ntx * nty, CinP, CoutP);
+    DIP_CHECK_LAUNCH();
+    return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 5: the same arithmetic, bit for bit (same walkers, same tiles per walker, same order of MFMAs per accumulator), as a
+// PING-PONG of two wave groups.  Counters on the round-4 kernel: matrix pipes busy 0.55.  Its two co-resident workgroups fall
+// into step -- both in their MFMA bursts at half rate each, then both in their staging phase (transform, exact split,
+// transposition: ~1500 cycles of vector ALU per 4608-cycle tile) with the pipes idle -- and lock-step is stable: whoever runs
+// ahead shares the pipe until the other has caught up.  Here ONE workgroup of 8 waves owns a CU: group g = wave / 4 owns the
+// 32 input channels c0 + 32 g (its own nine accumulators per wave, its own partial-slab rows: what a round-4 workgroup owned),
+// both groups share the staged dy tile, and the groups alternate by construction: in half-period h group (h & 1) runs the
+// MFMAs of tile h / 2 out of LDS buffer (h / 2) & 1 while the other group stages ITS share of the next tile (its 32 channels
+// of u, half of dy) into the other buffer; one barrier per half-period.  A SIMD holds one wave of each group, so its matrix
+// pipe always has exactly one wave feeding it, and the staging -- a quarter of the MFMA time -- hides completely.
+//   * dy is transformed / split once per 64 input channels instead of once per 32;
+//   * the A windows are walked by HALO ROW (row hr serves tap row ky = hr of tile row 0 and ky = hr - 1 of tile row 1: 4 row
+//     loads per tile instead of 6), the next row's windows are read under the current row's MFMAs;
+//   * LDS: 2 x (3 x 64 x 208 + 3 x 128 x 80) B = 138 KB + tables.
+template <int NT, int TR>
+__global__ __launch_bounds__(512) void wgrad_bf3_kernel(const DipWgradDesc d, const int ntx, const int ntiles, const int CinP,
+                                                        const int CoutP) {
+    using C = W3Cfg;
+    constexpr int U_PLANE2 = 64 * C::U_CH;                       // 13312: 64 channels per workgroup
+    constexpr int BUF = 3 * U_PLANE2 + 3 * C::D_PLANE;           // 70656
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* tra = reinterpret_cast<float*>(smem + 2 * BUF);
+    float* trb = tra + 64;
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wq = wave & 3, tg = tid & 255;
+    const int walker = blockIdx.x, nwalk = gridDim.x;
+    const int c0 = blockIdx.y * 64 + grp * 32;                   // this group's 32 input channels
+    const int o0 = blockIdx.z * 128;
+    const bool wave_active = (o0 + wq * 32) < CoutP;
+    const bool do_bias = d.bias_partial != nullptr && blockIdx.y == 0;
+    const float slope = d.tr.slope;
+
+    if (TR) {
+        if (tid < 64) {
+            const int c = blockIdx.y * 64 + tid;
+            const bool ok = c < d.Cin;
+            tra[tid] = ok ? d.tr.a[c] : 1.f;
+            trb[tid] = ok ? d.tr.b[c] : 0.f;
+        }
+    }
+    for (int i = tid; i < 2 * BUF / 4; i += 512) reinterpret_cast<unsigned*>(smem)[i] = 0u;     // pad bytes / pixels 18..23: no NaN patterns
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};                          // bias gradient of this thread's 4 dy channels
+
+    // ---- staging slots ----------------------------------------------------------------------------------------------
+    // u (per group, its 32 channels): slot s = tg + 256 i < 288 -> (4-channel group cg = s / 36, halo row (s % 36) / 9, pixel pair s % 9)
+    // dy (whole workgroup): slot = tid -> (4-channel group cg = tid / 16 (0..31), tile row (tid % 16) / 8, pixel pair tid % 8)
+    f32x4 ur[2][2], dr[2];
+    auto fetch = [&](int tile) {
+        const int ty = tile / ntx, tx = tile - ty * ntx;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int s = tg + i * 256;
+            const int cg = s / 36, rem = s - cg * 36, hr = rem / 9, pp = rem - hr * 9;
+            const int c = c0 + cg * 4;
+            const int sr = w3_map_src(ty * C::TH + hr - d.off, d.Hin, d.pad_mode);
+            const bool okc = s < C::U_PAIRS && c < d.Cin && sr >= 0;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int sc = w3_map_src(tx * C::TW + 2 * pp + q - d.off, d.Win, d.pad_mode);
+                const bool ok = okc && sc >= 0;
+                ur[i][q] = *reinterpret_cast<const f32x4*>(d.x + ((size_t)(ok ? sr : 0) * d.Win + (ok ? sc : 0)) * d.Cx + (ok ? c : 0));
+            }
+        }
+        {
+            const int cg = tid >> 4, rem = tid & 15, r = rem >> 3, pp = rem & 7;
+            const int o = o0 + cg * 4;
+            const int oy = ty * C::TH + r;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int ox = tx * C::TW + 2 * pp + q;
+                const bool ok = oy < d.Hout && ox < d.Wout && o < d.Cdy;
+                dr[q] = *reinterpret_cast<const f32x4*>(d.dy + ((size_t)(ok ? oy : 0) * d.Wout + (ok ? ox : 0)) * d.Cdy + (ok ? o : 0));
+            }
+        }
+    };
+    auto commit = [&](int tile, int buf) {
+        const int ty = tile / ntx, tx = tile - ty * ntx;
+        unsigned char* Us = smem + buf * BUF;
+        unsigned char* Ds = Us + 3 * U_PLANE2;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int s = tg + i * 256;
+            if (s < C::U_PAIRS) {
+                const int cg = s / 36, rem = s - cg * 36, hr = rem / 9, pp = rem - hr * 9;
+                const int c = c0 + cg * 4;
+                const int sr = w3_map_src(ty * C::TH + hr - d.off, d.Hin, d.pad_mode);
+                unsigned h[2][4], m[2][4], l[2][4];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int sc = w3_map_src(tx * C::TW + 2 * pp + q - d.off, d.Win, d.pad_mode);
+                    const bool ok = c < d.Cin && sr >= 0 && sc >= 0;
+                    f32x4 v = ur[i][q];
+                    if (TR) {
+                        const f32x4 a4 = *reinterpret_cast<const f32x4*>(tra + grp * 32 + cg * 4);
+                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(trb + grp * 32 + cg * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float tv = fmaf(a4[e], v[e], b4[e]);
+                            v[e] = TR == 1 ? dip_act_leaky(tv, slope) : dip_act(tv, slope);
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w3_split(ok ? v[e] : 0.f, h[q][e], m[q][e], l[q][e]);
+                }
+                unsigned char* base = Us + (grp * 32 + cg * 4) * C::U_CH + hr * C::U_ROW + pp * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    *reinterpret_cast<unsigned*>(base + e * C::U_CH) = (h[0][e] >> 16) | h[1][e];
+                    *reinterpret_cast<unsigned*>(base + e * C::U_CH + U_PLANE2) = (m[0][e] >> 16) | m[1][e];
+                    *reinterpret_cast<unsigned*>(base + e * C::U_CH + 2 * U_PLANE2) = (l[0][e] >> 16) | l[1][e];
+                }
+            }
+        }
+        {
+            const int cg = tid >> 4, rem = tid & 15, r = rem >> 3, pp = rem & 7;
+            const int o = o0 + cg * 4;
+            const int oy = ty * C::TH + r;
+            unsigned h[2][4], m[2][4], l[2][4];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int ox = tx * C::TW + 2 * pp + q;
+                const bool ok = oy < d.Hout && ox < d.Wout && o < d.Cdy;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = ok ? dr[q][e] : 0.f;
+                    bs[e] += v;
+                    w3_split(v, h[q][e], m[q][e], l[q][e]);
+                }
+            }
+            unsigned char* base = Ds + (cg * 4) * C::D_CH + r * C::D_ROW + pp * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                *reinterpret_cast<unsigned*>(base + e * C::D_CH) = (h[0][e] >> 16) | h[1][e];
+                *reinterpret_cast<unsigned*>(base + e * C::D_CH + C::D_PLANE) = (m[0][e] >> 16) | m[1][e];
+                *reinterpret_cast<unsigned*>(base + e * C::D_CH + 2 * C::D_PLANE) = (l[0][e] >> 16) | l[1][e];
+            }
+        }
+    };
+
+    // ---- the MFMAs of one tile out of buffer `buf`, by halo row ----
+    const int ua_off = (grp * 32 + l31) * C::U_CH + 16 * half;                   // channel l31 of the group, pixels 8 * half ..
+    const int da_off = 3 * U_PLANE2 + (wq * 32 + l31) * C::D_CH + 16 * half;     // output channel of this lane
+    auto mfma_tile = [&](int buf) {
+        const unsigned char* ua = smem + buf * BUF + ua_off;
+        const unsigned char* da = smem + buf * BUF + da_off;
+        bf16x8 b[2][3];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) b[s][p] = *reinterpret_cast<const bf16x8*>(da + p * C::D_PLANE + s * C::D_ROW);
+        u32x4 w0[2][3];
+        unsigned w1[2][3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            w0[0][p] = *reinterpret_cast<const u32x4*>(ua + p * U_PLANE2);
+            w1[0][p] = *reinterpret_cast<const unsigned*>(ua + p * U_PLANE2 + 16);
+        }
+#pragma unroll
+        for (int hr = 0; hr < 4; ++hr) {
+            const int cur = hr & 1, nxt = cur ^ 1;
+            if (hr < 3) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    w0[nxt][p] = *reinterpret_cast<const u32x4*>(ua + p * U_PLANE2 + (hr + 1) * C::U_ROW);
+                    w1[nxt][p] = *reinterpret_cast<const unsigned*>(ua + p * U_PLANE2 + (hr + 1) * C::U_ROW + 16);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {               // tile row s reads halo row hr as its tap row ky = hr - s
+                const int ky = hr - s;
+                if (ky < 0 || ky > 2) continue;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    bf16x8 a[3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        const u32x4 q0 = w0[cur][p];
+                        const unsigned q1 = w1[cur][p];
+                        u32x4 v;
+                        if (kx == 0) v = q0;
+                        else if (kx == 2) v = u32x4{q0[1], q0[2], q0[3], q1};
+                        else v = u32x4{__builtin_amdgcn_alignbyte(q0[1], q0[0], 2), __builtin_amdgcn_alignbyte(q0[2], q0[1], 2),
+                                       __builtin_amdgcn_alignbyte(q0[3], q0[2], 2), __builtin_amdgcn_alignbyte(q1, q0[3], 2)};
+                        a[p] = __builtin_bit_cast(bf16x8, v);
+                    }
+                    const int t = ky * 3 + kx;
+#pragma unroll
+                    for (int sm = 4; sm >= 0; --sm) {               // smallest partial products first
+                        if ((NT == 6 && sm > 2) || (NT == 8 && sm > 3)) continue;
+#pragma unroll
+                        for (int pa = 0; pa < 3; ++pa) {
+                            const int pb = sm - pa;
+                            if (pb < 0 || pb > 2) continue;
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa], b[s][pb], acc[t], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);          // one halo row at a time (hoisting more windows spills the accumulators)
+        }
+    };
+
+    // ---- prologue: both groups stage their share of the first tile; the second tile's loads go into flight ----
+    __syncthreads();                       // tables + zeroed LDS
+    const int ntl = walker < ntiles ? (ntiles - 1 - walker) / nwalk + 1 : 0;        // tiles of this walker
+    if (ntl > 0) {
+        fetch(walker);
+        commit(walker, 0);
+        if (ntl > 1) fetch(walker + nwalk);
+    }
+    __syncthreads();
+    // half-period h: group (h & 1) multiplies tile h / 2, the other group stages its share of tile h / 2 + 1
+    for (int h = 0; h < 2 * ntl; ++h) {
+        const int kt = h >> 1, buf = kt & 1;
+        if ((h & 1) == grp) {
+            if (wave_active) {
+                __builtin_amdgcn_s_setprio(2);
+                mfma_tile(buf);
+                __builtin_amdgcn_s_setprio(0);
+            }
+        } else if (kt + 1 < ntl) {
+            commit(walker + (kt + 1) * nwalk, buf ^ 1);
+            if (kt + 2 < ntl) fetch(walker + (kt + 2) * nwalk);          // in flight under this group's next MFMA phase
+        }
+        __syncthreads();
+    }
+
+    // ---- this group's rows c0 .. c0 + 31 of partial slab `walker` ----
+    if (wave_active) {
+        const int o = o0 + wq * 32 + l31;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (c < CinP) d.partial[(((size_t)walker * 9 + t) * CinP + c) * CoutP + o] = acc[t][r];
+            }
+    }
+    if (do_bias) {
+        // thread (cg, tile row, pixel pair): sum over the 16 threads that share a channel group, through LDS
+        float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[tid * 4 + e] = bs[e];
+        __syncthreads();
+        if (tid < 128 && o0 + tid < CoutP) {
+            const int cg = tid >> 2, e = tid & 3;
+            float sum = 0.f;
+            for (int k = 0; k < 16; ++k) sum += red[(cg * 16 + k) * 4 + e];
+            d.bias_partial[(size_t)walker * CoutP + o0 + tid] = sum;
+        }
+    }
+}
+
+template <int NT, int TR>
+int w3_launch(const DipWgradDesc& d, hipStream_t st) {
+    using C = W3Cfg;
+    constexpr int LDS2 = 2 * (3 * 64 * C::U_CH + 3 * C::D_PLANE) + 2 * 64 * 4;
+    auto kern = wgrad_bf3_kernel<NT, TR>;
+    static bool attr_set[16] = {};
+    int dev = 0;
+    hipGetDevice(&dev);
+    if (dev >= 0 && dev < 16 && !attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { dip_set_error(hipGetErrorString(e)); return (int)e; }
+        attr_set[dev] = true;
+    }
+    const int ntx = dip_cdiv(d.Wout, C::TW), nty = dip_cdiv(d.Hout, C::TH);
+    const int CinP = dip_round_up(d.Cin, 32), CoutP = dip_round_up(d.Cout, 32);
+    const int nfull = ((d.Cin & 31) >= 1 && (d.Cin & 31) <= 4 && d.Cin > 32) ? (d.Cin >> 5) : dip_cdiv(d.Cin, 32);
+    dip_launch(kern, dim3(d.nsplit, dip_cdiv(nfull, 2), dip_cdiv(CoutP, 128)), dim3(512), LDS2, st, d, ntx, ntx * nty, CinP, CoutP);
     DIP_CHECK_LAUNCH();
     return 0;
 }
@@ -334,6 +618,14 @@ extern "C" int dip_wgrad_bf3(const DipWgradDesc* dp, void* stream) {
     if (nt == 0) DIP_FAIL("wgrad_bf3: the bf16-pipe arithmetic is switched off (DIP_CONV_BF3=0)");
     const int tr = d.tr.a == nullptr ? 0 : (d.tr.slope > 0.f ? 1 : 2);
     int rc;
+    // DIP_WGRAD_BF3_V1=1: the round-4 kernel (two workgroups of 4 waves per CU), kept for this round's A/B and the
+    // bit-identity test of the ping-pong form against it
+    static const bool v1 = getenv("DIP_WGRAD_BF3_V1") != nullptr;
+    if (v1) {
+        if (nt == 6) rc = tr == 0 ? w3_launch_v1<6, 0>(d, st) : (tr == 1 ? w3_launch_v1<6, 1>(d, st) : w3_launch_v1<6, 2>(d, st));
+        else if (nt == 8) rc = tr == 0 ? w3_launch_v1<8, 0>(d, st) : (tr == 1 ? w3_launch_v1<8, 1>(d, st) : w3_launch_v1<8, 2>(d, st));
+        else rc = tr == 0 ? w3_launch_v1<9, 0>(d, st) : (tr == 1 ? w3_launch_v1<9, 1>(d, st) : w3_launch_v1<9, 2>(d, st));
+    } else
     if (nt == 6) rc = tr == 0 ? w3_launch<6, 0>(d, st) : (tr == 1 ? w3_launch<6, 1>(d, st) : w3_launch<6, 2>(d, st));
     else if (nt == 8) rc = tr == 0 ? w3_launch<8, 0>(d, st) : (tr == 1 ? w3_launch<8, 1>(d, st) : w3_launch<8, 2>(d, st));
     else rc = tr == 0 ? w3_launch<9, 0>(d, st) : (tr == 1 ? w3_launch<9, 1>(d, st) : w3_launch<9, 2>(d, st));

@@ -186,3 +186,24 @@ def test_wgrad_bf3(dev, case, terms):
     e3 = (dw.cpu().double() - res[torch.float64][0]).pow(2).sum().sqrt().item()
     e32 = (dw32.cpu().double() - res[torch.float64][0]).pow(2).sum().sqrt().item()
     assert e3 <= 1.5 * e32, f"bf16-pipe error {e3:.3e} vs fp32-MFMA error {e32:.3e}"
+
+
+def test_wgrad_bf3_pingpong_is_bit_identical_to_the_round4_kernel(dev, tmp_path):
+    """Round 5: wgrad_bf3_kernel as a ping-pong of two wave groups (one 8-wave workgroup per CU, staging of one group under
+    the MFMAs of the other) walks the same tiles in the same order with the same MFMA sequence per accumulator as the
+    round-4 kernel (DIP_WGRAD_BF3_V1=1): dW and db must agree BIT FOR BIT on every case, including an odd number of
+    32-channel chunks, a partial chunk, two column blocks and ragged tiles (tests/wgrad_bf3_probe.py)."""
+    import subprocess
+    import sys
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "wgrad_bf3_probe.py")
+    out = {}
+    for tag, env in (("new", {}), ("v1", {"DIP_WGRAD_BF3_V1": "1"})):
+        o = str(tmp_path / f"{tag}.npz")
+        r = subprocess.run([sys.executable, probe, o], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        out[tag] = np.load(o)
+    assert sorted(out["new"].files) == sorted(out["v1"].files) and len(out["new"].files) == 16
+    for k in out["new"].files:
+        a, b = out["new"][k], out["v1"][k]
+        assert np.isfinite(a).all(), k
+        assert np.array_equal(a, b), (k, float(np.abs(a.astype(np.float64) - b).max()))
