@@ -523,8 +523,10 @@ EQ_FAMILY_PERTURBS = (0, 1, 2, 4, 5, 6, 8, 9)
 def _hip_arms(size, iters, tmp_path, arms_spec=None, task="denoise", family="hip", extra_env=None):
     """The HIP fit once per environment in HIP_ARMS (each changes the summation order of some kernels and nothing
     else), every arm in a process of its own: the HIP-vs-HIP spread is the yard-stick next to the CPU-vs-CPU one.
-    Up to DIP_EQ_PAR (default 4) arms share the GPU at a time: the fits are bitwise deterministic functions of the code
-    and the environment (fixed-order reductions, no float atomics), so co-scheduling changes their wall time only."""
+    One arm at a time by default (DIP_EQ_PAR=1): measured in round 5 (profiles/r05_eq_families_call1.jsonl), EIGHT processes
+    sharing the MI355X took 300 s per 128x128 fit instead of 22 s -- 24 HIP streams time-slicing the hardware queues cost more
+    than they overlap.  (The fits are bitwise deterministic functions of code + environment, so co-scheduling would change
+    their wall time only.)"""
     import subprocess
     import sys
     from concurrent.futures import ThreadPoolExecutor
@@ -538,7 +540,7 @@ def _hip_arms(size, iters, tmp_path, arms_spec=None, task="denoise", family="hip
         assert r.returncode == 0, r.stderr[-3000:]
         return json.load(open(out))
 
-    with ThreadPoolExecutor(max_workers=int(os.environ.get("DIP_EQ_PAR", "4"))) as ex:
+    with ThreadPoolExecutor(max_workers=int(os.environ.get("DIP_EQ_PAR", "1"))) as ex:
         return list(ex.map(one, enumerate(arms_spec or HIP_ARMS)))
 
 
