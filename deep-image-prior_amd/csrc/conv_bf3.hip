@@ -39,7 +39,7 @@ constexpr int B3_CCH = 16;
 
 // BN_ = 128: the form of the big layers (a wave owns 64 pixels x 64 columns).  BN_ = 64: the same tile with 32 columns per wave,
 // i.e. two workgroups per pixel tile -- for layers with < 256 tiles, which 128-column workgroups cannot spread over 256 CUs
-// (round-5 candidate, DESIGN.md section 7 item 0: only reachable with DIP_CONV_BF3_N64=1, not yet run on hardware)
+// (round 5: 128^2 layers 66-85 us on the fp32 split-K kernels -> this form, +1.9 % per iteration; profiles/r05_ab_n64.txt)
 template <int BN_ = 128>
 struct B3Cfg {
     static constexpr int TH = 8, TW = 16, KS = 3;
@@ -383,12 +383,8 @@ int bf3_terms() {
     return g_bf3_override >= 0 ? g_bf3_override : v;
 }
 
-// DIP_CONV_BF3_N64=1 (experiment, default off): layers with 96..255 tiles run the 64-column form of
-// the kernel -- two workgroups per pixel tile -- instead of the fp32 split-K kernels
-bool bf3_n64() {
-    static const bool v = getenv("DIP_CONV_BF3_N64") != nullptr;
-    return v;
-}
+// layers with 96..255 tiles (the 128^2 layers of the default net) run the 64-column form of the kernel -- two workgroups per
+// pixel tile -- instead of the fp32 split-K kernels
 constexpr int B3_N64_MIN_TILES = 96;
 
 template <int NT, int TR, int BN>
@@ -409,14 +405,14 @@ int bf3_launch_bn(const DipConvDesc& d, int n_base, int ncols, hipStream_t st) {
 
 template <int NT, int TR>
 int bf3_launch(const DipConvDesc& d, int n_base, int ncols, hipStream_t st) {
-    if (bf3_n64() && dip_cdiv(d.Wout, 16) * dip_cdiv(d.Hout, 8) < 256) return bf3_launch_bn<NT, TR, 64>(d, n_base, ncols, st);
+    if (dip_cdiv(d.Wout, 16) * dip_cdiv(d.Hout, 8) < 256) return bf3_launch_bn<NT, TR, 64>(d, n_base, ncols, st);
     return bf3_launch_bn<NT, TR, 128>(d, n_base, ncols, st);
 }
 
 }  // namespace
 
 // 1 when dip_conv_igemm runs `d` on the bf16 matrix pipe (d->wp3 set; DIP_CONV_BF3=0 switches it off, =6 drops three terms): 3x3, stride 1, dil 1, one pass,
-// >= 256 tiles (the layers that are MFMA-bound), at least one full 128-column block
+// >= 96 tiles (128 columns per workgroup from 256 tiles, 64 below), at least one full 128-column block
 extern "C" int dip_conv_bf3_eligible(const DipConvDesc* dp) {
     const DipConvDesc& d = *dp;
     if (bf3_terms() == 0 || d.wp3 == nullptr) return 0;
@@ -424,13 +420,13 @@ extern "C" int dip_conv_bf3_eligible(const DipConvDesc* dp) {
     if ((d.Cin & 3) || (d.Cx & 3) || (d.Cy & 3) || d.Cin > d.Cx || d.Cin < 16) return 0;
     if (d.tr.a != nullptr && d.Cin > B3_TR_MAX) return 0;
     if (d.Cout < 128 || d.bnb_y != nullptr) return 0;
-    return dip_cdiv(d.Wout, 16) * dip_cdiv(d.Hout, 8) >= (bf3_n64() ? B3_N64_MIN_TILES : 256) ? 1 : 0;
+    return dip_cdiv(d.Wout, 16) * dip_cdiv(d.Hout, 8) >= B3_N64_MIN_TILES ? 1 : 0;
 }
 
-// 1 when DIP_CONV_BF3_N64 asks the planner (dip_conv_plan) for a one-pass plan of a 3x3 stride-1 layer with `ntiles` tiles:
-// it will run on the 64-column form of the bf16-pipe kernel
+// 1 when the planner (dip_conv_plan) must give a 3x3 stride-1 layer with `ntiles` tiles a one-pass plan because it will run
+// on the 64-column form of the bf16-pipe kernel
 extern "C" int dip_conv_bf3_n64_plan(int ntiles, int Cin, int Cout) {
-    return bf3_n64() && bf3_terms() != 0 && ntiles >= B3_N64_MIN_TILES && ntiles < 256 && Cout >= 128 && Cin >= 16 ? 1 : 0;
+    return bf3_terms() != 0 && ntiles >= B3_N64_MIN_TILES && ntiles < 256 && Cout >= 128 && Cin >= 16 ? 1 : 0;
 }
 
 // columns [n_base, n_base + ncols) of `d` (ncols a multiple of 128, or the rest of the row of blocks)

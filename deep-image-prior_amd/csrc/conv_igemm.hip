@@ -486,7 +486,7 @@ int units_of(int Cin, int ks, int stride) {
 }  // namespace
 
 extern "C" int dip_conv_ntiles(int Hout, int Wout) { return dip_cdiv(Wout, 16) * dip_cdiv(Hout, 8); }
-extern "C" int dip_conv_bf3_n64_plan(int ntiles, int Cin, int Cout);       // conv_bf3.hip (DIP_CONV_BF3_N64 experiment)
+extern "C" int dip_conv_bf3_n64_plan(int ntiles, int Cin, int Cout);       // conv_bf3.hip
 
 // Launch plan of one convolution: split-K factor, rows of the BatchNorm partial buffer, and the
 // split-K workspace size in floats (0 when ksplit == 1).
@@ -518,7 +518,7 @@ extern "C" int dip_conv_plan(int Hout, int Wout, int Cin, int Cout, int ks, int 
         if (kmin > units / 2) kmin = units / 2;
         if (k < kmin) k = kmin;
     }
-    // (experiment, default off: DIP_CONV_BF3_N64 sends these layers to the 64-column bf16-pipe kernel in one pass)
+    // 96..255 tiles: the 64-column bf16-pipe kernel, one pass
     if (ks == 3 && stride == 1 && dip_conv_bf3_n64_plan(ntiles, dip_round_up(Cin, 4), Cout)) k = 1;
     const int Cy = dip_round_up(Cout, 4);
     *ksplit = k;

@@ -296,11 +296,7 @@ int w3_launch_v1(const DipWgradDesc& d, hipStream_t st) {
     const int ntx = dip_cdiv(d.Wout, C::TW), nty = dip_cdiv(d.Hout, C::TH);
     const int CinP = dip_round_up(d.Cin, 32), CoutP = dip_round_up(d.Cout, 32);
     const int nfull = ((d.Cin & 31) >= 1 && (d.Cin & 31) <= 4 && d.Cin > 32) ? (d.Cin >> 5) : dip_cdiv(d.Cin, 32);
-    // DIP_WGRAD_BF3_LDS=<bytes>: ask for more LDS than the kernel uses, so that fewer workgroups of this (bulk-stream) launch
-    // fit on a CU and the main chain's kernels find free slots next to it (experiment)
-    static const int lds_req = [] { const char* e = getenv("DIP_WGRAD_BF3_LDS"); return e ? atoi(e) : 0; }();
-    const int lds = lds_req > C::LDS_BYTES ? lds_req : C::LDS_BYTES;
-    dip_launch(kern, dim3(d.nsplit, nfull, dip_cdiv(CoutP, 128)), dim3(256), lds, st, d, ntx, ntx * nty, CinP, CoutP);
+    dip_launch(kern, dim3(d.nsplit, nfull, dip_cdiv(CoutP, 128)), dim3(256), C::LDS_BYTES, st, d, ntx, ntx * nty, CinP, CoutP);
     DIP_CHECK_LAUNCH();
     return 0;
 }
@@ -595,7 +591,8 @@ extern "C" int dip_conv_bf3_terms(void);
 extern "C" int dip_conv_wgrad_tail(const DipWgradDesc* dp, void* stream);
 
 // 1 when dip_conv_wgrad runs `d` on the bf16 matrix pipe: 3x3, stride 1, >= 32 input channels, one tap group, one slab per
-// walker, and a layer large enough to be MFMA-bound (>= 2048 tiles of 2 x 16 pixels = 256 x 256)
+// walker, and >= 512 tiles of 2 x 16 pixels (128 x 128; round 5: the 128^2 layers' weight gradients 59-78 us on the fp32
+// kernel -> here, +1.3 % per iteration, profiles/r05_ab_n64.txt)
 extern "C" int dip_wgrad_bf3_eligible(const DipWgradDesc* dp) {
     const DipWgradDesc& d = *dp;
     static const bool off = getenv("DIP_WGRAD_NO_BF3") != nullptr;
@@ -606,9 +603,7 @@ extern "C" int dip_wgrad_bf3_eligible(const DipWgradDesc* dp) {
     if (tail >= 1 && tail <= 4 && (d.Cin >> 5) > 8) return 0;            // (dip_conv_wgrad_tail shares the tail among <= 8 chunks)
     const int ntiles = dip_cdiv(d.Wout, 16) * dip_cdiv(d.Hout, 2);
     if (d.nsplit < 1 || d.nsplit > dip_cdiv(d.Wout, 16) * dip_cdiv(d.Hout, 4)) return 0;
-    // (DIP_WGRAD_BF3_MIN_TILES: experiment knob for the 128^2 layers; default = the measured crossover)
-    static const int min_tiles = [] { const char* e = getenv("DIP_WGRAD_BF3_MIN_TILES"); return e && atoi(e) > 0 ? atoi(e) : 2048; }();
-    return ntiles >= min_tiles ? 1 : 0;
+    return ntiles >= 512 ? 1 : 0;
 }
 
 extern "C" int dip_wgrad_bf3(const DipWgradDesc* dp, void* stream) {
@@ -618,9 +613,13 @@ extern "C" int dip_wgrad_bf3(const DipWgradDesc* dp, void* stream) {
     if (nt == 0) DIP_FAIL("wgrad_bf3: the bf16-pipe arithmetic is switched off (DIP_CONV_BF3=0)");
     const int tr = d.tr.a == nullptr ? 0 : (d.tr.slope > 0.f ? 1 : 2);
     int rc;
-    // DIP_WGRAD_BF3_V1=1: the round-4 kernel (two workgroups of 4 waves per CU), kept for this round's A/B and the
-    // bit-identity test of the ping-pong form against it
-    static const bool v1 = getenv("DIP_WGRAD_BF3_V1") != nullptr;
+    // Two forms of the kernel.  >= 2048 tiles (256 x 256 and up): the ping-pong of two wave groups, one 8-wave workgroup per
+    // CU.  512 .. 2047 tiles (the 128^2 layers: 64 walkers x 4 channel chunks = 256 workgroups, ONE per CU, so there is no
+    // co-resident workgroup to fall into step with, and 64-channel workgroups would leave half the chip empty): the 4-wave
+    // form.  DIP_WGRAD_BF3_V1=1 forces the 4-wave form everywhere: the bit-identity test of the two forms
+    // (tests/test_bf3_gpu.py) and the A/B.
+    static const bool force_v1 = getenv("DIP_WGRAD_BF3_V1") != nullptr;
+    const bool v1 = force_v1 || dip_cdiv(d.Wout, 16) * dip_cdiv(d.Hout, 2) < 2048;
     if (v1) {
         if (nt == 6) rc = tr == 0 ? w3_launch_v1<6, 0>(d, st) : (tr == 1 ? w3_launch_v1<6, 1>(d, st) : w3_launch_v1<6, 2>(d, st));
         else if (nt == 8) rc = tr == 0 ? w3_launch_v1<8, 0>(d, st) : (tr == 1 ? w3_launch_v1<8, 1>(d, st) : w3_launch_v1<8, 2>(d, st));

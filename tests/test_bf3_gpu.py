@@ -97,11 +97,9 @@ N64_CASES = [
 ]
 
 
-@pytest.mark.skipif(os.environ.get("DIP_CONV_BF3_N64") is None,
-                    reason="the 64-column form of the bf16-pipe kernel is an experiment (DESIGN.md 7, item 0): set DIP_CONV_BF3_N64=1")
 @pytest.mark.parametrize("case", N64_CASES, ids=lambda c: "x".join(map(str, c)))
 def test_conv_bf3_n64_forward_dgrad(dev, case):
-    """conv_bf3_kernel<*, *, 64> (DIP_CONV_BF3_N64=1: layers with 96..255 tiles) under the criteria of the 128-column form."""
+    """conv_bf3_kernel<*, *, 64> (layers with 96..255 tiles: the 128^2 layers) under the criteria of the 128-column form."""
     Cin, Cout, pad, Hh, Ww, use_tr = case
     assert 96 <= N.lib().dip_conv_ntiles(Hh, Ww) < 256
     x, w, b, a, bb = _mk((Cin, Cout, 3, 1, pad, Hh, Ww, use_tr))
@@ -143,7 +141,9 @@ def test_split_is_exact(dev):
 
 
 WGRAD_BF3_CASES = [
-    # Cin, Cout, pad, H, W, transform   (>= 2048 tiles of 2 x 16 pixels)
+    # Cin, Cout, pad, H, W, transform   (>= 2048 tiles of 2 x 16 pixels: the ping-pong form; 512 .. 2047: the 4-wave form)
+    (128, 128, REFLECT, 128, 128, True),      # the 128^2 layers of the default net (round 5: on the bf16 pipe too)
+    (132, 128, REFLECT, 128, 128, True),
     (128, 128, REFLECT, 256, 256, True),
     (132, 128, REFLECT, 256, 256, True),      # four full chunks on the bf16 pipe + the 4-channel tail (dip_conv_wgrad_tail)
     (48, 160, ZERO, 250, 280, False),         # a 16-channel partial chunk, two 128-column blocks, ragged tiles, zero padding

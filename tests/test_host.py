@@ -86,8 +86,10 @@ def test_launch_plans_of_the_round2_kernels(built):
     assert 1 < k <= 4 and wsf == k * 130 * 130 * 128                             # bounded by the 1-tap phase's 4 chunks
     assert N.conv_plan_dil2(258, 258, 128, 32, 3)[0] == N.conv_plan(258, 258, 128, 32, 3, 1)[0]   # not whole 128-blocks
     assert N.conv_plan_dil2(260, 260, 128, 128, 5)[0] == N.conv_plan(260, 260, 128, 128, 5, 1)[0]  # 5x5: dilated path
-    # split-K fills one round of 2 workgroups per CU
-    assert N.conv_plan(128, 128, 128, 128, 3, 1)[0] == 4 and N.conv_plan(128, 128, 128, 128, 3, 2)[0] == 4
+    # split-K fills one round of 2 workgroups per CU; round 5: a 3x3 stride-1 layer with 96 .. 255 tiles and >= 128 columns runs
+    # the 64-column form of the bf16-pipe kernel in ONE pass (two workgroups per pixel tile)
+    assert N.conv_plan(128, 128, 128, 128, 3, 1)[0] == 1 and N.conv_plan(128, 128, 128, 128, 3, 2)[0] == 4
+    assert N.conv_plan(128, 128, 128, 64, 3, 1)[0] == 4             # < 128 columns: the fp32 split-K kernel as before
     # weight gradient: nsplit counts SLABS; narrow layers write 4 / 2 per workgroup (waves split the K steps)
     n16 = N.wgrad_plan2(224, 352, 16, 16, 3, 1)[0]
     n64 = N.wgrad_plan2(224, 352, 16, 64, 3, 1)[0]
