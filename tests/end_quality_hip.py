@@ -3,7 +3,7 @@
 environment switches that change the summation order of the kernels (read once per process:
 DIP_TWO_STREAMS, DIP_CONV_PLAN_WGS, DIP_WGRAD_NO_SLIDE, DIP_CONV_NO_DMA ...) can differ between arms.
 
-    python tests/end_quality_hip.py <size> <iters> <out.json> [<perturb> [<task> [<family>]]]
+    python tests/end_quality_hip.py <size> <iters> <out.json> [<perturb>[,<perturb>...] [<task> [<family>]]]
 
 <task> = denoise (default) | sr | inpaint: the closures of the three notebooks (tests/end_quality_cpu.run_fit).
 <family> = hip (default: this package's net, optimize() and Downsampler) or one of the bisect families of DESIGN.md
@@ -35,15 +35,12 @@ ge.build()
 import end_quality_cpu as E  # noqa: E402
 
 
-def main():
-    size, iters, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+def one_fit(size, iters, perturb, task, family):
     from utils.common_utils import get_params, optimize
     dev = torch.device("cuda:0")
-    task = sys.argv[5] if len(sys.argv) > 5 else "denoise"
     clean, noisy = E.problem(size, task)
     net, z = E.build(size, task)
-    E.perturb_one_weight(net.parameters(), int(sys.argv[4]) if len(sys.argv) > 4 else 0)
-    family = sys.argv[6] if len(sys.argv) > 6 else "hip"
+    E.perturb_one_weight(net.parameters(), perturb)
     down = None
 
     def torch_down():
@@ -84,11 +81,25 @@ def main():
             assert family in ("hip", "hip_torchloss"), family
             step = lambda c: optimize("adam", get_params("net", net, None), c, 0.01, iters)
         res = E.run_fit(net, step, z, noisy, clean, iters, dev, task=task, down=down)
-    res["task"], res["family"], res["perturb"] = task, family, int(sys.argv[4]) if len(sys.argv) > 4 else 0
+    res["task"], res["family"], res["perturb"] = task, family, perturb
     res["env"] = {k: v for k, v in os.environ.items() if k.startswith("DIP_")}
+    return res
+
+
+def main():
+    size, iters, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+    # <perturb> may be a comma list: the fits run one after the other in THIS process (the environment is the same for all of
+    # them; saves the interpreter / library start-up per arm) and <out.json> holds the list
+    perturbs = [int(x) for x in (sys.argv[4] if len(sys.argv) > 4 else "0").split(",")]
+    task = sys.argv[5] if len(sys.argv) > 5 else "denoise"
+    family = sys.argv[6] if len(sys.argv) > 6 else "hip"
+    res = []
+    for p in perturbs:
+        res.append(one_fit(size, iters, p, task, family))
+        print(json.dumps(res[-1]), flush=True)
+        torch.cuda.empty_cache()
     with open(out, "w") as f:
-        json.dump(res, f)
-    print(json.dumps(res))
+        json.dump(res if len(perturbs) > 1 else res[0], f)
 
 
 if __name__ == "__main__":
