@@ -59,6 +59,42 @@ __device__ __forceinline__ void w3_split(float a, unsigned& h, unsigned& m, unsi
     h = uh; m = um; l = __float_as_uint(r2) & 0xFFFF0000u;
 }
 
+// The three horizontal taps of one (tile row, tap row) out of the 16-byte-aligned windows w0 (8 pixels) + w1 (2 more) of a halo
+// row, all partial products, smallest first.  The three taps' accumulators take turns MFMA by MFMA: v_mfma_f32_32x32x16_bf16
+// issues every 32 cycles but its result feeds a DEPENDENT MFMA only after ~64 (16 passes), so a run of MFMAs on ONE
+// accumulator -- how round 4's kernel walked the products of a tap -- runs the matrix pipe at half rate (round 5: 515 us at
+// 512^2 in both the 4-wave and the ping-pong form = 0.46 of the pipe; conv_bf3 rotates four accumulators and never saw it).
+// Per accumulator the order of the products is unchanged, so the result is bit-identical.
+template <int NT>
+__device__ __forceinline__ void w3_taps_of_row(const u32x4 (&w0)[3], const unsigned (&w1)[3], const bf16x8 (&b)[3], f32x16& acc0,
+                                               f32x16& acc1, f32x16& acc2) {
+    bf16x8 a[3][3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        a[0][p] = __builtin_bit_cast(bf16x8, w0[p]);
+        a[1][p] = __builtin_bit_cast(bf16x8, u32x4{__builtin_amdgcn_alignbyte(w0[p][1], w0[p][0], 2), __builtin_amdgcn_alignbyte(w0[p][2], w0[p][1], 2),
+                                                     __builtin_amdgcn_alignbyte(w0[p][3], w0[p][2], 2), __builtin_amdgcn_alignbyte(w1[p], w0[p][3], 2)});
+        a[2][p] = __builtin_bit_cast(bf16x8, u32x4{w0[p][1], w0[p][2], w0[p][3], w1[p]});
+    }
+#pragma unroll
+    for (int sm = 4; sm >= 0; --sm) {               // smallest partial products first
+        if ((NT == 6 && sm > 2) || (NT == 8 && sm > 3)) continue;
+#pragma unroll
+        for (int pa = 0; pa < 3; ++pa) {
+            const int pb = sm - pa;
+            if (pb < 0 || pb > 2) continue;
+            // (sched_barrier 0x7F6: everything but MFMAs may cross -- hipcc's scheduler, whose latency model does not know the
+            // 64 cycles, otherwise puts MFMAs on the same accumulator back to back again)
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][pa], b[pb], acc0, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0x7F6);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][pa], b[pb], acc1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0x7F6);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][pa], b[pb], acc2, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0x7F6);
+        }
+    }
+}
+
 template <int NT, int TR>
 __global__ __launch_bounds__(256, 2) void wgrad_bf3_v1_kernel(const DipWgradDesc d, const int ntx, const int ntiles, const int CinP,
                                                               const int CoutP) {
@@ -482,32 +518,7 @@ __global__ __launch_bounds__(512) void wgrad_bf3_kernel(const DipWgradDesc d, co
             for (int s = 0; s < 2; ++s) {               // tile row s reads halo row hr as its tap row ky = hr - s
                 const int ky = hr - s;
                 if (ky < 0 || ky > 2) continue;
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    bf16x8 a[3];
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) {
-                        const u32x4 q0 = w0[cur][p];
-                        const unsigned q1 = w1[cur][p];
-                        u32x4 v;
-                        if (kx == 0) v = q0;
-                        else if (kx == 2) v = u32x4{q0[1], q0[2], q0[3], q1};
-                        else v = u32x4{__builtin_amdgcn_alignbyte(q0[1], q0[0], 2), __builtin_amdgcn_alignbyte(q0[2], q0[1], 2),
-                                       __builtin_amdgcn_alignbyte(q0[3], q0[2], 2), __builtin_amdgcn_alignbyte(q1, q0[3], 2)};
-                        a[p] = __builtin_bit_cast(bf16x8, v);
-                    }
-                    const int t = ky * 3 + kx;
-#pragma unroll
-                    for (int sm = 4; sm >= 0; --sm) {               // smallest partial products first
-                        if ((NT == 6 && sm > 2) || (NT == 8 && sm > 3)) continue;
-#pragma unroll
-                        for (int pa = 0; pa < 3; ++pa) {
-                            const int pb = sm - pa;
-                            if (pb < 0 || pb > 2) continue;
-                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa], b[s][pb], acc[t], 0, 0, 0);
-                        }
-                    }
-                }
+                w3_taps_of_row<NT>(w0[cur], w1[cur], b[s], acc[ky * 3], acc[ky * 3 + 1], acc[ky * 3 + 2]);
             }
             __builtin_amdgcn_sched_barrier(0);          // one halo row at a time (hoisting more windows spills the accumulators)
         }
@@ -613,13 +624,9 @@ extern "C" int dip_wgrad_bf3(const DipWgradDesc* dp, void* stream) {
     if (nt == 0) DIP_FAIL("wgrad_bf3: the bf16-pipe arithmetic is switched off (DIP_CONV_BF3=0)");
     const int tr = d.tr.a == nullptr ? 0 : (d.tr.slope > 0.f ? 1 : 2);
     int rc;
-    // Two forms of the kernel.  >= 2048 tiles (256 x 256 and up): the ping-pong of two wave groups, one 8-wave workgroup per
-    // CU.  512 .. 2047 tiles (the 128^2 layers: 64 walkers x 4 channel chunks = 256 workgroups, ONE per CU, so there is no
-    // co-resident workgroup to fall into step with, and 64-channel workgroups would leave half the chip empty): the 4-wave
-    // form.  DIP_WGRAD_BF3_V1=1 forces the 4-wave form everywhere: the bit-identity test of the two forms
-    // (tests/test_bf3_gpu.py) and the A/B.
-    static const bool force_v1 = getenv("DIP_WGRAD_BF3_V1") != nullptr;
-    const bool v1 = force_v1 || dip_cdiv(d.Wout, 16) * dip_cdiv(d.Hout, 2) < 2048;
+    // DIP_WGRAD_BF3_V1=1: the round-4 form of the kernel (4 waves, two workgroups per CU, one accumulator at a time), kept as
+    // the REFERENCE of the bit-identity test (tests/test_bf3_gpu.py) and for A/B runs; never taken otherwise.
+    static const bool v1 = getenv("DIP_WGRAD_BF3_V1") != nullptr;
     if (v1) {
         if (nt == 6) rc = tr == 0 ? w3_launch_v1<6, 0>(d, st) : (tr == 1 ? w3_launch_v1<6, 1>(d, st) : w3_launch_v1<6, 2>(d, st));
         else if (nt == 8) rc = tr == 0 ? w3_launch_v1<8, 0>(d, st) : (tr == 1 ? w3_launch_v1<8, 1>(d, st) : w3_launch_v1<8, 2>(d, st));
