@@ -29,6 +29,18 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef DIP_W3_PROFILE
+// per-wave cycle sums of the ping-pong kernel's phases (s_memtime ticks = shader cycles): [workgroup][wave][8]
+//   0 MFMA phases, 1 barrier waits after an MFMA phase, 2 commit (transform + split + LDS writes), 3 fetch issue,
+//   4 barrier waits after a staging phase, 5 half-periods, 6 whole kernel, 7 prologue
+__device__ unsigned long long g_w3_prof[1024 * 8 * 8];
+#define W3_T() __builtin_amdgcn_s_memtime()
+#define W3_ADD(slot, t0, t1) prof[slot] += (t1) - (t0)
+#else
+#define W3_T() 0ull
+#define W3_ADD(slot, t0, t1) ((void)0)
+#endif
+
 struct W3Cfg {
     static constexpr int TH = 2, TW = 16;                   // output pixels per tile: two K = 16 steps
     static constexpr int HTH = TH + 2, HTW = TW + 2;        // 4 x 18 halo
@@ -525,6 +537,10 @@ __global__ __launch_bounds__(512) void wgrad_bf3_kernel(const DipWgradDesc d, co
     };
 
     // ---- prologue: both groups stage their share of the first tile; the second tile's loads go into flight ----
+#ifdef DIP_W3_PROFILE
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    const unsigned long long tk0 = W3_T();
     __syncthreads();                       // tables + zeroed LDS
     const int ntl = walker < ntiles ? (ntiles - 1 - walker) / nwalk + 1 : 0;        // tiles of this walker
     if (ntl > 0) {
@@ -533,21 +549,46 @@ __global__ __launch_bounds__(512) void wgrad_bf3_kernel(const DipWgradDesc d, co
         if (ntl > 1) fetch(walker + nwalk);
     }
     __syncthreads();
+    W3_ADD(7, tk0, W3_T());
     // half-period h: group (h & 1) multiplies tile h / 2, the other group stages its share of tile h / 2 + 1
     for (int h = 0; h < 2 * ntl; ++h) {
         const int kt = h >> 1, buf = kt & 1;
+        const unsigned long long t0 = W3_T();
         if ((h & 1) == grp) {
             if (wave_active) {
                 __builtin_amdgcn_s_setprio(2);
                 mfma_tile(buf);
                 __builtin_amdgcn_s_setprio(0);
             }
-        } else if (kt + 1 < ntl) {
-            commit(walker + (kt + 1) * nwalk, buf ^ 1);
-            if (kt + 2 < ntl) fetch(walker + (kt + 2) * nwalk);          // in flight under this group's next MFMA phase
+            const unsigned long long t1 = W3_T();
+            __syncthreads();
+            W3_ADD(0, t0, t1);
+            W3_ADD(1, t1, W3_T());
+        } else {
+            unsigned long long t1 = t0, t2 = t0;
+            if (kt + 1 < ntl) {
+                commit(walker + (kt + 1) * nwalk, buf ^ 1);
+                t1 = W3_T();
+                if (kt + 2 < ntl) fetch(walker + (kt + 2) * nwalk);          // in flight under this group's next MFMA phase
+                t2 = W3_T();
+            }
+            __syncthreads();
+            W3_ADD(2, t0, t1);
+            W3_ADD(3, t1, t2);
+            W3_ADD(4, t2, W3_T());
         }
-        __syncthreads();
+#ifdef DIP_W3_PROFILE
+        prof[5] += 1;
+#endif
     }
+#ifdef DIP_W3_PROFILE
+    prof[6] = W3_T() - tk0;
+    if (lane == 0) {
+        const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        if (wg < 1024)
+            for (int i = 0; i < 8; ++i) g_w3_prof[(wg * 8 + wave) * 8 + i] = prof[i];
+    }
+#endif
 
     // ---- this group's rows c0 .. c0 + 31 of partial slab `walker` ----
     if (wave_active) {
@@ -597,6 +638,12 @@ int w3_launch(const DipWgradDesc& d, hipStream_t st) {
 }
 
 }  // namespace
+
+#ifdef DIP_W3_PROFILE
+extern "C" int dip_w3_prof_read(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_w3_prof), (size_t)n * sizeof(unsigned long long));
+}
+#endif
 
 extern "C" int dip_conv_bf3_terms(void);
 extern "C" int dip_conv_wgrad_tail(const DipWgradDesc* dp, void* stream);
