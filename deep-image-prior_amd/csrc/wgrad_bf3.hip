@@ -403,15 +403,21 @@ __global__ __launch_bounds__(512) void wgrad_bf3_kernel(const DipWgradDesc d, co
     float bs[4] = {0.f, 0.f, 0.f, 0.f};                          // bias gradient of this thread's 4 dy channels
 
     // ---- staging slots ----------------------------------------------------------------------------------------------
-    // u (per group, its 32 channels): slot s = tg + 256 i < 288 -> (4-channel group cg = s / 36, halo row (s % 36) / 9, pixel pair s % 9)
-    // dy (whole workgroup): slot = tid -> (4-channel group cg = tid / 16 (0..31), tile row (tid % 16) / 8, pixel pair tid % 8)
+    // A slot = two horizontally adjacent pixels x 4 channels (2 x 16-byte loads).  The CHANNEL GROUP is the fastest lane index:
+    // 8 lanes read the 128 contiguous bytes of one pixel's 32 channels, a wave-wide load touches 8-16 cache lines.  (Round 4's
+    // map -- channel group slowest, so that the transposing LDS writes were conflict-free -- made every lane of a load hit a
+    // line of its own, 64 per instruction: tools/w3_profile.py measured 4000 cycles per tile for ISSUING the six loads, more than
+    // the 2400 of the transform + split + LDS writes and, with them, more than the 5200-cycle MFMA phase they should hide
+    // under.  The LDS writes now pay a 2-way bank conflict instead.)
+    // u (per group, its 32 channels): slot s = tg + 256 i < 288 -> (4-channel group cg = s % 8, halo row (s / 8) / 9, pixel pair (s / 8) % 9)
+    // dy (whole workgroup): slot = tid -> (pixel pair tid % 8, cg = 8 (tid / 128) + (tid / 8) % 8, tile row (tid / 64) % 2)
     f32x4 ur[2][2], dr[2];
     auto fetch = [&](int tile) {
         const int ty = tile / ntx, tx = tile - ty * ntx;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int s = tg + i * 256;
-            const int cg = s / 36, rem = s - cg * 36, hr = rem / 9, pp = rem - hr * 9;
+            const int cg = s & 7, rem = s >> 3, hr = rem / 9, pp = rem - hr * 9;
             const int c = c0 + cg * 4;
             const int sr = w3_map_src(ty * C::TH + hr - d.off, d.Hin, d.pad_mode);
             const bool okc = s < C::U_PAIRS && c < d.Cin && sr >= 0;
@@ -423,7 +429,7 @@ __global__ __launch_bounds__(512) void wgrad_bf3_kernel(const DipWgradDesc d, co
             }
         }
         {
-            const int cg = tid >> 4, rem = tid & 15, r = rem >> 3, pp = rem & 7;
+            const int pp = tid & 7, r = (tid >> 6) & 1, cg = ((tid >> 7) << 3) | ((tid >> 3) & 7);
             const int o = o0 + cg * 4;
             const int oy = ty * C::TH + r;
 #pragma unroll
@@ -442,7 +448,7 @@ __global__ __launch_bounds__(512) void wgrad_bf3_kernel(const DipWgradDesc d, co
         for (int i = 0; i < 2; ++i) {
             const int s = tg + i * 256;
             if (s < C::U_PAIRS) {
-                const int cg = s / 36, rem = s - cg * 36, hr = rem / 9, pp = rem - hr * 9;
+                const int cg = s & 7, rem = s >> 3, hr = rem / 9, pp = rem - hr * 9;
                 const int c = c0 + cg * 4;
                 const int sr = w3_map_src(ty * C::TH + hr - d.off, d.Hin, d.pad_mode);
                 unsigned h[2][4], m[2][4], l[2][4];
@@ -473,7 +479,7 @@ __global__ __launch_bounds__(512) void wgrad_bf3_kernel(const DipWgradDesc d, co
             }
         }
         {
-            const int cg = tid >> 4, rem = tid & 15, r = rem >> 3, pp = rem & 7;
+            const int pp = tid & 7, r = (tid >> 6) & 1, cg = ((tid >> 7) << 3) | ((tid >> 3) & 7);
             const int o = o0 + cg * 4;
             const int oy = ty * C::TH + r;
             unsigned h[2][4], m[2][4], l[2][4];
@@ -610,7 +616,8 @@ __global__ __launch_bounds__(512) void wgrad_bf3_kernel(const DipWgradDesc d, co
         if (tid < 128 && o0 + tid < CoutP) {
             const int cg = tid >> 2, e = tid & 3;
             float sum = 0.f;
-            for (int k = 0; k < 16; ++k) sum += red[(cg * 16 + k) * 4 + e];
+            // (the 4-wave form's order: tile row 0, pixel pairs 0..7, then tile row 1 -- the bias gradient stays bit-identical)
+            for (int k = 0; k < 16; ++k) sum += red[((k & 7) + 8 * (cg & 7) + 64 * (k >> 3) + 128 * (cg >> 3)) * 4 + e];
             d.bias_partial[(size_t)walker * CoutP + o0 + tid] = sum;
         }
     }
