@@ -34,6 +34,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 //   0 MFMA phases, 1 barrier waits after an MFMA phase, 2 commit (transform + split + LDS writes), 3 fetch issue,
 //   4 barrier waits after a staging phase, 5 half-periods, 6 whole kernel, 7 prologue
 __device__ unsigned long long g_w3_prof[1024 * 8 * 8];
+__device__ int g_w3_mode;          // knock-outs (results are garbage): 1 = no MFMAs, 2 = no staging after the prologue
 #define W3_T() __builtin_amdgcn_s_memtime()
 #define W3_ADD(slot, t0, t1) prof[slot] += (t1) - (t0)
 #else
@@ -596,6 +597,11 @@ __global__ __launch_bounds__(512) void wgrad_bf3_kernel(const DipWgradDesc d, co
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     const unsigned long long tk0 = W3_T();
+#ifdef DIP_W3_PROFILE
+    const int w3_mode = __builtin_amdgcn_readfirstlane(g_w3_mode);
+#else
+    constexpr int w3_mode = 0;
+#endif
     __syncthreads();                       // tables + zeroed LDS
     const int ntl = walker < ntiles ? (ntiles - 1 - walker) / nwalk + 1 : 0;        // tiles of this walker
     if (ntl > 0) {
@@ -610,7 +616,7 @@ __global__ __launch_bounds__(512) void wgrad_bf3_kernel(const DipWgradDesc d, co
         const int kt = h >> 1, buf = kt & 1;
         const unsigned long long t0 = W3_T();
         if ((h & 1) == grp) {
-            if (wave_active) {
+            if (wave_active && w3_mode != 1) {
                 __builtin_amdgcn_s_setprio(2);
                 mfma_tile(buf);
                 __builtin_amdgcn_s_setprio(0);
@@ -621,7 +627,7 @@ __global__ __launch_bounds__(512) void wgrad_bf3_kernel(const DipWgradDesc d, co
             W3_ADD(1, t1, W3_T());
         } else {
             unsigned long long t1 = t0, t2 = t0;
-            if (kt + 1 < ntl) {
+            if (kt + 1 < ntl && w3_mode != 2) {
                 commit(walker + (kt + 1) * nwalk, buf ^ 1);
                 t1 = W3_T();
                 if (kt + 2 < ntl) fetch(walker + (kt + 2) * nwalk);          // in flight under this group's next MFMA phase
@@ -696,6 +702,7 @@ int w3_launch(const DipWgradDesc& d, hipStream_t st) {
 }  // namespace
 
 #ifdef DIP_W3_PROFILE
+extern "C" int dip_w3_prof_mode(int mode) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_w3_mode), &mode, sizeof(int)); }
 extern "C" int dip_w3_prof_read(unsigned long long* host, int n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_w3_prof), (size_t)n * sizeof(unsigned long long));
 }
@@ -727,9 +734,10 @@ extern "C" int dip_wgrad_bf3(const DipWgradDesc* dp, void* stream) {
     if (nt == 0) DIP_FAIL("wgrad_bf3: the bf16-pipe arithmetic is switched off (DIP_CONV_BF3=0)");
     const int tr = d.tr.a == nullptr ? 0 : (d.tr.slope > 0.f ? 1 : 2);
     int rc;
-    // DIP_WGRAD_BF3_V1=1: the round-4 form of the kernel (4 waves, two workgroups per CU, one accumulator at a time), kept as
-    // the REFERENCE of the bit-identity test (tests/test_bf3_gpu.py) and for A/B runs; never taken otherwise.
-    static const bool v1 = getenv("DIP_WGRAD_BF3_V1") != nullptr;
+    // DIP_WGRAD_BF3_V1=1: the round-4 form of the kernel (4 waves, two workgroups per CU, one accumulator at a time) for every
+    // layer: the REFERENCE of the bit-identity test (tests/test_bf3_gpu.py) and of A/B runs.  =2: only below 2048 tiles.
+    static const int v1_mode = [] { const char* e = getenv("DIP_WGRAD_BF3_V1"); return e ? atoi(e) : 0; }();
+    const bool v1 = v1_mode == 1 || (v1_mode == 2 && dip_cdiv(d.Wout, 16) * dip_cdiv(d.Hout, 2) < 2048);
     if (v1) {
         if (nt == 6) rc = tr == 0 ? w3_launch_v1<6, 0>(d, st) : (tr == 1 ? w3_launch_v1<6, 1>(d, st) : w3_launch_v1<6, 2>(d, st));
         else if (nt == 8) rc = tr == 0 ? w3_launch_v1<8, 0>(d, st) : (tr == 1 ? w3_launch_v1<8, 1>(d, st) : w3_launch_v1<8, 2>(d, st));

@@ -32,7 +32,9 @@ def main():
     dev = torch.device("cuda:0")
     st = H.stream(dev)
     names = ["mfma", "bar_after_mfma", "commit", "fetch_issue", "bar_after_stage", "half_periods", "kernel", "prologue"]
-    for (Cin, Cout, Hh, Ww) in ((128, 128, 512, 512), (128, 128, 256, 256), (128, 128, 128, 128)):
+    for mode, (Cin, Cout, Hh, Ww) in [(m, sh) for sh in ((128, 128, 512, 512), (128, 128, 128, 128)) for m in (0, 1, 2)]:
+        assert raw.dip_w3_prof_mode(mode) == 0
+        print(f"--- mode {mode} ({['full kernel', 'knock-out: no MFMAs', 'knock-out: no staging after the prologue'][mode]})")
         g = torch.Generator().manual_seed(0)
         x = torch.randn(1, Cin, Hh, Ww, generator=g).to(dev)
         dy = torch.randn(1, Cout, Hh, Ww, generator=g).to(dev)
