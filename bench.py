@@ -947,6 +947,9 @@ def main():
     ap.add_argument("--group", default="both", choices=["both", "native", "graphs"],
                     help="--instances B > 1: 'native' = ONE launch list for the B fits (dip_group.GroupedFits: every launch "
                          "serves all instances), 'graphs' = B hipGraphs on B streams, 'both' = time both, report the faster")
+    ap.add_argument("--first-image", type=int, default=0,
+                    help="index (= seed) of the first image: `--gpus 1 --first-image r` is the solo run of what rank r of a "
+                         "multi-GPU run fits (per_rank_final_loss_hex must match bit for bit: tests/test_shard_gpu.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-eager-line", action="store_true")
@@ -998,7 +1001,7 @@ def main():
 
     # one independent image (x --instances) per rank; image index = global fit index = seed
     n_inst = max(args.instances, 1)
-    my_images = shard_images(world * n_inst, rank, world)
+    my_images = [args.first_image + i for i in shard_images(world * n_inst, rank, world)]
     fits = [Fit(args.config, img, dev, args.closure) for img in my_images]
     # Execution mode of the timed region: eager launches or hipGraph replays of the same iteration.
     # `auto` times K steps in each mode and reports the faster one as `value` (the other goes to
@@ -1145,6 +1148,7 @@ def main():
                                      "fp32 everywhere (v_mfma_f32_32x32x2_f32)"},
             "per_rank_it_s": [round(v, 3) for v in per_rank],
             "per_rank_final_loss": [round(v, 6) for v in per_rank_loss],
+            "per_rank_final_loss_hex": [float(v).hex() for v in per_rank_loss],
             "timed_region_power": best.get("power"),
             "roofline": rl, "roofline_wgrad": rw, "roofline_conv3x3_all": r3, "roofline_hbm": rh,
             "sustained": sustained, "build_id": _N.lib().dip_build_id().decode(),

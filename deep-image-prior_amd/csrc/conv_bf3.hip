@@ -34,6 +34,11 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
+#ifdef DIP_W3_PROFILE
+// clock probe of the profile build (tools/w3_profile.py): per workgroup {s_memtime cycles, s_memrealtime ticks (100 MHz)} of wave 0
+__device__ unsigned long long g_b3_prof[8192 * 2];
+#endif
+
 constexpr int B3_TR_MAX = 512;
 constexpr int B3_CCH = 16;
 
@@ -100,6 +105,9 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(const DipConvDesc d, c
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave & 1, wm = wave >> 1;
+#ifdef DIP_W3_PROFILE
+    const unsigned long long pk0 = __builtin_amdgcn_s_memtime(), pr0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int tile = dip_xcd_remap(blockIdx.x, ntiles);
     const int ty = tile / ntx, tx = tile - ty * ntx;
     const int n0 = n_base + blockIdx.y * BN;
@@ -316,6 +324,12 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(const DipConvDesc d, c
 
     // ---- epilogue (conv_epilogue.h) ----
     __syncthreads();
+#ifdef DIP_W3_PROFILE
+    if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 8192) {
+        g_b3_prof[blockIdx.x * 2] = __builtin_amdgcn_s_memtime() - pk0;
+        g_b3_prof[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime() - pr0;
+    }
+#endif
     const DipEpi epi = dip_epi_make(d, ty, tx, C::TH, C::TW);
     dip_conv_epilogue<C, BN>(d, acc, epi, n0, wn, wm, l31, half, tid, tile, CoutP, reinterpret_cast<float*>(smem));
 }
@@ -410,6 +424,12 @@ int bf3_launch(const DipConvDesc& d, int n_base, int ncols, hipStream_t st) {
 }
 
 }  // namespace
+
+#ifdef DIP_W3_PROFILE
+extern "C" int dip_b3_prof_read(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_b3_prof), (size_t)n * sizeof(unsigned long long));
+}
+#endif
 
 // 1 when dip_conv_igemm runs `d` on the bf16 matrix pipe (d->wp3 set; DIP_CONV_BF3=0 switches it off, =6 drops three terms): 3x3, stride 1, dil 1, one pass,
 // >= 96 tiles (128 columns per workgroup from 256 tiles, 64 below), at least one full 128-column block

@@ -32,7 +32,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifdef DIP_W3_PROFILE
 // per-wave cycle sums of the ping-pong kernel's phases (s_memtime ticks = shader cycles): [workgroup][wave][8]
 //   0 MFMA phases, 1 barrier waits after an MFMA phase, 2 commit (transform + split + LDS writes), 3 fetch issue,
-//   4 barrier waits after a staging phase, 5 half-periods, 6 whole kernel, 7 prologue
+//   4 barrier waits after a staging phase, 5 half-periods, 6 whole kernel, 7 whole kernel in s_memrealtime ticks (100 MHz)
 __device__ unsigned long long g_w3_prof[1024 * 8 * 8];
 __device__ int g_w3_mode;          // knock-outs (results are garbage): 1 = no MFMAs, 2 = no staging after the prologue
 #define W3_T() __builtin_amdgcn_s_memtime()
@@ -598,6 +598,7 @@ __global__ __launch_bounds__(512) void wgrad_bf3_kernel(const DipWgradDesc d, co
 #endif
     const unsigned long long tk0 = W3_T();
 #ifdef DIP_W3_PROFILE
+    const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();
     const int w3_mode = __builtin_amdgcn_readfirstlane(g_w3_mode);
 #else
     constexpr int w3_mode = 0;
@@ -610,7 +611,6 @@ __global__ __launch_bounds__(512) void wgrad_bf3_kernel(const DipWgradDesc d, co
         if (ntl > 1) fetch(walker + nwalk);
     }
     __syncthreads();
-    W3_ADD(7, tk0, W3_T());
     // half-period h: group (h & 1) multiplies tile h / 2, the other group stages its share of tile h / 2 + 1
     for (int h = 0; h < 2 * ntl; ++h) {
         const int kt = h >> 1, buf = kt & 1;
@@ -644,6 +644,7 @@ __global__ __launch_bounds__(512) void wgrad_bf3_kernel(const DipWgradDesc d, co
     }
 #ifdef DIP_W3_PROFILE
     prof[6] = W3_T() - tk0;
+    prof[7] = __builtin_amdgcn_s_memrealtime() - tr0;
     if (lane == 0) {
         const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
         if (wg < 1024)

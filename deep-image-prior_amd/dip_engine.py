@@ -906,10 +906,8 @@ class SkipEngine:
         slot = "cap" if capturing else "eager"      # separate streams / events for captured and eager runs
         st_ = self._aux.get((slot, self.device))
         if st_ is None:
-            # DIP_SIDE_PRIORITY / DIP_BULK_PRIORITY: HIP stream priorities of the auxiliary streams (-1 high .. 1 low; experiment)
-            pr = [int(os.environ.get("DIP_SIDE_PRIORITY", "0")), int(os.environ.get("DIP_BULK_PRIORITY", "0"))]
-            st_ = self._aux[(slot, self.device)] = ([torch.cuda.Stream(self.device, priority=pr[0]),
-                                                     torch.cuda.Stream(self.device, priority=pr[1])], {})
+            # (HIP stream priorities for the auxiliary streams were measured in round 4: no effect; default priority)
+            st_ = self._aux[(slot, self.device)] = ([torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)], {})
         aux, events = st_
         streams = [main, aux[0], aux[1]]
         ptrs = [s_.cuda_stream for s_ in streams]
