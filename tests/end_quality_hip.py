@@ -34,6 +34,11 @@ import __graft_entry__ as ge  # noqa: E402
 ge.build()
 import end_quality_cpu as E  # noqa: E402
 
+# the host side of an arm is a few small torch CPU ops per iteration (reg-noise draw, scaling): on the 128-core GPU boxes the
+# default intra-op pool (one thread per core) makes each of them a many-thread barrier.  The values do not depend on it (the
+# normal draw is sequential in the generator, the scaling element-wise).
+torch.set_num_threads(4)
+
 
 def one_fit(size, iters, perturb, task, family):
     from utils.common_utils import get_params, optimize
