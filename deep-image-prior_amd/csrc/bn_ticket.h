@@ -1,4 +1,7 @@
 // "The last workgroup to arrive finalises" -- WITHOUT an agent-scope fence.
+// OPT-IN (DIP_TICKET_FIN=1), gfx950-ONLY BEHAVIOUR: the protocol below has no release/acquire pair -- it relies on a store's vmcnt
+// retirement implying agent-scope visibility across the XCD L2s, which the HIP / LLVM memory model does not guarantee.
+// Measured slower than the separate finalisation launch; kept for the record and covered by tests/test_small_gpu.py.
 //
 // A BatchNorm needs a reduction over the whole image between two element-wise passes; the producers of
 // the partial rows (conv epilogues, up-sample + concat, the statistics passes of the backward) used to

@@ -13,14 +13,11 @@
 //     LDS staging, no barriers in the K loop, a ring of 3 x 4 K-steps of loads in flight per wave;
 //   * split-K INSIDE the workgroup: 1, 2 or 4 waves share a tile and sum their accumulators through
 //     LDS in a fixed order (deterministic), so there is no workspace and no finish launch;
-//   * epilogue: bias, store, BatchNorm partial statistics {count, mean, M2} per workgroup row, and the
-//     LAST workgroup of a 32-channel block to arrive (fence-free ticket: write-through sc1 stores,
-//     s_waitcnt, relaxed agent-scope atomic add; tools/ubench/ticket_sc1.hip) reduces the <= 128 rows
-//     in fp64 and writes the BatchNorm state + running statistics -- what dip_bn_finalize does in a
-//     launch of its own;
+//   * epilogue: bias, store, BatchNorm partial statistics {count, mean, M2} per workgroup row -- PARTIALS ONLY: the engine
+//     emits a dip_bn_finalize launch after every dip_conv_small (the "last workgroup to arrive finalises" form of round 4,
+//     bn_ticket.h, lives on in the opt-in *_fin entry points of other kernels; this kernel never had ticket code);
 //   * data-gradient launches: phase 1 of the BatchNorm(+activation) backward of the conv's input
-//     (DipConvDesc.bnb_*) rides in the epilogue the same way, finalised (dgamma, dbeta, k1, k2) by the
-//     last arriver; stride-2 transposed convs walk the four output-parity classes separately, so a
+//     (DipConvDesc.bnb_*) rides in the epilogue as partial rows too (dip_bn_bwd_finalize2 follows); stride-2 transposed convs walk the four output-parity classes separately, so a
 //     wave only visits the taps that hit non-zero positions of the dilated gradient (9 taps per 4
 //     pixels instead of 36, as the phase mode of the LDS-DMA kernel).
 // Any stride-1/2 1x1 / 3x3 convolution or data gradient with reflection / zero / replication padding,

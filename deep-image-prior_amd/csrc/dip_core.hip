@@ -37,15 +37,17 @@ extern "C" int dip_device_pci_bus_id(int device, char* buf, int len) {
 // ---------------------------------------------------------------------------------------------
 // Grouped multi-instance execution (dip_group.h; include/dip_hip.h "grouped execution").  Host-side state only: which
 // launches are grouped is decided where they are issued, so a grouped launch list is hipGraph-capturable like a solo one.
-// One process per GPU, one launching thread (header conventions): a plain global.
+// One process per GPU; the context is THREAD-LOCAL: a group opened by one host thread replicates that thread's launches only
+// (round 4 had a process-wide global: a launch from another thread between dip_group_begin and dip_group_end -- a solo net's
+// forward, a monitor -- was replicated B times or refused, and a fault raised there was consumed by whoever checked next).
 // ---------------------------------------------------------------------------------------------
 static unsigned native_default() {
     const char* e = getenv("DIP_GROUP_NATIVE");
     return e ? (unsigned)strtoul(e, nullptr, 0) : ~0u;
 }
-static DipGroupCtx g_grp = {1, 0, nullptr, 0, ~0u};
-static bool g_grp_native_init = false;
-static bool g_grp_fault = false;
+static thread_local DipGroupCtx g_grp = {1, 0, nullptr, 0, ~0u};
+static thread_local bool g_grp_native_init = false;
+static thread_local bool g_grp_fault = false;
 
 extern "C" const DipGroupCtx* dip_group_ctx(void) { return &g_grp; }
 extern "C" void dip_group_fault(const char* what) {

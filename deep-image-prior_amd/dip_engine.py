@@ -127,9 +127,9 @@ class SkipEngine:
         # replace (+0.5 % on a fast-class box, -1.5 % on a slow-class one) -- so it is opt-in
         self.fuse_bnb = os.environ.get("DIP_BNB_FUSE", "0") == "1"
         # low-resolution layers (<= DIP_SMALL_MAX_PIXELS output pixels): ONE dip_conv_small launch per convolution
-        # (conv + in-workgroup split-K + BatchNorm partials + in-launch finalisation) instead of conv + split-K finish +
-        # bn_finalize, and data gradient + BatchNorm-backward statistics + finalisation instead of four launches
-        # (csrc/conv_small.hip, csrc/bn_ticket.h); DIP_CONV_NO_SMALL=1 / DIP_NO_TICKET_FIN=1 restore the round-3 lists
+        # (conv + in-workgroup split-K + BatchNorm partials; dip_bn_finalize follows) instead of conv + split-K finish +
+        # bn_finalize, and data gradient + BatchNorm-backward partials (+ dip_bn_bwd_finalize2) instead of four launches
+        # (csrc/conv_small.hip); DIP_CONV_NO_SMALL=1 restores the round-3 lists
         self.use_small = os.environ.get("DIP_CONV_NO_SMALL") is None
         # in-launch BatchNorm finalisation by the last workgroup to arrive (csrc/bn_ticket.h) for up-sample + concat and
         # the backward statistics passes: built, parity-tested, and measured SLOWER than a finalisation launch of its own
@@ -460,10 +460,13 @@ class SkipEngine:
                            ticket)
 
     def _emit_bn_finalize(self, bn: BNRec, scratch, rows, cstride):
-        """Partial rows -> state block + running statistics (dip_bn_finalize).  A separate launch on
-        purpose: finishing inside the producer ("last-arriving workgroup", arrival tickets) was built and
-        measured -- every workgroup then needs an agent-scope release fence, which on the multi-XCD MI355X
-        writes back / invalidates L2 per workgroup: +200 us on a 2048-tile conv launch."""
+        """Partial rows -> state block + running statistics (dip_bn_finalize).  A separate launch on purpose: finishing
+        inside the producer ("last-arriving workgroup") was built and measured twice -- with an agent-scope release fence
+        per workgroup (round 2: +200 us on a 2048-tile conv launch, the fence writes back / invalidates L2 on the multi-XCD
+        part) and fence-free (round 4, csrc/bn_ticket.h: sc1 write-through stores + a relaxed ticket, which leans on gfx950
+        behaviour the HIP memory model does not promise; -1.5 % end to end: the last arriver's serial read of the rows
+        costs more than the 5-7 us launch).  The fence-free form stays opt-in (DIP_TICKET_FIN=1) on the up-sample / backward
+        statistics kernels only."""
         m = bn.module
         args = (_ptr(scratch), rows, cstride, bn.C, _ptr(self.params, bn.gamma_off), _ptr(self.params, bn.beta_off),
                 float(m.eps), float(m.momentum), _ptr(bn.state), bn.Cs,

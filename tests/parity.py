@@ -106,7 +106,8 @@ def grad_report(named_grads, g64, g32, g64n, zero_keys, ratio=RATIO, floor=FLOOR
     dbl = lambda t: torch.as_tensor(t).detach().cpu().double()
     gscale = max(dbl(v).norm().item() for k, v in g64.items() if k not in zero_keys)
     rep = {"worst": 0.0, "worst_key": None, "worst_unmasked": 0.0, "worst_unmasked_key": None, "worst_zero": 0.0,
-           "n_zero": 0, "worst_rel": 0.0, "worst_rel_key": None, "worst_rel_ref": 0.0, "worst_rel_excess": 0.0}
+           "n_zero": 0, "worst_rel": 0.0, "worst_rel_key": None, "worst_rel_ref": 0.0, "worst_rel_excess": 0.0,
+           "relaxed": []}          # tensors whose rel-L2 bound is RATIO x the reference's own (> REL_L2): the set is printed, so it cannot grow silently
     for k, g in named_grads.items():
         g = dbl(g)
         t, tn, r = dbl(g64[k]), dbl(g64n[k]), dbl(g32[k])
@@ -133,7 +134,9 @@ def grad_report(named_grads, g64, g32, g64n, zero_keys, ratio=RATIO, floor=FLOOR
             # RATIO x the reference's own rel-L2, the same factor as the primary criterion (round 4: with "1 x the
             # reference" the test was a coin flip per such tensor -- 2.3e-3 vs the reference's 8.4e-4 on s2.skip_bn.beta at
             # 512^2 after the low-resolution layers changed their summation order, 0.69 of the primary bound)
-            excess = rel / (REL_L2 if rel_ref <= REL_L2 else RATIO * rel_ref)
+            excess = rel / max(REL_L2, RATIO * rel_ref)       # continuous in rel_ref (the 1e-4 -> 4e-4 jump at rel_ref = 1e-4 is gone)
+            if RATIO * rel_ref > REL_L2:
+                rep["relaxed"].append(f"{k} (reference rel-L2 {rel_ref:.1e}, HIP {rel:.1e})")
             if excess > rep["worst_rel_excess"]:
                 rep["worst_rel_excess"], rep["worst_rel_key"] = excess, desc
         if q > rep["worst"]:
@@ -183,7 +186,8 @@ def fmt(rep):
     return (f"grad err/tol masked {rep['worst']:.2f} [{rep['worst_key']}], unmasked {rep['worst_unmasked']:.2f} "
             f"[{rep['worst_unmasked_key']}], zero-tensors {rep['worst_zero']:.2f} (n={rep['n_zero']}), "
             f"worst rel-L2 {rep['worst_rel']:.2e} (reference fp32 vs its fp64: {rep['worst_rel_ref']:.2e}; "
-            f"vs max(1e-4, reference) x{rep['worst_rel_excess']:.2f})")
+            f"vs max(1e-4, {RATIO:g} x reference) x{rep['worst_rel_excess']:.2f}; {len(rep.get('relaxed', []))} tensor(s) on the relaxed bound"
+            + (": " + "; ".join(rep["relaxed"][:6]) if rep.get("relaxed") else "") + ")")
 
 
 def psnr(a, b):
