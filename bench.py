@@ -524,8 +524,8 @@ def roofline_hbm(eng, per_op_ms):
     untimed = sum(b for k, b in B.items() if k not in timed and ":" not in k)
     pmc = None
     try:
-        pth = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
-        with open(pth if os.path.exists(pth) else os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as f:
+        pth = [q for q in (os.path.join(ROOT, "profiles", f"{r}_pmc_traffic.json") for r in ("r05", "r04", "r03")) if os.path.exists(q)][0]
+        with open(pth) as f:
             pmc = json.load(f).get("memory_bound_group")
     except (OSError, ValueError):
         pass
@@ -676,7 +676,7 @@ def pmc_traffic():
     (profiles/r0N_pmc_traffic.json, produced by tools/pmc_traffic.py); None when absent."""
     import dip_native as N
     want = "conv_bf3_kernel<*>" if N.lib().dip_conv_bf3_terms() else DOMINANT
-    for rnd in ("r04", "r03", "r02", "r01"):
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):
         try:
             with open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")) as f:
                 t = json.load(f)
@@ -728,10 +728,12 @@ def roofline(eng, per_op_ms, with_pmc=True):
           "all_conv_launches": {"gflop_per_step": round(all_f / 1e9, 1), "ms_per_step_serial": round(all_ms, 3),
                                 "tflops": round(all_f / (all_ms * 1e-3) / 1e12, 2) if all_ms > 0 else None}}
     try:        # matrix-pipe utilisation from the committed counter pass (tools/pmc_mfma.py; another run than this line)
-        with open(os.path.join(ROOT, "profiles", "r04_pmc_mfma.json")) as f:
+        pmf = [q for q in (os.path.join(ROOT, "profiles", f"{r}_pmc_mfma.json") for r in ("r05", "r04")) if os.path.exists(q)][0]
+        with open(pmf) as f:
             pm = json.load(f)
         key = "conv_bf3_kernel" if terms else "conv_igemm_dma_kernel<3, 128"
-        us = [(v["launches"], v["utilisation"], v.get("clock_ghz", 2.4)) for k, v in pm["kernels"].items() if k.startswith(key)]
+        us = [(v["launches"], v["utilisation"], v.get("clock_ghz") or 2.4) for k, v in pm["kernels"].items()
+              if k.startswith(key) and not v.get("short_dispatch")]
         if us:
             nl = sum(n for n, _, _ in us)
             util, ghz = sum(n * u for n, u, _ in us) / nl, sum(n * g for n, _, g in us) / nl
@@ -740,8 +742,8 @@ def roofline(eng, per_op_ms, with_pmc=True):
             # frac prices the kernel against the peak at the nominal 2.4 GHz; the counters count CYCLES: the two meet at
             # utilisation x (clock the kernel ran at) / 2.4 (every executed MFMA of these launches is algorithmic work)
             rl["frac_from_pmc"] = round(util * ghz / 2.4, 4)
-            rl["mfma_util_pmc_source"] = ("profiles/r04_rocprofv3_pmc_MFMA.txt (a counter pass of the same code; same box and call as this "
-                                          "line when tools/gpu_round4.sh / gpu_round4_final.sh produced both): utilisation = SQ_VALU_MFMA_BUSY_CYCLES / "
+            rl["mfma_util_pmc_source"] = (os.path.relpath(pmf, ROOT).replace("_pmc_mfma.json", "_rocprofv3_pmc_MFMA.txt") + " (a counter pass of the same code; same box and call as this "
+                                          "line when tools/gpu_round5_final.sh produced both): utilisation = SQ_VALU_MFMA_BUSY_CYCLES / "
                                           "(128 x GRBM_GUI_ACTIVE), clock = GRBM_GUI_ACTIVE / (8 x duration), units calibrated on the "
                                           "pure-MFMA loops of tools/ubench in the same call; frac_from_pmc = utilisation x clock / 2.4 GHz "
                                           f"is the counter-derived value of `frac`: the matrix pipes of this kernel are busy {100 * util:.0f} % "
