@@ -132,7 +132,8 @@ def pin_to_gpu_numa(local_rank, world):
         import torch
         if world > 1:
             torch.set_num_threads(1)
-        cards = [gpu_sysfs_dir(r) for r in range(max(world, local_rank + 1))] if torch.cuda.is_available() else []
+        ngpu = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        cards = [gpu_sysfs_dir(r) if r < ngpu else None for r in range(max(world, local_rank + 1))]
         if local_rank >= len(cards) or cards[local_rank] is None:
             return {"pinned": False, "why": "no sysfs entry for this GPU"}
         node = int(open(cards[local_rank] + "/numa_node").read().strip())

@@ -30,7 +30,11 @@ extern "C" const char* dip_build_id(void) { return g_build_id + 13; }
 extern "C" int dip_device_pci_bus_id(int device, char* buf, int len) {
     if (buf == nullptr || len < 13) DIP_FAIL("device_pci_bus_id: buffer of >= 13 bytes required");
     hipError_t e = hipDeviceGetPCIBusId(buf, len, device);
-    if (e != hipSuccess) { dip_set_error(hipGetErrorString(e)); return (int)e; }
+    if (e != hipSuccess) {
+        dip_set_error(hipGetErrorString(e));
+        (void)hipGetLastError();        // a query must not leave HIP's sticky last-error set: the next torch call would raise it
+        return (int)e;                   // (round 5: rank r asking for GPU r + 1 on a 1-GPU box made `net.to(dev)` fail later)
+    }
     return 0;
 }
 
