@@ -4,6 +4,10 @@
 //
 //   dW[tap][c][o] = sum_p  u[p + tap][c] * dy[p][o]            (u = transform(x), as in the forward)
 //
+// Two forms of the kernel live in this file: the ping-pong of two wave groups that runs every eligible layer since round 5
+// (wgrad_bf3_kernel, described where it is defined) and the round-4 form described next (wgrad_bf3_v1_kernel: the reference
+// of the bit-identity test, DIP_WGRAD_BF3_V1=1).  Both share the LDS layouts, the split and the per-accumulator MFMA order.
+//
 // GEMM per tap: M = 32 input channels per workgroup, N = 128 output channels (32 per wave), K = output pixels.  The
 // contraction runs over PIXELS, so v_mfma_f32_32x32x16_bf16 wants 8 consecutive pixels of one channel per lane: both
 // operands are staged TRANSPOSED in LDS ([plane][channel][pixel] bf16; the fp32 kernel keeps them pixel-major and feeds
@@ -73,11 +77,11 @@ __device__ __forceinline__ void w3_split(float a, unsigned& h, unsigned& m, unsi
 }
 
 // The three horizontal taps of one (tile row, tap row) out of the 16-byte-aligned windows w0 (8 pixels) + w1 (2 more) of a halo
-// row, all partial products, smallest first.  The three taps' accumulators take turns MFMA by MFMA: v_mfma_f32_32x32x16_bf16
-// issues every 32 cycles but its result feeds a DEPENDENT MFMA only after ~64 (16 passes), so a run of MFMAs on ONE
-// accumulator -- how round 4's kernel walked the products of a tap -- runs the matrix pipe at half rate (round 5: 515 us at
-// 512^2 in both the 4-wave and the ping-pong form = 0.46 of the pipe; conv_bf3 rotates four accumulators and never saw it).
-// Per accumulator the order of the products is unchanged, so the result is bit-identical.
+// row, all partial products, smallest first, the three taps' accumulators taking turns MFMA by MFMA.  Per accumulator the
+// order of the products is that of the 4-wave form, so the result is bit-identical.  (The rotation was written on the
+// hypothesis that a run of v_mfma_f32_32x32x16_bf16 on ONE accumulator issues at half rate; measured in round 5, it does not --
+// same-accumulator chains issue back to back, the kernel's time did not move.  It is kept because it costs nothing and keeps
+// the operand registers of the three taps live together, one window load per row.)
 template <int NT>
 __device__ __forceinline__ void w3_taps_of_row(const u32x4 (&w0)[3], const unsigned (&w1)[3], const bf16x8 (&b)[3], f32x16& acc0,
                                                f32x16& acc1, f32x16& acc2) {
@@ -96,8 +100,7 @@ __device__ __forceinline__ void w3_taps_of_row(const u32x4 (&w0)[3], const unsig
         for (int pa = 0; pa < 3; ++pa) {
             const int pb = sm - pa;
             if (pb < 0 || pb > 2) continue;
-            // (sched_barrier 0x7F6: everything but MFMAs may cross -- hipcc's scheduler, whose latency model does not know the
-            // 64 cycles, otherwise puts MFMAs on the same accumulator back to back again)
+            // (sched_barrier 0x7F6: everything but MFMAs may cross, so the MFMAs stay in this order)
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][pa], b[pb], acc0, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0x7F6);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][pa], b[pb], acc1, 0, 0, 0);
@@ -353,15 +356,18 @@ int w3_launch_v1(const DipWgradDesc& d, hipStream_t st) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Round 5: the same arithmetic, bit for bit (same walkers, same tiles per walker, same order of MFMAs per accumulator), as a
-// PING-PONG of two wave groups.  Counters on the round-4 kernel: matrix pipes busy 0.55.  Its two co-resident workgroups fall
-// into step -- both in their MFMA bursts at half rate each, then both in their staging phase (transform, exact split,
-// transposition: ~1500 cycles of vector ALU per 4608-cycle tile) with the pipes idle -- and lock-step is stable: whoever runs
-// ahead shares the pipe until the other has caught up.  Here ONE workgroup of 8 waves owns a CU: group g = wave / 4 owns the
-// 32 input channels c0 + 32 g (its own nine accumulators per wave, its own partial-slab rows: what a round-4 workgroup owned),
-// both groups share the staged dy tile, and the groups alternate by construction: in half-period h group (h & 1) runs the
-// MFMAs of tile h / 2 out of LDS buffer (h / 2) & 1 while the other group stages ITS share of the next tile (its 32 channels
-// of u, half of dy) into the other buffer; one barrier per half-period.  A SIMD holds one wave of each group, so its matrix
-// pipe always has exactly one wave feeding it, and the staging -- a quarter of the MFMA time -- hides completely.
+// PING-PONG of two wave groups.  ONE workgroup of 8 waves owns a CU: group g = wave / 4 owns the 32 input channels c0 + 32 g
+// (its own nine accumulators per wave, its own partial-slab rows: what a round-4 workgroup owned), both groups share the
+// staged dy tile, and the groups alternate by construction: in half-period h group (h & 1) runs the MFMAs of tile h / 2 out of
+// LDS buffer (h / 2) & 1 while the other group stages ITS share of the next tile (its 32 channels of u, half of dy) into the
+// other buffer; one barrier per half-period.  A SIMD holds one wave of each group.
+// What it was built for and what the counters say (tools/w3_profile.py): the round-4 kernel keeps the matrix
+// pipes busy 0.55 of the time and the hypothesis was lock-step of its two co-resident workgroups (both in their MFMA bursts at
+// half rate, then both staging with the pipes idle).  The ping-pong removes that by construction -- and times the same in
+// isolation: an MFMA phase is 5 300 cycles per tile (4 608 ideal), the staging 3 000 cycles alone but 6 200 beside the other
+// group's MFMA wave on the same SIMD, and the clock inside the kernel is 1.66 GHz (1.89 with the staging knocked out, 2.34
+// with the MFMAs knocked out): the kernel is bound by what a SIMD can issue for two waves and by the power budget, not by
+// idle pipes.  In the iteration the form is worth +1.1 %.
 //   * dy is transformed / split once per 64 input channels instead of once per 32;
 //   * the A windows are walked by HALO ROW (row hr serves tap row ky = hr of tile row 0 and ky = hr - 1 of tile row 1: 4 row
 //     loads per tile instead of 6), the next row's windows are read under the current row's MFMAs;
