@@ -38,7 +38,12 @@ The JSON line also carries
                    TFLOP/s fp32 MFMA peak (MI355X_MICROARCH.md chip table);
   roofline_wgrad : the same for conv_wgrad_kernel (3x3), the top line of the rocprof profile;
   cpu_baseline   : the CPU oracle (oracle/dip_oracle.py, a bitwise-verified restatement of the
-                   reference's PyTorch-CPU path) timed on this box's host cores on the same workload.
+                   reference's PyTorch-CPU path) timed on this box's host cores on the same workload;
+  sustained      : (round 5) BASELINE.md section 4's own protocol next to the driver's short one -- 50 warm-up + 300 timed
+                   iterations of the reported mode, with the PPT / sclk samples of that region;
+  build_id       : (round 5) dip_build_id(): the sha256 of the sources the loaded libdip_hip.so was built from;
+  per_rank_final_loss_hex : every rank's final loss, exact; `--gpus 1 --first-image r` is the solo run of rank r's fit
+                   (tests/test_shard_gpu.py compares the two bit for bit).
 """
 import argparse
 import json

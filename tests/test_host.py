@@ -597,3 +597,48 @@ def test_sr_and_inpainting_helpers(built, tmp_path):
     assert m.shape == (3, 64, 96) and 0.07 < m.mean() < 0.13
     t = I.get_text_mask(Image.fromarray(np.zeros((200, 300, 3), dtype=np.uint8)))
     assert t.size == (300, 200) and np.array(t).max() == 255
+
+
+def test_build_id_is_the_hash_of_the_sources(built):
+    """dip_build_id() (round 5): the library carries the first 16 hex digits of the sha256 over csrc/*.hip, csrc/*.h and
+    include/dip_hip.h; build() rebuilds when it differs from the sources on disk (not on mtimes), bench.py prints it."""
+    import __graft_entry__ as ge
+    sid = ge.source_id()
+    assert len(sid) == 16 and int(sid, 16) >= 0
+    assert built.dip_build_id().decode() == sid == ge.library_id()
+    assert ge.library_id("/nonexistent/libdip_hip.so") is None and not ge._stale()
+
+
+def test_end_quality_rule_on_synthetic_families():
+    """The registered end-quality rule (tests/test_net_gpu._compare_end_quality) on synthetic families:
+    duplicates count once, the 3 % loss rule applies where the reference family is tight, Welch on log(loss) at alpha = 0.01
+    where it is not (and needs n >= 8), the PSNR thresholds act on the family means."""
+    import numpy as np
+    from test_net_gpu import _compare_end_quality
+    rng = np.random.RandomState(0)
+
+    def fam(n, gt, sm, loss, jitter, tail=None):
+        out = []
+        for k in range(n):
+            a = {"psnr_gt": gt + 0.2 * rng.randn(), "psnr_gt_sm": sm + 0.2 * rng.randn(), "loss": loss * (1 + jitter * rng.randn())}
+            if tail is not None:
+                a["loss_tail"] = tail * float(np.exp(0.13 * rng.randn()))
+            out.append(a)
+        return out
+
+    # denoising-like: tight loss -> 3 % rule; a duplicate arm is dropped
+    cpu = fam(8, 34.0, 38.0, 0.0089, 0.002)
+    hip = fam(6, 34.05, 37.95, 0.0089, 0.002)
+    _compare_end_quality("synthetic denoise", hip + [dict(hip[0])], cpu)
+    with pytest.raises(AssertionError):
+        _compare_end_quality("synthetic denoise, loss 5 % off", [dict(h, loss=h["loss"] * 1.05) for h in hip], cpu)
+    with pytest.raises(AssertionError):
+        _compare_end_quality("synthetic denoise, 0.6 dB off", [dict(h, psnr_gt=h["psnr_gt"] + 0.6) for h in hip], cpu)
+    # SR-like: the tail loss jitters by 13 % -> Welch on the log; equal families pass, a 40 % offset is rejected, n < 8 is refused
+    cpu = fam(16, 36.0, 36.6, 5e-5, 0.2, tail=5e-5)
+    hip = fam(16, 36.0, 36.6, 5e-5, 0.2, tail=5e-5)
+    _compare_end_quality("synthetic sr", hip, cpu)
+    with pytest.raises(AssertionError):
+        _compare_end_quality("synthetic sr, loss 40 % low", [dict(h, loss_tail=h["loss_tail"] * 0.6) for h in hip], cpu)
+    with pytest.raises(AssertionError):
+        _compare_end_quality("synthetic sr, too few arms", hip[:5], cpu)
