@@ -1,6 +1,6 @@
 """CPU arms of the BASELINE.json configs[1] end-quality check, produced by the REAL reference.
 
-    python oracle/make_end_quality_golden.py [--task sr|inpaint] [--reg0] <size> <iters> <threads>[:<perturb>[:<grad_noise>]] [...]
+    python oracle/make_end_quality_golden.py [--task sr|inpaint] [--nomkldnn] [--reg0] <size> <iters> <threads>[:<perturb>[:<grad_noise>]] [...]
 
 --task sr / inpaint (BASELINE.json configs[2] / [3]): the super-resolution closure (super-resolution.ipynb:169-199: the
 loss goes through the reference's Downsampler, PSNR on the full-resolution output) and the masked closure
@@ -38,6 +38,11 @@ def main():
     if sys.argv[1] == "--task":
         task = sys.argv[2]
         del sys.argv[1:3]
+    nomkldnn = False
+    if sys.argv[1] == "--nomkldnn":           # bisect arms: the reference with oneDNN switched off (ATen's im2col + GEMM convolutions), file ..._nomkldnn.json
+        nomkldnn = True
+        torch._C._set_mkldnn_enabled(False)
+        del sys.argv[1]
     reg0 = False
     if sys.argv[1] == "--reg0":               # bisect arms: the same fits without the reg-noise path (file ..._reg0.json)
         reg0 = True
@@ -55,7 +60,7 @@ def main():
     if reg0:
         E.REG_SCALE = 0.0
     path = os.path.join(ROOT, "tests", "golden", (f"end_quality_{size}_{iters}" if task == "denoise" else
-                        f"end_quality_{task}_{size}_{iters}") + ("_reg0" if reg0 else "") + ".json")
+                        f"end_quality_{task}_{size}_{iters}") + ("_reg0" if reg0 else "") + ("_nomkldnn" if nomkldnn else "") + ".json")
     arms = json.load(open(path))["cpu_arms"] if os.path.exists(path) else []
     for th, perturb, gnoise in specs:
         torch.set_num_threads(th)
