@@ -496,6 +496,7 @@ def hbm_ops(eng):
             t = F4 * a.H * a.W * a.Cs
             B[f"bnb_stats:{bn.name}"] = 2 * t                    # g (the ring of a padded g: < 2 %) + y
             B[f"bnb_apply:{bn.name}"] = 3 * t                    # g + y -> dy  (in place after upb_stats: dz + y -> dz)
+            B[f"bnb_one:{bn.name}"] = 3 * t                      # one-launch form: g + y -> dy (the second pass re-reads from L2)
         if s.ns:
             B[f"conv_fwd:{s.skip_conv.name}"] = conv_io(s.skip_conv, xin, H * W)
             B[f"dgrad+:{s.skip_conv.name}"] = F4 * H * W * (round_up(s.ns, 4) + 2 * xin.Cs)
@@ -503,6 +504,7 @@ def hbm_ops(eng):
         deep, cat = st["deep"], st["cat_act"]
         B[f"upcat:{s.cat_bn.name}"] = F4 * (H * W * (round_up(s.ns, 4) if s.ns else 0) + deep.H * deep.W * deep.Cs + H * W * cat.Cs)
         B[f"upb_stats:{deep.bn.name}"] = F4 * (H * W * deep.C + 2 * deep.H * deep.W * deep.Cs)
+        B[f"upb_one:{deep.bn.name}"] = F4 * (H * W * deep.C + 2 * deep.H * deep.W * deep.Cs)
         if s.up.Cin > 128 and s.up.Cin <= 132:                   # thin columns of the 132-column data gradient
             B[f"dgthin:{s.up.name}"] = F4 * H * W * (round_up(s.up.Cout, 4) + 4)
     B[f"wgrad:{oc.name}"] = F4 * z * (eng.last_act.Cs + round_up(oc.Cout, 4))

@@ -3,6 +3,7 @@
 #include "dip_common.h"
 #include "bn_ticket.h"
 #include "dip_group.h"
+#include "dip_gradsrc.h"
 #include <stdlib.h>
 
 namespace {
@@ -121,43 +122,6 @@ __device__ __forceinline__ RowLayout row_layout(int C) {
     L.cg = threadIdx.x - L.prow * L.nc4;
     L.active = (int)threadIdx.x < L.rpi * L.nc4;
     return L;
-}
-
-__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
-
-// incoming gradient for pixel (r,c), channels [ch, ch+4): padded source with optional reflection fold
-__device__ __forceinline__ f32x4 grad_src4(const DipGradSrc& s, int r, int c, int H, int W, int ch) {
-    const int P = s.pad;
-    const float* base = s.g + s.choff + ch;
-    if (s.win_h > 0) {                       // adjoint of a centre crop: zero outside the window
-        const int wr = r - s.win_y, wc = c - s.win_x;
-        if (wr < 0 || wr >= s.win_h || wc < 0 || wc >= s.win_w) return f32x4{0.f, 0.f, 0.f, 0.f};
-        return ld4(base + ((size_t)wr * s.win_w + wc) * s.Cg);
-    }
-    const int Wg = W + 2 * P;
-    if (!s.fold || P == 0) return ld4(base + ((size_t)(r + P) * Wg + (c + P)) * s.Cg);
-    if (s.fold == 2) {
-        // adjoint of nn.ReplicationPad2d: a border pixel collects every ring position that clamps onto it
-        const int r0 = r == 0 ? 0 : r + P, r1 = r == H - 1 ? H - 1 + 2 * P : r + P;
-        const int c0 = c == 0 ? 0 : c + P, c1 = c == W - 1 ? W - 1 + 2 * P : c + P;
-        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int i = r0; i <= r1; ++i)
-            for (int j = c0; j <= c1; ++j) acc += ld4(base + ((size_t)i * Wg + j) * s.Cg);
-        return acc;
-    }
-    // rows of the padded domain that reflect onto r: r+P itself, P-r (top), 2(H-1)-r+P (bottom)
-    int rr[3], nr = 0, cc[3], ncn = 0;
-    rr[nr++] = r + P;
-    if (r >= 1 && r <= P) rr[nr++] = P - r;
-    if (r <= H - 2 && r >= H - 1 - P) rr[nr++] = 2 * (H - 1) - r + P;
-    cc[ncn++] = c + P;
-    if (c >= 1 && c <= P) cc[ncn++] = P - c;
-    if (c <= W - 2 && c >= W - 1 - P) cc[ncn++] = 2 * (W - 1) - c + P;
-    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int i = 0; i < nr; ++i)
-        for (int j = 0; j < ncn; ++j) acc += ld4(base + ((size_t)rr[i] * Wg + cc[j]) * s.Cg);
-    return acc;
 }
 
 // block-level reduction of per-thread (s1, s2) float4 pairs over prow, written as [blk][2][Cs]

@@ -30,6 +30,7 @@ namespace {
 
 constexpr int SM_TR_MAX = 512;      // input channels whose BatchNorm coefficients are cached in LDS
 constexpr int SM_MAX_TAPS = 27;     // ring mode: up to 3 mirror sources x 9 taps per target pixel
+constexpr int SM_BIG_TAPS = 49;     // KBIG instantiations: 5x5 / 7x7 filters (filter_size_down / _up = 5, 7: inpainting.ipynb:222-232)
 
 struct SmallGeom;
 template <class F> __host__ __device__ inline void dip_ptrs(SmallGeom&, F&) {}      // (dip_group.h: no pointers inside)
@@ -83,7 +84,8 @@ __device__ __forceinline__ void sm_wait(f32x4& a, f32x4& b) {
 
 // TR: 0 = no input transform, 1 = BatchNorm + LeakyReLU / identity (slope in (0, 1]), 2 = BatchNorm + Swish / ELU
 // One workgroup = one 32-pixel x 32-channel output tile; its NW waves split K and are summed through LDS.
-template <int TR, int NW, bool RING = false, bool GRP = false>
+// KBIG: tap tables sized for 5x5 / 7x7 filters (6 KB of LDS more; the 1x1 / 3x3 instantiations keep their occupancy)
+template <int TR, int NW, bool RING = false, bool GRP = false, bool KBIG = false>
 __global__ __launch_bounds__(64 * NW) void conv_small_kernel(const DipConvDesc d_, const SmallGeom g, const DipGrpArg<GRP> grp) {
     DIP_GRP_DESC(DipConvDesc, d);
     constexpr int SMAX = SmCfg<NW>::SMAX;
@@ -92,10 +94,11 @@ __global__ __launch_bounds__(64 * NW) void conv_small_kernel(const DipConvDesc d
     extern __shared__ __attribute__((aligned(16))) float red[];      // [NW][16][64] K-slice partial tiles
     __shared__ __attribute__((aligned(16))) float tra[TR ? SM_TR_MAX : 4];
     __shared__ __attribute__((aligned(16))) float trb[TR ? SM_TR_MAX : 4];
-    __shared__ int srcoff[RING ? SM_MAX_TAPS : 9][32];     // source pixel of (tap, output pixel), -1: padding zero / outside
+    constexpr int MAXT = RING ? SM_MAX_TAPS : (KBIG ? SM_BIG_TAPS : 9);
+    __shared__ int srcoff[MAXT][32];            // source pixel of (tap, output pixel), -1: padding zero / outside
     __shared__ int yoff[32];                    // output pixel offset (oy * pitch + ox) of the 32 pixels, -1: none
     __shared__ int boff[32];                    // mirror pixel of the fused BatchNorm backward (bnb_y index), -1: none
-    __shared__ int taps[NW][(RING ? SM_MAX_TAPS : 9) + 1];
+    __shared__ int taps[NW][MAXT + 1];
     __shared__ float fin[16 * 64];              // the summed tile, handed to wave 0
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
@@ -348,7 +351,7 @@ int small_max_pixels() {
 }
 
 bool small_geom(const DipConvDesc& d, SmallGeom* g) {
-    if (d.ks != 1 && d.ks != 3) return false;
+    if (d.ks != 1 && d.ks != 3 && d.ks != 5 && d.ks != 7) return false;
     if (d.stride != 1 && d.stride != 2) return false;
     if (d.dil != 1 && d.dil != 2) return false;
     if (d.dil == 2 && d.stride != 1) return false;
@@ -377,7 +380,8 @@ bool small_geom(const DipConvDesc& d, SmallGeom* g) {
     }
     g->nblk = dip_cdiv(d.Cout, 32);
     // waves per tile: every wave keeps its whole K slice in flight (<= SMAX steps), up to 16 waves
-    const int tmax = (d.dil == 2 && d.ks == 3 ? 4 : d.ks * d.ks) * ((d.Cin + 7) / 8);      // (a parity class sees <= 4 taps)
+    const int kcls = d.dil == 2 ? (d.ks + 1) / 2 : d.ks;            // (a parity class of a dilated gradient sees <= ceil(ks / 2)^2 taps)
+    const int tmax = kcls * kcls * ((d.Cin + 7) / 8);
     int nw = 4;
     while (nw < 16 && tmax > nw * SmCfg<8>::SMAX / 2) nw *= 2;
     static const char* force = getenv("DIP_SMALL_NW");
@@ -386,10 +390,10 @@ bool small_geom(const DipConvDesc& d, SmallGeom* g) {
     return true;
 }
 
-template <int TR, int NW, bool RING = false>
+template <int TR, int NW, bool RING = false, bool KBIG = false>
 int small_launch(const DipConvDesc& d, const SmallGeom& g, hipStream_t st) {
-    auto kern = conv_small_kernel<TR, NW, RING>;
-    auto kern_g = conv_small_kernel<TR, NW, RING, true>;         // grouped multi-instance form (dip_group.h)
+    auto kern = conv_small_kernel<TR, NW, RING, false, KBIG>;
+    auto kern_g = conv_small_kernel<TR, NW, RING, true, KBIG>;   // grouped multi-instance form (dip_group.h)
     constexpr int lds = NW * 16 * 64 * 4;
     static bool attr_set[16] = {};
     if (dip_once_per_device(attr_set)) {
@@ -403,6 +407,10 @@ int small_launch(const DipConvDesc& d, const SmallGeom& g, hipStream_t st) {
 
 template <int TR>
 int small_launch_nw(const DipConvDesc& d, const SmallGeom& g, hipStream_t st) {
+    if (d.ks > 3) {                              // 5x5 / 7x7: >= 50 K steps even at 16 channels -> 8 or 16 waves
+        if (g.nw == 16) return small_launch<TR, 16, false, true>(d, g, st);
+        return small_launch<TR, 8, false, true>(d, g, st);
+    }
     if (g.nw == 16) return small_launch<TR, 16>(d, g, st);
     if (g.nw == 8) return small_launch<TR, 8>(d, g, st);
     return small_launch<TR, 4>(d, g, st);
@@ -461,7 +469,7 @@ extern "C" int dip_conv_small_rows(const DipConvDesc* dp) {
 extern "C" int dip_conv_small(const DipConvDesc* dp, void* stream) {
     const DipConvDesc& d = *dp;
     SmallGeom g;
-    if (!small_geom(d, &g)) DIP_FAIL("conv_small: unsupported shape (1x1 / 3x3, stride or dil <= 2, <= 160 output channels)");
+    if (!small_geom(d, &g)) DIP_FAIL("conv_small: unsupported shape (1x1 / 3x3 / 5x5 / 7x7, stride or dil <= 2, <= 160 output channels)");
     if (d.bnb_y != nullptr) {
         if (d.bnb_state == nullptr || d.bnb_partials == nullptr || d.bnb_Cs < d.Cout || d.bnb_pad < 0 ||
             d.Hout <= 2 * d.bnb_pad || d.Wout <= 2 * d.bnb_pad || d.stats != nullptr)

@@ -4,12 +4,11 @@
 #include "dip_common.h"
 #include "dip_group.h"
 #include "bn_ticket.h"
+#include "dip_gradsrc.h"
 #include <stdlib.h>
 
 namespace {
 
-__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
 // PyTorch upsample_bilinear2d source index, align_corners=False, scale 0.5 (src per dst)
 __device__ __forceinline__ void bil_src(int dst, int n_in, int& i0, int& i1, float& l0, float& l1) {
@@ -290,51 +289,7 @@ __global__ __launch_bounds__(256) void upsample_bwd_stats_kernel(const float* __
         const int p0 = blockIdx.x * ppb, p1 = min(p0 + ppb, npix);
         for (int p = p0 + L.prow; p < p1; p += L.rpi) {
             const int i = p / Wl, j = p - i * Wl;
-            f32x4 du = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (mode == DIP_UP_NEAREST) {
-#pragma unroll
-                for (int dr = 0; dr < 2; ++dr)
-#pragma unroll
-                    for (int dc = 0; dc < 2; ++dc) {
-                        const int hr = 2 * i + dr - ody, hc = 2 * j + dc - odx;          // position inside the crop window
-                        const f32x4 gq = ld4(dcat + ((size_t)min(max(hr, 0), H - 1) * W + min(max(hc, 0), W - 1)) * Cs_cat + choff + ch);
-                        const float wq = (hr >= 0 && hr < H && hc >= 0 && hc < W) ? 1.f : 0.f;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) du[e] = fmaf(wq, gq[e], du[e]);
-                    }
-            } else {
-                // adjoint weights of the scale-2 bilinear up-sampling (align_corners = False) in closed form: high-res
-                // rows 2i-1 .. 2i+2 touch low-res row i with (0.25, 0.75, 0.75, 0.25); row 0 gives all of itself to
-                // i = 0, the last low-res row also collects the clamped upper neighbour, rows outside [0, H) nothing
-                // (weights of the FULL up-sampled image x "is the row inside the crop window")
-                auto inw = [](int u, int o, int nwin) { return (u - o >= 0 && u - o < nwin) ? 1.f : 0.f; };
-                const float wr[4] = {(i >= 1 ? 0.25f : 0.f) * inw(2 * i - 1, ody, H), (i == 0 ? 1.f : 0.75f) * inw(2 * i, ody, H),
-                                     (i == Hl - 1 ? 1.f : 0.75f) * inw(2 * i + 1, ody, H),
-                                     (i + 1 <= Hl - 1 ? 0.25f : 0.f) * inw(2 * i + 2, ody, H)};
-                const float wc[4] = {(j >= 1 ? 0.25f : 0.f) * inw(2 * j - 1, odx, W), (j == 0 ? 1.f : 0.75f) * inw(2 * j, odx, W),
-                                     (j == Wl - 1 ? 1.f : 0.75f) * inw(2 * j + 1, odx, W),
-                                     (j + 1 <= Wl - 1 ? 0.25f : 0.f) * inw(2 * j + 2, odx, W)};
-                // all 16 loads of the 4x4 window are issued unconditionally (clamped address, zero
-                // weight outside the image): branching on the weights serialised them
-                f32x4 gw[16];
-#pragma unroll
-                for (int tr = 0; tr < 4; ++tr) {
-                    const int hr = min(max(2 * i - 1 + tr - ody, 0), H - 1);
-#pragma unroll
-                    for (int tc = 0; tc < 4; ++tc) {
-                        const int hc = min(max(2 * j - 1 + tc - odx, 0), W - 1);
-                        gw[tr * 4 + tc] = ld4(dcat + ((size_t)hr * W + hc) * Cs_cat + choff + ch);
-                    }
-                }
-#pragma unroll
-                for (int tr = 0; tr < 4; ++tr)
-#pragma unroll
-                    for (int tc = 0; tc < 4; ++tc) {
-                        const float w = wr[tr] * wc[tc];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) du[e] = fmaf(w, gw[tr * 4 + tc][e], du[e]);
-                    }
-            }
+            const f32x4 du = up_adj_du4(dcat + choff + ch, Cs_cat, H, W, Hl, Wl, ody, odx, mode, i, j);
             const f32x4 yv = ld4(y + (size_t)p * Cy + ch);
             f32x4 g;
 #pragma unroll

@@ -136,6 +136,10 @@ class SkipEngine:
         # (the write-through stores, the ticket and the L2-bypassing row loads are three dependent memory round trips at
         # the end of the producer: -1.5 % end to end) -- opt-in
         self.ticket_fin = os.environ.get("DIP_TICKET_FIN") == "1"
+        # low-resolution BatchNorm backward as ONE launch (csrc/bn_bwd_one.hip: a workgroup owns four channels of the whole
+        # plane, so statistics -> finalise -> apply needs no grid-wide dependency); the library decides per shape
+        # (dip_bn_bwd_one_ok: DIP_BNB_ONE_MAX_PIXELS, 0 = off)
+        self.bnb_one = os.environ.get("DIP_BNB_NO_ONE") is None
         # bf16 matrix pipe for the big 3x3 layers (csrc/conv_bf3.hip: fp32 operands as three exact bf16 terms, the
         # cross products accumulated in fp32): the library decides per descriptor (DIP_CONV_BF3=8 | 9 | 6 | 0), the engine only
         # keeps the split weight planes up to date
@@ -652,7 +656,7 @@ class SkipEngine:
             # of its BatchNorm(+activation) backward rides in the epilogue
             d.ksplit, d.ws = 1, None
             rows = self.lib.dip_conv_small_rows(C.byref(d))
-            fuse = fuse_bn and x.bn is not None and r.pad_mode != N.PAD_REPLICATE
+            fuse = fuse_bn and x.bn is not None and r.pad_mode != N.PAD_REPLICATE and not self._bnb_one_ok(x)
             if sizing:
                 if fuse:
                     self.bwdp_need = max(self.bwdp_need, rows * 2 * x.bn.Cs)
@@ -736,6 +740,12 @@ class SkipEngine:
         dz = self._new(a.H * a.W * a.Cs)
         src = self._gradsrc(g, Cg if Cg is not None else a.Cs, choff, window)
         lib = self.lib
+        if self._bnb_one_ok(a) and self._fused_bnb.get(g[0].data_ptr()) is None:
+            # low resolution: statistics, finalisation and apply in ONE launch (a workgroup owns 4 channels of the plane)
+            ops.append((lib.dip_bn_bwd_one, (C.byref(src), _ptr(a.buf), a.H, a.W, a.Cs, a.C, _ptr(bn.state), bn.Cs,
+                                             float(a.slope), _ptr(dz), a.Cs, _ptr(self.grads, bn.gamma_off),
+                                             _ptr(self.grads, bn.beta_off), _ptr(bn.coef)), "bnb_one:" + bn.name))
+            return dz
         # phase 1 only reduces (dz = NULL); phase 3 recomputes the masked gradient from the source:
         # 5 tensor passes per BatchNorm instead of 6
         fused = self._fused_bnb.get(g[0].data_ptr()) if (choff == 0 and not side) else None
@@ -764,6 +774,9 @@ class SkipEngine:
                                                float(a.slope), _ptr(bn.coef), _ptr(dz), a.Cs), "bnb_apply:" + bn.name))
         return dz
 
+    def _bnb_one_ok(self, a: Act) -> bool:
+        return self.bnb_one and a.bn is not None and bool(self.lib.dip_bn_bwd_one_ok(a.H * a.W, a.C))
+
     def _emit_up_bwd(self, deep: Act, dcat, Cs_cat, choff, H, W, mode, ops, geom=None):
         bn = deep.bn
         nblk = self.lib.dip_bn_bwd_nblk(deep.H, deep.W, deep.C)
@@ -775,6 +788,14 @@ class SkipEngine:
         dz = self._new(deep.H * deep.W * deep.Cs)
         lib = self.lib
         m = N.UP_BILINEAR if mode == "bilinear" else N.UP_NEAREST
+        if self._bnb_one_ok(deep):
+            # low resolution: adjoint of the up-sampling + the three BatchNorm-backward phases of the deeper branch in ONE launch
+            gm = geom if geom is not None else dict(Hd=(H + 1) // 2, Wd=(W + 1) // 2, od_y=0, od_x=0)
+            ops.append((lib.dip_upsample_bwd_one,
+                        (_ptr(dcat), Cs_cat, choff, H, W, gm["Hd"], gm["Wd"], gm["od_y"], gm["od_x"], m, _ptr(deep.buf),
+                         deep.Cs, deep.C, _ptr(bn.state), bn.Cs, float(deep.slope), _ptr(dz), deep.Cs,
+                         _ptr(self.grads, bn.gamma_off), _ptr(self.grads, bn.beta_off), _ptr(bn.coef)), "upb_one:" + bn.name))
+            return dz
         if fin_ok:
             # adjoint of the up-sampling + phases 1 and 2 of the deeper branch's BatchNorm backward in one launch
             fin = self._bnb_fin(bn, deep.H * deep.W, ticket)
@@ -973,6 +994,8 @@ class SkipEngine:
         deps = {}
         for i, sc in enumerate(self.sc):
             c, p = f"dgrad+:s{i}.skip_conv", f"bnb_apply:s{i}.skip_bn"
+            if p not in present:
+                p = f"bnb_one:s{i}.skip_bn"            # (low resolution: the one-launch form)
             if sc.ns and c in present and p in present:        # (a wait on a never-recorded event is illegal under capture)
                 deps.setdefault(c, []).append(p)
             # ... and so does the skip conv's weight gradient (bulk stream)

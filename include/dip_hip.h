@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DIP_ABI_VERSION 5
+#define DIP_ABI_VERSION 6
 
 #define DIP_PAD_ZERO 0
 #define DIP_PAD_REFLECT 1
@@ -356,6 +356,16 @@ int dip_bn_bwd_apply(float* dz, int Cdz, const float* y, int Cy, int npix, int C
 int dip_bn_bwd_apply_src(const DipGradSrc* src, const float* y, int H, int W, int Cy, int C,
                          const float* state, int Cs, float slope, const float* coef, float* dy, int Cdy,
                          void* stream);
+/* The three phases in ONE launch for low-resolution activations (round 6; csrc/bn_bwd_one.hip): a workgroup owns four
+ * channels of the whole H x W plane, so S1 = sum dz and S2 = sum dz * xhat are workgroup-local (per-thread fp32 sums, a
+ * fixed-order fp64 reduction) and dy = a * (du * act'(a*y+b) - S1/N - xhat * S2/N) follows in the same launch; dgamma,
+ * dbeta and coef [2][Cs] are written as dip_bn_bwd_finalize writes them (each may be NULL).  Same reference ops as
+ * dip_bn_bwd_stats / _finalize / _apply_src (autograd NativeBatchNormBackward + LeakyReluBackward of
+ * models/common.py:82,96).  dip_bn_bwd_one_ok: 1 when the engine should use this form (npix <= DIP_BNB_ONE_MAX_PIXELS,
+ * default 16384 = 128 x 128; 0 switches it off). */
+int dip_bn_bwd_one_ok(int npix, int C);
+int dip_bn_bwd_one(const DipGradSrc* src, const float* y, int H, int W, int Cy, int C, const float* state, int Cs,
+                   float slope, float* dy, int Cdy, float* dgamma, float* dbeta, float* coef, void* stream);
 /* Fold a (reflection-)padded gradient back onto the image and emit it NCHW: gradient wrt
  * `net_input` for get_params('net,input') (utils/common_utils.py:47-49). */
 int dip_fold_to_nchw(const DipGradSrc* src, int H, int W, int C, float* dst, void* stream);
@@ -420,6 +430,14 @@ int dip_upsample_bwd_stats_crop_fin(const float* dcat, int Cs_cat, int choff, in
                                     int od_x, int mode, const float* y, int Cy, int C, const float* state, int Cs,
                                     float slope, float* dz, int Cdz, float* partials, int nblk, const DipBnbFin* fin,
                                     void* stream);
+
+/* Adjoint of the up-sampling + all three BatchNorm-backward phases of the deeper branch in ONE launch (the form of
+ * dip_bn_bwd_one with dip_upsample_bwd_stats_crop's gradient source; autograd UpsampleBilinear2DBackward / Nearest +
+ * NativeBatchNormBackward + LeakyReluBackward, models/skip.py:81, models/common.py:82,96): dy [Hd][Wd][Cdy] = gradient wrt
+ * the raw output y of the deeper branch's last conv.  Use when dip_bn_bwd_one_ok(Hd * Wd, C). */
+int dip_upsample_bwd_one(const float* dcat, int Cs_cat, int choff, int H, int W, int Hd, int Wd, int od_y, int od_x,
+                         int mode, const float* y, int Cy, int C, const float* state, int Cs, float slope, float* dy,
+                         int Cdy, float* dgamma, float* dbeta, float* coef, void* stream);
 
 /* ---------------------------------------------------------------- optimiser --------------- */
 /* torch.optim.Adam(lr) defaults, one fused launch over a flat arena

@@ -23,7 +23,7 @@ def test_cabi_exports_every_declared_symbol(built):
     L = ctypes.CDLL(dip_native.LIB_PATH)
     for name in declared:
         assert hasattr(L, name), name
-    assert built.dip_abi_version() == dip_native.ABI_VERSION == 5
+    assert built.dip_abi_version() == dip_native.ABI_VERSION == 6
     # struct layouts agree with the header's field order (sizes on LP64)
     assert ctypes.sizeof(dip_native.DipTransform) == 24
     assert ctypes.sizeof(dip_native.DipGradSrc) == 40     # + the crop window of round 3
@@ -119,7 +119,7 @@ def test_planner_builds_launch_lists_for_every_option(built):
         assert names[-1] == "conv_fwd:out" and sum(n.startswith("conv_fwd:") for n in names) == len(eng.convs), name
         bnames = [n for _, _, n in eng.bwd_ops]
         assert sum(n.startswith("wgrad:") for n in bnames) == len(eng.convs), name
-        assert sum(n.startswith("bnb_apply:") for n in bnames) == len(eng.bns), name
+        assert sum(n.startswith(("bnb_apply:", "bnb_one:", "upb_one:")) for n in bnames) == len(eng.bns), name
         if cfg["kw"].get("downsample_mode") in ("avg", "max"):
             assert any(n.startswith("pool:") for n in names) and any(n.startswith("poolb:") for n in bnames), name
     net = skip(8, 3, [16, 16], [16, 16], [4, 4], act_fun="none", pad="reflection")

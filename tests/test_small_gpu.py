@@ -34,6 +34,13 @@ SMALL_CASES = [
     (256, 128, 3, 1, REFLECT, 16, 16, True),     # kate net decoder conv (256 input channels)
     (128, 132, 3, 1, REFLECT, 24, 24, False),    # 5 column blocks (the data gradient's shape as a forward)
     (16, 16, 3, 1, REPLICATE, 12, 20, True),     # replication padding
+    # 5x5 / 7x7 filters (round 6: filter_size_down = 5 of the 'library' inpainting net, inpainting.ipynb:222-232)
+    (16, 16, 5, 1, REFLECT, 40, 56, True),       # library s0.down_b at reduced size: 50 K steps, 8 waves
+    (32, 64, 5, 2, REFLECT, 24, 36, True),       # library s2.down_a (stride 2)
+    (128, 128, 5, 1, REFLECT, 14, 22, True),     # library s4.down_b at its real size: 400 K steps, 16 waves, 3 chunks
+    (128, 128, 5, 2, REFLECT, 14, 22, True),     # library s5.down_a at its real size
+    (4, 16, 5, 2, REFLECT, 32, 48, False),       # first conv of the net (<= 4 input channels)
+    (16, 24, 7, 1, ZERO, 12, 20, True),          # 7x7 (feature_inversion.ipynb:169), zero padding
 ]
 
 
@@ -89,6 +96,11 @@ DGRAD_CASES = [
     (36, 64, 3, 1, ZERO, 21, 13),
     (160, 128, 3, 1, REFLECT, 16, 16),           # 5 full column blocks
     (16, 16, 3, 1, REPLICATE, 12, 20),
+    (16, 16, 5, 1, REFLECT, 24, 40),             # 5x5: gradient on the domain padded by 2
+    (32, 64, 5, 2, REFLECT, 24, 36),             # stride-2 5x5: parity classes of 9 / 6 / 6 / 4 taps
+    (128, 128, 5, 2, REFLECT, 14, 22),           # library s5.down_a at its real size
+    (64, 64, 5, 1, ZERO, 13, 9),
+    (16, 8, 7, 2, REFLECT, 16, 20),
 ]
 
 

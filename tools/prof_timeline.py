@@ -14,6 +14,8 @@ qcol = "stream_id" if "stream_id" in cols else ("queue_id" if "queue_id" in cols
 rows = list(cur.execute(f"select name, start, end, {qcol or 0} from kernels order by start"))
 short = lambda n: re.sub(r"\(anonymous namespace\)::|\(Dip.*|void ", "", n)[:58]
 marks = [i for i, r in enumerate(rows) if "noise_axpy" in r[0]]
+if not marks:      # a configuration without reg-noise (the 'library' inpainting net, reg_noise_std = 0): the weight repack opens an iteration
+    marks = [i for i, r in enumerate(rows) if "pack_weights_kernel" in r[0]]
 if len(marks) < back + 1:
     sys.exit("not enough iterations in the trace")
 i0, i1 = marks[-back - 1], marks[-back]
