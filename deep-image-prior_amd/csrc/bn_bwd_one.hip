@@ -4,17 +4,21 @@
 //
 // Why.  The three-launch form (bn_kernels.hip: statistics -> finalise -> apply) exists because the two sums
 //   S1 = sum dz,  S2 = sum dz * xhat,   dz = du * act'(a y + b)
-// run over the whole H x W plane: a grid-wide dependency.  At <= 128 x 128 each of the three launches is 6..10 us of
-// launch + dependent-load latency for 1..30 us-worth of HBM traffic, and the hour-glass walks 14 such BatchNorms per
-// iteration of the default 512 x 512 net (24 of the 'library' net): 0.3..0.4 ms of the dependent chain.  Here a workgroup
+// run over the whole H x W plane: a grid-wide dependency.  Here a workgroup
 // OWNS four channels of the whole plane (NHWC: one 16-byte load per pixel), so the dependency is workgroup-local:
 //   pass 1  every thread walks its pixels: du (gradient source, reflection / replication fold, crop window, or the
 //           up-sampling adjoint), y -> per-thread fp32 sums, then a fixed-order fp64 reduction over the workgroup's waves;
 //   pass 2  the same pixels again (the plane's slice is L2-resident: <= 2 x 16 B x 16 K pixels per workgroup):
 //           dy = a * (dz - S1 / N - xhat * S2 / N), written once.
 // dgamma, dbeta and the coefficient block [k1, k2] are written as dip_bn_bwd_finalize writes them.  grid = ceil(C / 4)
-// workgroups of 1024 threads: 32 CUs for a 128-channel layer -- the rest of the chip stays free for the bulk stream's
-// weight gradients, which is where the main chain's low-resolution walk wants it.
+// workgroups of 1024 threads: 32 CUs for a 128-channel layer.
+// MEASURED (round 6, tools/bnone_time.py, profiles/r06_bn_bwd_one.txt): back to back, 8.2 / 10.5 us at 16^2 / 32^2 x 128
+// channels against 12.1 / 12.5 us for the three launches -- and 34 / 135 us at 64^2 / 128^2 against 13 / 19: a workgroup
+// that owns 4 of 128 channels uses 16 bytes of every 128-byte line it pulls into its L1, so 32 CUs deliver 1/8 of their
+// fill bandwidth, and owning 32 channels (whole lines) leaves 4 CUs: ownership needs few CUs, bandwidth needs many.  The
+// form therefore serves <= 1024 pixels only (DIP_BNB_ONE_MAX_PIXELS); in the iteration it removes 12 launches of the
+// default net (244 -> 232) and 9 of the 'library' net for +-0 / +0.4 % it/s: what the low-resolution walk waits for is
+// dependent memory round trips, not launches (DESIGN.md section 3.7 said so; this is the measurement).
 // Deterministic (fixed pixel -> thread map, fixed reduction order); the rounded product dz = du * act'(z) is the same
 // expression as in bn_kernels.hip.
 #include "dip_common.h"
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(ONE_NT) void bn_bwd_one_kernel(const DipGradSrc src
 int one_max_pixels() {
     static const int v = [] {
         const char* e = getenv("DIP_BNB_ONE_MAX_PIXELS");
-        return e ? atoi(e) : 1536;
+        return e ? atoi(e) : 1024;
     }();
     return v;
 }
@@ -145,7 +149,7 @@ int one_max_pixels() {
 }  // namespace
 
 // 1 when the engine should run a BatchNorm backward over npix pixels x C channels as ONE launch (DIP_BNB_ONE_MAX_PIXELS,
-// default 16384 = 128 x 128; 0 switches the form off)
+// default 1024; 0 switches the form off)
 extern "C" int dip_bn_bwd_one_ok(int npix, int C) {
     return (npix >= 1 && npix <= one_max_pixels() && C >= 1 && C <= 4096) ? 1 : 0;
 }

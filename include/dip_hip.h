@@ -362,7 +362,7 @@ int dip_bn_bwd_apply_src(const DipGradSrc* src, const float* y, int H, int W, in
  * dbeta and coef [2][Cs] are written as dip_bn_bwd_finalize writes them (each may be NULL).  Same reference ops as
  * dip_bn_bwd_stats / _finalize / _apply_src (autograd NativeBatchNormBackward + LeakyReluBackward of
  * models/common.py:82,96).  dip_bn_bwd_one_ok: 1 when the engine should use this form (npix <= DIP_BNB_ONE_MAX_PIXELS,
- * default 16384 = 128 x 128; 0 switches it off). */
+ * default 1024 = 32 x 32: above that a 4-channel slice of the plane costs 8x its bytes in L1 fills; 0 switches it off). */
 int dip_bn_bwd_one_ok(int npix, int C);
 int dip_bn_bwd_one(const DipGradSrc* src, const float* y, int H, int W, int Cy, int C, const float* state, int Cs,
                    float slope, float* dy, int Cdy, float* dgamma, float* dbeta, float* coef, void* stream);
