@@ -254,21 +254,91 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 }
 
 // ------------------------------------------------------------------------------------------
+// Phase 2 inside the phase-3 launches (round 6).  For a low-resolution BatchNorm the finalisation launch between the
+// statistics pass and the apply pass is a dependent ~10 us (bn_bwd_finalize_kernel: 18 per iteration of the 'library' net,
+// 191 us of its main chain; 30 per iteration of the default net) that produces 2 x C floats.  With few partial rows
+// EVERY block of the apply launch reduces them for itself in its prologue -- thread (prow, cg) sums rows prow, prow + rpi, ..
+// of its four channels in fp64, a fixed-order tree over prow through LDS, the same values in every block -- and block 0
+// writes dgamma, dbeta and the coefficient block.  No ticket, no fence, no cross-workgroup dependency (the forms of
+// bn_ticket.h were measured slower than the launch; this one reads <= 320 rows x C x 8 bytes from L2 per block).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bnb_fin_prologue(const RowLayout& L, const float* __restrict__ partials, int nrows, int Cs,
+                                                 int C, int npix, double* shd, float* dgamma, float* dbeta, float* coef,
+                                                 f32x4& k1, f32x4& k2) {
+    double a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = 0.0;
+    if (L.active) {
+        const int ch = L.cg * 4;
+#pragma unroll 4
+        for (int t = L.prow; t < nrows; t += L.rpi) {
+            const float* p = partials + (size_t)t * 2 * Cs + ch;
+            const f32x4 v1 = ld4(p), v2 = ld4(p + Cs);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a[e] += (double)v1[e]; a[4 + e] += (double)v2[e]; }
+        }
+    }
+    double* mine = shd + (size_t)threadIdx.x * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) mine[k] = a[k];
+    for (int s = dip_pow2_ceil(L.rpi) >> 1; s >= 1; s >>= 1) {
+        __syncthreads();
+        if (L.active && L.prow < s && L.prow + s < L.rpi) {
+            const double* q = shd + (size_t)((L.prow + s) * L.nc4 + L.cg) * 8;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) mine[k] += q[k];
+        }
+    }
+    __syncthreads();
+    if (!L.active) return;
+    const double* r0 = shd + (size_t)L.cg * 8;          // the prow == 0 thread of this channel group
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        k1[e] = (float)(r0[e] / npix);
+        k2[e] = (float)(r0[4 + e] / npix);
+    }
+    if (blockIdx.x == 0 && L.prow == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = L.cg * 4 + e;
+            if (c < C) {
+                if (dbeta != nullptr) dbeta[c] = (float)r0[e];
+                if (dgamma != nullptr) dgamma[c] = (float)r0[4 + e];
+                if (coef != nullptr) { coef[c] = k1[e]; coef[Cs + c] = k2[e]; }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // backward phase 3 (in place): dy = a * (dz - k1 - xhat * k2)
 // ------------------------------------------------------------------------------------------
-template <bool GRP = false>
+// FIN: phase 2 in the prologue (bnb_fin_prologue): `fin` = {partials, nrows, dgamma, dbeta}, coef is written, not read
+struct BnbFinArg {
+    const float* partials;
+    int nrows;
+    float* dgamma;
+    float* dbeta;
+};
+template <class F> __host__ __device__ inline void dip_ptrs(BnbFinArg& b, F& f) { f(b.partials); f(b.dgamma); f(b.dbeta); }
+
+template <bool GRP = false, bool FIN = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* dz_, int Cdz, const float* __restrict__ y_, int Cy,
                                                            int npix, int C, const float* __restrict__ state_, int Cs,
-                                                           const float* __restrict__ coef_, int ppb, const DipGrpArg<GRP> grp) {
+                                                           float* coef_, int ppb, const BnbFinArg fin_, const DipGrpArg<GRP> grp) {
     DIP_GRP_PTR(float*, dz);
     DIP_GRP_PTR(const float*, y);
     DIP_GRP_PTR(const float*, state);
-    DIP_GRP_PTR(const float*, coef);
+    DIP_GRP_PTR(float*, coef);
+    DIP_GRP_DESC(BnbFinArg, fin);
+    __shared__ __attribute__((aligned(16))) double shd[FIN ? 256 * 8 : 1];
     const RowLayout L = row_layout(C);
+    f32x4 k1 = f32x4{0.f, 0.f, 0.f, 0.f}, k2 = k1;
+    if constexpr (FIN) bnb_fin_prologue(L, fin.partials, fin.nrows, Cs, C, npix, shd, fin.dgamma, fin.dbeta, coef, k1, k2);
     if (!L.active) return;
     const int ch = L.cg * 4;
     const f32x4 mean = ld4(state + ch), rstd = ld4(state + Cs + ch), a = ld4(state + 2 * Cs + ch);
-    const f32x4 k1 = ld4(coef + ch), k2 = ld4(coef + Cs + ch);
+    if constexpr (!FIN) { k1 = ld4(coef + ch); k2 = ld4(coef + Cs + ch); }
     const int p0 = blockIdx.x * ppb;
     const int p1 = min(p0 + ppb, npix);
     for (int p = p0 + L.prow; p < p1; p += L.rpi) {
@@ -286,22 +356,27 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* dz_, int Cdz, 
 // backward phase 3 from the gradient source (phase 1 ran with dz == NULL): the masked gradient is
 // recomputed instead of being written by phase 1 and re-read here -- 5 tensor passes per BatchNorm
 // instead of 6:  dy = a * (du * lrelu'(a*y+b) - k1 - xhat * k2)
-template <bool GRP = false>
+template <bool GRP = false, bool FIN = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_src_kernel(const DipGradSrc src_, const float* __restrict__ y_, int H,
                                                                int W, int Cy, int C, const float* __restrict__ state_,
-                                                               int Cs, float slope, const float* __restrict__ coef_,
-                                                               float* __restrict__ dy_, int Cdy, int ppb, const DipGrpArg<GRP> grp) {
+                                                               int Cs, float slope, float* coef_,
+                                                               float* __restrict__ dy_, int Cdy, int ppb, const BnbFinArg fin_,
+                                                               const DipGrpArg<GRP> grp) {
     DIP_GRP_DESC(DipGradSrc, src);
     DIP_GRP_PTR(const float*, y);
     DIP_GRP_PTR(const float*, state);
-    DIP_GRP_PTR(const float*, coef);
+    DIP_GRP_PTR(float*, coef);
     DIP_GRP_PTR(float*, dy);
+    DIP_GRP_DESC(BnbFinArg, fin);
+    __shared__ __attribute__((aligned(16))) double shd[FIN ? 256 * 8 : 1];
     const RowLayout L = row_layout(C);
+    f32x4 k1 = f32x4{0.f, 0.f, 0.f, 0.f}, k2 = k1;
+    if constexpr (FIN) bnb_fin_prologue(L, fin.partials, fin.nrows, Cs, C, H * W, shd, fin.dgamma, fin.dbeta, coef, k1, k2);
     if (!L.active) return;
     const int ch = L.cg * 4;
     const f32x4 mean = ld4(state + ch), rstd = ld4(state + Cs + ch), a = ld4(state + 2 * Cs + ch),
                 b = ld4(state + 3 * Cs + ch);
-    const f32x4 k1 = ld4(coef + ch), k2 = ld4(coef + Cs + ch);
+    if constexpr (!FIN) { k1 = ld4(coef + ch); k2 = ld4(coef + Cs + ch); }
     const int npix = H * W;
     const int p0 = blockIdx.x * ppb;
     const int p1 = min(p0 + ppb, npix);
@@ -439,7 +514,7 @@ extern "C" int dip_bn_bwd_apply(float* dz, int Cdz, const float* y, int Cy, int 
     int nb;
     const int ppb = pixels_per_block(npix, C, &nb, true);
     dip_launch_pair<DIP_FAM_BN>(bn_bwd_apply_kernel<false>, bn_bwd_apply_kernel<true>, dim3(nb), dim3(256), 0, (hipStream_t)stream, dz, Cdz, y, Cy, npix,
-                                C, state, Cs, coef, ppb);
+                                C, state, Cs, const_cast<float*>(coef), ppb, BnbFinArg{});
     DIP_CHECK_LAUNCH();
     return 0;
 }
@@ -451,7 +526,37 @@ extern "C" int dip_bn_bwd_apply_src(const DipGradSrc* src, const float* y, int H
     int nb;
     const int ppb = pixels_per_block(H * W, C, &nb, true);
     dip_launch_pair<DIP_FAM_BN>(bn_bwd_apply_src_kernel<false>, bn_bwd_apply_src_kernel<true>, dim3(nb), dim3(256), 0, (hipStream_t)stream, *src, y, H,
-                                W, Cy, C, state, Cs, slope, coef, dy, Cdy, ppb);
+                                W, Cy, C, state, Cs, slope, const_cast<float*>(coef), dy, Cdy, ppb, BnbFinArg{});
+    DIP_CHECK_LAUNCH();
+    return 0;
+}
+
+// phase 2 + phase 3 in one launch: every block reduces the `nrows` partial rows [nrows][2][Cs] in its prologue
+// (bnb_fin_prologue); block 0 writes dgamma, dbeta (may be NULL) and coef
+extern "C" int dip_bn_bwd_fin_rows_ok(int nrows, int C) {
+    static const int maxrows = getenv("DIP_BNB_FIN_MAX_ROWS") ? atoi(getenv("DIP_BNB_FIN_MAX_ROWS")) : 320;
+    return (nrows >= 1 && nrows <= maxrows && C >= 1 && C <= 1024) ? 1 : 0;
+}
+
+extern "C" int dip_bn_bwd_apply_fin(float* dz, int Cdz, const float* y, int Cy, int npix, int C, const float* state, int Cs,
+                                    const float* partials, int nrows, float* dgamma, float* dbeta, float* coef, void* stream) {
+    if (C > 1024 || (Cs & 3) || partials == nullptr || nrows < 1) DIP_FAIL("bn_bwd_apply_fin: C <= 1024, Cs % 4 == 0, partial rows");
+    int nb;
+    const int ppb = pixels_per_block(npix, C, &nb, true);
+    dip_launch_pair<DIP_FAM_BN>(bn_bwd_apply_kernel<false, true>, bn_bwd_apply_kernel<true, true>, dim3(nb), dim3(256), 0, (hipStream_t)stream, dz, Cdz,
+                                y, Cy, npix, C, state, Cs, coef, ppb, BnbFinArg{partials, nrows, dgamma, dbeta});
+    DIP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dip_bn_bwd_apply_src_fin(const DipGradSrc* src, const float* y, int H, int W, int Cy, int C, const float* state,
+                                        int Cs, float slope, const float* partials, int nrows, float* dgamma, float* dbeta,
+                                        float* coef, float* dy, int Cdy, void* stream) {
+    if (C > 1024 || (Cs & 3) || partials == nullptr || nrows < 1) DIP_FAIL("bn_bwd_apply_src_fin: C <= 1024, Cs % 4 == 0, partial rows");
+    int nb;
+    const int ppb = pixels_per_block(H * W, C, &nb, true);
+    dip_launch_pair<DIP_FAM_BN>(bn_bwd_apply_src_kernel<false, true>, bn_bwd_apply_src_kernel<true, true>, dim3(nb), dim3(256), 0, (hipStream_t)stream,
+                                *src, y, H, W, Cy, C, state, Cs, slope, coef, dy, Cdy, ppb, BnbFinArg{partials, nrows, dgamma, dbeta});
     DIP_CHECK_LAUNCH();
     return 0;
 }

@@ -452,11 +452,27 @@ extern "C" int dip_conv_dgrad_ring(const DipConvDesc* dp, void* stream) {
 }
 
 // 1 when the engine should run `d` through dip_conv_small: a shape the kernel serves and a small output
+// 5x5 / 7x7 filters (round 6; tools/thin_sweep.py on the 'library' net's layers, profiles/r06_thin_sweep.txt): the tiled
+// kernel's alternative is split-K + finish, so the bound depends on the shape --
+//   * dilated (data gradient of a stride-2 conv): four parity classes of <= 9 taps each, the tiled kernel multiplies the
+//     zeros of the dilation: conv_small wins up to ~21 k output pixels (116 x 180: 28 us against 50), loses at 228 x 356;
+//   * stride 2 forward: up to ~5 k output pixels (56 x 88: 27 against 30 us);
+//   * stride 1: the 3x3 bound; but K >= 3200 products on < 600 pixels (128 channels at 14 x 22 and below) is ONE 32 x 32
+//     tile per CU doing 10 us of MFMAs on <= 40 CUs, and the tiled kernel's 24-way split-K + finish is 4 us faster.
 extern "C" int dip_conv_small_eligible(const DipConvDesc* dp) {
     static const bool off = getenv("DIP_CONV_NO_SMALL") != nullptr;
+    static const int k5_d2 = getenv("DIP_SMALL_K5_DIL2_MAX_PIXELS") ? atoi(getenv("DIP_SMALL_K5_DIL2_MAX_PIXELS")) : 24000;
+    static const int k5_s2 = getenv("DIP_SMALL_K5_S2_MAX_PIXELS") ? atoi(getenv("DIP_SMALL_K5_S2_MAX_PIXELS")) : 5000;
+    static const int k5_min = getenv("DIP_SMALL_K5_MIN_PIXELS") ? atoi(getenv("DIP_SMALL_K5_MIN_PIXELS")) : 600;
     SmallGeom g;
     if (off || !small_geom(*dp, &g)) return 0;
-    return dp->Hout * dp->Wout <= small_max_pixels() ? 1 : 0;
+    const int px = dp->Hout * dp->Wout;
+    if (dp->ks >= 5) {
+        if (dp->dil == 2) return px <= (k5_d2 > small_max_pixels() ? k5_d2 : small_max_pixels()) ? 1 : 0;
+        if (dp->stride == 2) return px <= (k5_s2 > small_max_pixels() ? k5_s2 : small_max_pixels()) ? 1 : 0;
+        if (dp->ks * dp->ks * dp->Cin >= 3200 && px < k5_min) return 0;
+    }
+    return px <= small_max_pixels() ? 1 : 0;
 }
 
 // rows of the partial buffers (stats: [rows][3][CoutP32]; bnb_partials: [rows][2][bnb_Cs]) of dip_conv_small(d)

@@ -823,9 +823,27 @@ extern "C" int dip_wgrad_plan2(int Hout, int Wout, int Cin, int Cout, int ks, in
     *chan_block = (ks == 1) ? 4 : 1;
     int rc = dip_wgrad_plan(Hout, Wout, Cin, Cout, ks, stride, nsplit);
     if (rc) return rc;
-    if (is_thin(ks, Cin, Cout) || is_thin_cin(ks, Cin, Cout) || (ks != 3 && ks != 1)) return 0;
+    if (is_thin(ks, Cin, Cout) || is_thin_cin(ks, Cin, Cout)) return 0;
     const int nt = dip_conv_wgrad_ntiles(Hout, Wout);
     static const bool off = getenv("DIP_WGRAD_NO_SMALL_PLAN") != nullptr;
+    if (ks == 5 && !off) {
+        // 5x5 layers (round 6; tools/wgrad_sweep.py k5 on the 'library' net's shapes, kernel + slab reduction in us,
+        // profiles/r06_wgrad_sweep_k5.txt): dip_wgrad_plan's ">= 4 pixel tiles per workgroup, ~512 workgroups" gave the
+        // low-resolution 128-channel layers 20..100 heavy workgroups; one pixel tile per walker (<= 128 walkers) and, at
+        // <= 2 tiles, one TAP per workgroup instead of one filter row:
+        //   128>128 @28x44 (nt 21): (5 rows, n 5) 55+11 -> (n 21) 27+15      64>128 s2: 68+7 -> 22+8
+        //   128>128 @14x22 (nt 8):  (n 2) 44+11 -> (n 8) 18+12               s2: 55+11 -> 20+12
+        //   128>128 @7x11  (nt 2):  (n 1) 24+11 -> (25 taps, n 2) 10+11      s2: 31+11 -> 13+11
+        //   16>32 s2 @112x176 (nt 308): (n 77) 95+5 -> (n 128) 76+8          16>16 @224x352: 101+5 -> 91+5
+        const int CoutP5 = dip_round_up(Cout, 32);
+        int n = nt < 128 ? nt : 128;
+        const long long slab5 = 25ll * dip_round_up(Cin, 32) * CoutP5;
+        while (n > 1 && (long long)n * slab5 > (64ll << 20)) n /= 2;
+        *nsplit = n * wgrad_kw(CoutP5);
+        *tap_groups = nt <= 2 ? 25 : 5;
+        return 0;
+    }
+    if (ks != 3 && ks != 1) return 0;
     if (nt > 256 || off) return 0;
     if (ks == 3 && nt > 128) return 0;
     const int CinP = dip_round_up(Cin, 32), CoutP = dip_round_up(Cout, 32);
@@ -911,8 +929,11 @@ extern "C" int dip_conv_wgrad(const DipWgradDesc* dp, void* stream) {
     }
     if (d.ks == 3 && d.stride == 2)
         return g == 1 ? launch<3, 2, 9, 1>(d, st) : (g == 3 ? launch<3, 2, 3, 1>(d, st) : launch<3, 2, 1, 1>(d, st));
-    if (d.ks == 5 && d.stride == 1) return launch<5, 1, 5, 1>(d, st);
-    if (d.ks == 5 && d.stride == 2) return launch<5, 2, 5, 1>(d, st);
+    // 5x5: one filter row per workgroup (5 tap groups) or -- low-resolution layers, tap_groups == 25 from dip_wgrad_plan2 --
+    // one tap per workgroup
+    if (d.ks == 5 && g != 1 && g != 5 && g != 25) DIP_FAIL("conv_wgrad: tap_groups of a 5x5 layer must be 5 (0, 1) or 25");
+    if (d.ks == 5 && d.stride == 1) return g == 25 ? launch<5, 1, 1, 1>(d, st) : launch<5, 1, 5, 1>(d, st);
+    if (d.ks == 5 && d.stride == 2) return g == 25 ? launch<5, 2, 1, 1>(d, st) : launch<5, 2, 5, 1>(d, st);
     if (d.ks == 7 && d.stride == 1) return launch<7, 1, 7, 1>(d, st);
     if (d.ks == 7 && d.stride == 2) return launch<7, 2, 7, 1>(d, st);
     if (d.ks == 8 && d.stride == 2) return launch<8, 2, 8, 1>(d, st);        // Lanczos2 Downsampler conv: one filter row per workgroup

@@ -140,6 +140,25 @@ class SkipEngine:
         # plane, so statistics -> finalise -> apply needs no grid-wide dependency); the library decides per shape
         # (dip_bn_bwd_one_ok: DIP_BNB_ONE_MAX_PIXELS, 0 = off)
         self.bnb_one = os.environ.get("DIP_BNB_NO_ONE") is None
+        # phase 2 of a BatchNorm backward in the prologue of its apply launch when phase 1 left few partial rows
+        # (dip_bn_bwd_apply_src_fin / _apply_fin; the library decides: dip_bn_bwd_fin_rows_ok, DIP_BNB_FIN_MAX_ROWS)
+        # MEASURED (profiles/r06_ab_bnb_fin_fuse.txt): -8 launches per iteration of the default net, -10 of the 'library' net,
+        # and -0.4 % / -0.5 % it/s -- a dependent 5 us launch costs the chain ~2.5 us, the prologue's rows cost every block
+        # as much.  Opt-in (DIP_BNB_FIN_FUSE=1); parity-tested either way (tests/test_bnone_gpu.py).
+        self.bnb_fin_fuse = os.environ.get("DIP_BNB_FIN_FUSE") == "1"
+        # second bulk stream (round 6): the weight gradients of layers with <= DIP_BULK2_MAX_PIXELS output pixels alternate
+        # between two bulk streams (scratch sets of their own), so that two of these small launches -- none fills the chip --
+        # run side by side.  The 'library' net's bulk stream was backlogged: 1.35 ms of weight gradients queued one after the
+        # other, the last three still waiting when the main chain had finished (profiles/r06_library_timeline_*.txt)
+        # Only for nets WITHOUT big MFMA-bound layers: with them (the default / kate nets: 128 x 128-channel 3x3 convs at
+        # >= 256 x 256) the one bulk stream is not backlogged and a second one costs 2 % (more fork events on the main
+        # chain, two MFMA-bound launches side by side gain nothing): library 370.6 -> 383.0 it/s, default 182.4 -> 178.1
+        # (profiles/r06_ab_bulk2.txt).  DIP_BULK2_MAX_PIXELS overrides (0 = off).
+        self.bulk2_max_pixels = 0
+        if self.two_streams:
+            env = os.environ.get("DIP_BULK2_MAX_PIXELS")
+            self.bulk2_max_pixels = int(env) if env is not None else -1        # -1: decided per plan (_build_plan)
+        self._bulk2, self._bulk_flip = set(), False
         # bf16 matrix pipe for the big 3x3 layers (csrc/conv_bf3.hip: fp32 operands as three exact bf16 terms, the
         # cross products accumulated in fp32): the library decides per descriptor (DIP_CONV_BF3=8 | 9 | 6 | 0), the engine only
         # keeps the split weight planes up to date
@@ -312,6 +331,7 @@ class SkipEngine:
     def _reset_sizing(self):
         """Sizes of the shared scratch buffers, accumulated by the sizing pass of the planner."""
         self.stat_need = self.wg_need = self.wgb_need = self.bwdp_need = self.ws_need = 4
+        self.wg2_need = self.wgb2_need = 4             # slab scratch of the second bulk stream
         self.stat2_need = self.ws2_need = 4            # scratch of the skip-branch convs (side stream)
         self.bwdp2_need = 4                            # ... and of the skip-branch BatchNorm backward
         self.bwdp3_need = 4                            # fused BatchNorm-backward partials of the thin data-gradient columns
@@ -325,6 +345,17 @@ class SkipEngine:
         self._alloc = []
         oc = self.out_conv
         self.n_out = oc.Cout
+        if getattr(self, "_bulk2_auto", self.bulk2_max_pixels < 0):
+            # second bulk stream iff no conv of the net is a big MFMA-bound layer at this input size (see __init__)
+            self._bulk2_auto = True
+            big, h, w = False, H, W
+            for sc in self.sc:
+                hl, wl = ((h + 1) // 2, (w + 1) // 2) if sc.pool is None else (h // 2, w // 2)
+                for r, px in ((sc.down_a, hl * wl), (sc.down_b, hl * wl), (sc.up, h * w), (sc.up1, h * w)):
+                    if r is not None and r.ks >= 3 and r.Cin >= 96 and r.Cout >= 96 and px >= 65536:
+                        big = True
+                h, w = hl, wl
+            self.bulk2_max_pixels = 0 if big else 100000
         # The plan is generated twice: a sizing pass (no allocations, no descriptors) that only
         # measures the shared scratch buffers, then the emitting pass.
         for sizing in (True, False):
@@ -335,6 +366,8 @@ class SkipEngine:
                 self.bwd_scratch = self._new(self.bwdp_need)
                 self.wg_scratch = self._new(self.wg_need)
                 self.wgb_scratch = self._new(self.wgb_need)
+                self.wg_scratch2 = self._new(self.wg2_need)
+                self.wgb_scratch2 = self._new(self.wgb2_need)
                 self.ws_scratch = self._new(self.ws_need)
                 self.stats_scratch2 = self._new(self.stat2_need)
                 self.ws_scratch2 = self._new(self.ws2_need)
@@ -348,6 +381,7 @@ class SkipEngine:
             self._deferred = []
             self._replicate_bufs = set()
             self._fwd_side = set()
+            self._bulk2, self._bulk_flip = set(), False
             self._entered_defer_scale = False
             self.x_nhwc = self._buf(H * W * round_up(Cin_img, 4))
             xin = Act(self.x_nhwc, H, W, Cin_img)
@@ -578,19 +612,31 @@ class SkipEngine:
         if scale is not None and self.defer_scale >= 0:
             ops = self._deferred            # enters the list at the next _flush_deferred_wgrads()
         slab = r.ks * r.ks * CinP * CoutP
+        # small layers alternate between the two bulk streams (same decision in both planner passes)
+        second = False
+        if Ho * Wo <= self.bulk2_max_pixels:
+            second = self._bulk_flip
+            self._bulk_flip = not self._bulk_flip
         if self._sizing:
-            self.wg_need = max(self.wg_need, nsplit * slab)
-            self.wgb_need = max(self.wgb_need, nsplit * CoutP)
+            if second:
+                self.wg2_need = max(self.wg2_need, nsplit * slab)
+                self.wgb2_need = max(self.wgb2_need, nsplit * CoutP)
+            else:
+                self.wg_need = max(self.wg_need, nsplit * slab)
+                self.wgb_need = max(self.wgb_need, nsplit * CoutP)
             return
         has_b = r.b_off >= 0
+        wg, wgb = (self.wg_scratch2, self.wgb_scratch2) if second else (self.wg_scratch, self.wgb_scratch)
+        if second:
+            self._bulk2.update(("wgrad:" + r.name, "wgred:" + r.name))
         d = N.DipWgradDesc(_ptr(x.buf), x.H, x.W, x.Cs, x.C, x.transform(), _ptr(dy), Ho, Wo,
                            round_up(r.Cout, 4), r.Cout, r.ks, r.stride, r.pad_mode, r.P,
-                           _ptr(self.wg_scratch), _ptr(self.wgb_scratch) if has_b else None, nsplit, tap_groups,
+                           _ptr(wg), _ptr(wgb) if has_b else None, nsplit, tap_groups,
                            chan_block)
         self.keep.append(d)
         ops.append((self.lib.dip_conv_wgrad, (C.byref(d),), "wgrad:" + r.name))
         ops.append((self.lib.dip_wgrad_reduce,
-                    (_ptr(self.wg_scratch), _ptr(self.wgb_scratch) if has_b else None, nsplit, r.ks, r.Cin, r.Cout,
+                    (_ptr(wg), _ptr(wgb) if has_b else None, nsplit, r.ks, r.Cin, r.Cout,
                      _ptr(self.grads, r.w_off), _ptr(self.grads, r.b_off) if has_b else None), "wgred:" + r.name))
 
     def _emit_dgrad(self, r: ConvRec, x: Act, dy, ops, accumulate_into=None, fuse_bn=False, need_pad=0):
@@ -759,6 +805,9 @@ class SkipEngine:
         elif fused is not None:
             # phase 1 already ran in the epilogue of the data-gradient launch(es) that produced g (_emit_dgrad)
             rows, rows_lo, c_lo = fused
+            if c_lo == 0 and self._fin_rows_ok(rows, a.C):
+                ops.append(self._apply_src_fin(src, a, bn, self.bwd_scratch, rows, dz))
+                return dz
             ops.append((lib.dip_bn_bwd_finalize2, (_ptr(self.bwd_scratch), rows, _ptr(self.bwd_scratch3) if c_lo else None,
                                                    rows_lo, c_lo, bn.Cs, bn.C, a.H * a.W,
                                                    _ptr(self.grads, bn.gamma_off), _ptr(self.grads, bn.beta_off),
@@ -767,12 +816,25 @@ class SkipEngine:
             ops.append((lib.dip_bn_bwd_stats, (C.byref(src), _ptr(a.buf), a.H, a.W, a.Cs, a.C, _ptr(bn.state), bn.Cs,
                                                float(a.slope), None, a.Cs, _ptr(scratch), nblk),
                         "bnb_stats:" + bn.name))
+            if self._fin_rows_ok(nblk, a.C):
+                # few partial rows: every block of the apply launch reduces them in its prologue (no finalisation launch)
+                ops.append(self._apply_src_fin(src, a, bn, scratch, nblk, dz))
+                return dz
             ops.append((lib.dip_bn_bwd_finalize, (_ptr(scratch), nblk, bn.Cs, bn.C, a.H * a.W,
                                                   _ptr(self.grads, bn.gamma_off), _ptr(self.grads, bn.beta_off),
                                                   _ptr(bn.coef)), "bnb_fin:" + bn.name))
         ops.append((lib.dip_bn_bwd_apply_src, (C.byref(src), _ptr(a.buf), a.H, a.W, a.Cs, a.C, _ptr(bn.state), bn.Cs,
                                                float(a.slope), _ptr(bn.coef), _ptr(dz), a.Cs), "bnb_apply:" + bn.name))
         return dz
+
+    def _fin_rows_ok(self, rows, Cc) -> bool:
+        return self.bnb_fin_fuse and bool(self.lib.dip_bn_bwd_fin_rows_ok(rows, Cc))
+
+    def _apply_src_fin(self, src, a: Act, bn: BNRec, scratch, rows, dz):
+        return (self.lib.dip_bn_bwd_apply_src_fin,
+                (C.byref(src), _ptr(a.buf), a.H, a.W, a.Cs, a.C, _ptr(bn.state), bn.Cs, float(a.slope), _ptr(scratch), rows,
+                 _ptr(self.grads, bn.gamma_off), _ptr(self.grads, bn.beta_off), _ptr(bn.coef), _ptr(dz), a.Cs),
+                "bnb_apply:" + bn.name)
 
     def _bnb_one_ok(self, a: Act) -> bool:
         return self.bnb_one and a.bn is not None and bool(self.lib.dip_bn_bwd_one_ok(a.H * a.W, a.C))
@@ -817,6 +879,12 @@ class SkipEngine:
                         (_ptr(dcat), Cs_cat, choff, H, W, geom["Hd"], geom["Wd"], geom["od_y"], geom["od_x"], m,
                          _ptr(deep.buf), deep.Cs, deep.C, _ptr(bn.state), bn.Cs, float(deep.slope), _ptr(dz), deep.Cs,
                          _ptr(self.bwd_scratch), nblk), "upb_stats:" + bn.name))
+        if self._fin_rows_ok(nblk, deep.C):
+            ops.append((lib.dip_bn_bwd_apply_fin, (_ptr(dz), deep.Cs, _ptr(deep.buf), deep.Cs, deep.H * deep.W, deep.C,
+                                                   _ptr(bn.state), bn.Cs, _ptr(self.bwd_scratch), nblk,
+                                                   _ptr(self.grads, bn.gamma_off), _ptr(self.grads, bn.beta_off),
+                                                   _ptr(bn.coef)), "bnb_apply:" + bn.name))
+            return dz
         ops.append((lib.dip_bn_bwd_finalize, (_ptr(self.bwd_scratch), nblk, bn.Cs, bn.C, deep.H * deep.W,
                                               _ptr(self.grads, bn.gamma_off), _ptr(self.grads, bn.beta_off),
                                               _ptr(bn.coef)), "bnb_fin:" + bn.name))
@@ -931,9 +999,9 @@ class SkipEngine:
         st_ = self._aux.get((slot, self.device))
         if st_ is None:
             # (HIP stream priorities for the auxiliary streams were measured in round 4: no effect; default priority)
-            st_ = self._aux[(slot, self.device)] = ([torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)], {})
+            st_ = self._aux[(slot, self.device)] = ([torch.cuda.Stream(self.device) for _ in range(3)], {})
         aux, events = st_
-        streams = [main, aux[0], aux[1]]
+        streams = [main, aux[0], aux[1], aux[2]]         # main, side, bulk, second bulk
         ptrs = [s_.cuda_stream for s_ in streams]
         check = N.check
         deps = deps or {}
@@ -946,8 +1014,8 @@ class SkipEngine:
             return ev
 
         main_seq = 0                          # main-stream ops issued so far
-        forked = [0, -1, -1]                  # main_seq at the last fork of each auxiliary stream
-        pending = [False, False, False]       # auxiliary work the main stream has not joined yet
+        forked = [0, -1, -1, -1]              # main_seq at the last fork of each auxiliary stream
+        pending = [False, False, False, False]    # auxiliary work the main stream has not joined yet
         for k, (fn, args, name) in enumerate(ops):
             c = cls_fn(name)
             if c and forked[c] != main_seq:
@@ -971,7 +1039,7 @@ class SkipEngine:
                 pending[c] = True
             else:
                 main_seq += 1
-        for c in (1, 2):
+        for c in (1, 2, 3):
             if pending[c]:
                 ev = event((key, "join", -c))
                 ev.record(streams[c])
@@ -1018,7 +1086,9 @@ class SkipEngine:
         if deps is None:
             deps = self._bwd_deps = self._backward_deps(ops)
             self._bwd_deps_for = ops
-        self._run_two_streams(ops, main, self._BWD_SIDE, lambda n: False, "bwd", deps)
+        bulk2 = self._bulk2
+        cls = self._BWD_SIDE if not bulk2 else (lambda n: 3 if n in bulk2 else self._BWD_SIDE(n))
+        self._run_two_streams(ops, main, cls, lambda n: False, "bwd", deps)
 
     def _run_forward_two_streams(self, ops, main):
         side = self._fwd_side

@@ -151,6 +151,12 @@ _SIGS = {
                                    C.c_void_p, C.c_void_p]),
     "dip_bn_bwd_apply_src": (C.c_int, [C.POINTER(DipGradSrc), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "dip_bn_bwd_fin_rows_ok": (C.c_int, [C.c_int, C.c_int]),
+    "dip_bn_bwd_apply_fin": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                       C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dip_bn_bwd_apply_src_fin": (C.c_int, [C.POINTER(DipGradSrc), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                           C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_int, C.c_void_p]),
     "dip_bn_bwd_one_ok": (C.c_int, [C.c_int, C.c_int]),
     "dip_bn_bwd_one": (C.c_int, [C.POINTER(DipGradSrc), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                  C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

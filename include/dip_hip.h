@@ -356,6 +356,17 @@ int dip_bn_bwd_apply(float* dz, int Cdz, const float* y, int Cy, int npix, int C
 int dip_bn_bwd_apply_src(const DipGradSrc* src, const float* y, int H, int W, int Cy, int C,
                          const float* state, int Cs, float slope, const float* coef, float* dy, int Cdy,
                          void* stream);
+/* Phases 2 + 3 in one launch (round 6): every block of the apply launch reduces the `nrows` partial rows [nrows][2][Cs] of
+ * phase 1 for itself in its prologue (fp64, fixed order: the same k1, k2 in every block) and block 0 writes dgamma, dbeta
+ * (may be NULL) and coef -- no dip_bn_bwd_finalize launch in the dependent chain.  Same reference ops as above.
+ * dip_bn_bwd_fin_rows_ok: 1 when the engine should use the form (nrows <= DIP_BNB_FIN_MAX_ROWS, default 320: every block
+ * reads nrows * C * 8 bytes from L2). */
+int dip_bn_bwd_fin_rows_ok(int nrows, int C);
+int dip_bn_bwd_apply_fin(float* dz, int Cdz, const float* y, int Cy, int npix, int C, const float* state, int Cs,
+                         const float* partials, int nrows, float* dgamma, float* dbeta, float* coef, void* stream);
+int dip_bn_bwd_apply_src_fin(const DipGradSrc* src, const float* y, int H, int W, int Cy, int C, const float* state, int Cs,
+                             float slope, const float* partials, int nrows, float* dgamma, float* dbeta, float* coef,
+                             float* dy, int Cdy, void* stream);
 /* The three phases in ONE launch for low-resolution activations (round 6; csrc/bn_bwd_one.hip): a workgroup owns four
  * channels of the whole H x W plane, so S1 = sum dz and S2 = sum dz * xhat are workgroup-local (per-thread fp32 sums, a
  * fixed-order fp64 reduction) and dy = a * (du * act'(a*y+b) - S1/N - xhat * S2/N) follows in the same launch; dgamma,

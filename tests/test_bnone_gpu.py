@@ -184,3 +184,64 @@ def test_upsample_bwd_one_matches_autograd(dev, ns, nd, Hh, Ww, mode, od):
     torch.cuda.synchronize()
     scale = float(dz.abs().max())
     assert torch.allclose(dy, dz, rtol=1e-4, atol=2e-5 * scale)
+
+
+@pytest.mark.parametrize("Cc,Hh,Ww,P,slope", [(128, 28, 44, 2, 0.2), (64, 56, 88, 2, 0.2), (132, 32, 32, 1, 1.0), (4, 64, 64, 0, 0.2),
+                                               (16, 19, 23, 1, 0.2)])
+def test_bn_bwd_finalise_in_the_apply_prologue(dev, Cc, Hh, Ww, P, slope):
+    """dip_bn_bwd_stats + dip_bn_bwd_apply_src_fin (phase 2 in the prologue of phase 3) against fp64 autograd and against
+    the three-launch form; dip_bn_bwd_apply_fin (in place on dz) against the same."""
+    lib = N.lib()
+    g = torch.Generator().manual_seed(4)
+    y = torch.randn(1, Cc, Hh, Ww, generator=g) * 2.0 + torch.randn(1, Cc, 1, 1, generator=g) * 3.0
+    gamma, beta = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g)
+    G = torch.randn(1, Cc, Hh + 2 * P, Ww + 2 * P, generator=g)
+
+    def ref(dt):
+        yy = y.to(dt).requires_grad_(True)
+        ga, be = gamma.to(dt).requires_grad_(True), beta.to(dt).requires_grad_(True)
+        u = F.batch_norm(yy, None, None, ga, be, True, 0.1, 1e-5)
+        u = torch.maximum(u, slope * u)
+        if P:
+            u = F.pad(u, (P,) * 4, mode="reflect")
+        (u * G.to(dt)).sum().backward()
+        return yy.grad, ga.grad, be.grad
+
+    r64, r32 = ref(torch.float64), ref(torch.float32)
+    Cs = round_up(Cc, 4)
+    state = _state(y, gamma, beta).to(dev).contiguous()
+    st = H.stream(dev)
+    yb, Gb = H.to_nhwc(y.to(dev)), H.to_nhwc(G.to(dev))
+    src = N.DipGradSrc(Gb.data_ptr(), P, 1 if P else 0, Cs, 0)
+    nblk = lib.dip_bn_bwd_nblk(Hh, Ww, Cc)
+    assert lib.dip_bn_bwd_fin_rows_ok(nblk, Cc) == 1, nblk
+    part = torch.full((nblk * 2 * Cs,), float("nan"), device=dev)
+    dz = torch.full((Hh * Ww * Cs,), float("nan"), device=dev)
+    N.check(lib.dip_bn_bwd_stats(C.byref(src), yb.data_ptr(), Hh, Ww, Cs, Cc, state.data_ptr(), Cs, slope, dz.data_ptr(), Cs,
+                                 part.data_ptr(), nblk, st))
+    dy = torch.full((Hh * Ww * Cs,), float("nan"), device=dev)
+    dgam, dbet = torch.full((Cc,), float("nan"), device=dev), torch.full((Cc,), float("nan"), device=dev)
+    coef = torch.full((2 * Cs,), float("nan"), device=dev)
+    N.check(lib.dip_bn_bwd_apply_src_fin(C.byref(src), yb.data_ptr(), Hh, Ww, Cs, Cc, state.data_ptr(), Cs, slope, part.data_ptr(),
+                                         nblk, dgam.data_ptr(), dbet.data_ptr(), coef.data_ptr(), dy.data_ptr(), Cs, st), "apply_src_fin")
+    torch.cuda.synchronize()
+    _check("bn_bwd_fin.dy", H.from_nhwc(dy, Cc, Hh, Ww), r64[0], r32[0], floor=5e-6)
+    _check("bn_bwd_fin.dgamma", dgam, r64[1], r32[1], floor=5e-6)
+    _check("bn_bwd_fin.dbeta", dbet, r64[2], r32[2], floor=5e-6)
+    # three launches on the same partial rows: the same fp64 sums up to their order -> coefficients within an ulp or two
+    dg3, db3, coef3 = torch.zeros(Cc, device=dev), torch.zeros(Cc, device=dev), torch.zeros(2 * Cs, device=dev)
+    N.check(lib.dip_bn_bwd_finalize(part.data_ptr(), nblk, Cs, Cc, Hh * Ww, dg3.data_ptr(), db3.data_ptr(), coef3.data_ptr(), st))
+    dy3 = torch.full((Hh * Ww * Cs,), float("nan"), device=dev)
+    N.check(lib.dip_bn_bwd_apply_src(C.byref(src), yb.data_ptr(), Hh, Ww, Cs, Cc, state.data_ptr(), Cs, slope, coef3.data_ptr(),
+                                     dy3.data_ptr(), Cs, st))
+    torch.cuda.synchronize()
+    assert torch.allclose(coef.view(2, Cs)[:, :Cc], coef3.view(2, Cs)[:, :Cc], rtol=3e-7, atol=0)
+    assert torch.allclose(dgam, dg3, rtol=3e-7, atol=0) and torch.allclose(dbet, db3, rtol=3e-7, atol=0)
+    assert torch.allclose(dy, dy3, rtol=1e-5, atol=1e-6 * float(dy3.abs().max()))
+    # in place on dz (the form behind dip_upsample_bwd_stats)
+    dgam2, dbet2, coef2 = torch.zeros(Cc, device=dev), torch.zeros(Cc, device=dev), torch.zeros(2 * Cs, device=dev)
+    N.check(lib.dip_bn_bwd_apply_fin(dz.data_ptr(), Cs, yb.data_ptr(), Cs, Hh * Ww, Cc, state.data_ptr(), Cs, part.data_ptr(), nblk,
+                                     dgam2.data_ptr(), dbet2.data_ptr(), coef2.data_ptr(), st), "apply_fin")
+    torch.cuda.synchronize()
+    assert torch.equal(coef2, coef) and torch.equal(dgam2, dgam) and torch.equal(dbet2, dbet)
+    assert torch.allclose(dz, dy, rtol=1e-5, atol=1e-6 * float(dy.abs().max()))

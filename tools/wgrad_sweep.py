@@ -60,7 +60,35 @@ SHAPES = ((132, 128, 3, 1, 512), (128, 128, 3, 1, 512), (132, 128, 3, 1, 256), (
           (128, 128, 3, 2, 32), (128, 128, 3, 1, 16), (128, 128, 1, 1, 256), (128, 128, 1, 1, 128), (128, 128, 1, 1, 64),
           (128, 128, 1, 1, 32), (256, 128, 3, 1, 512))
 
+K5 = ((16, 16, 5, 1, 224, 352), (16, 32, 5, 2, 224, 352), (32, 32, 5, 1, 112, 176), (32, 64, 5, 2, 112, 176), (64, 64, 5, 1, 56, 88),
+      (64, 128, 5, 2, 56, 88), (128, 128, 5, 1, 28, 44), (128, 128, 5, 2, 28, 44), (128, 128, 5, 1, 14, 22), (128, 128, 5, 2, 14, 22),
+      (128, 128, 5, 1, 7, 11))       # the 'library' inpainting net at 448 x 704 (inpainting.ipynb:222-232): Cin, Cout, ks, stride, Hin, Win
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "k5":       # (tap_groups, nsplit) sweep of the 5x5 layers (dip_wgrad_plan2's 5x5 table)
+        for (Cin, Cout, ks, s, Hh, Ww) in K5:
+            Ho, Wo = Hh // s, Ww // s
+            nt = lib.dip_conv_wgrad_ntiles(Ho, Wo)
+            planned = N.wgrad_plan2(Ho, Wo, Cin, Cout, ks, s)
+            kw = 4 if Cout <= 32 else (2 if Cout <= 64 else 1)
+            rows = []
+            for g in (5, 25):
+                n = 1
+                while n <= nt:
+                    try:
+                        _, us, rus, tf = bench(Cin, Cout, ks, s, Hh, Ww, plan=(n * kw, g, 1), reps=5)
+                        rows.append((us + rus, g, n, us, rus))
+                    except Exception as e:
+                        print("fail", g, n, e)
+                    n *= 2
+                if n // 2 != nt:
+                    _, us, rus, tf = bench(Cin, Cout, ks, s, Hh, Ww, plan=(nt * kw, g, 1), reps=5)
+                    rows.append((us + rus, g, nt, us, rus))
+            _, us0, rus0, _ = bench(Cin, Cout, ks, s, Hh, Ww, plan=planned, reps=5)
+            rows.sort()
+            best = " ".join(f"g{g}n{n}:{us:.0f}+{rus:.0f}" for _, g, n, us, rus in rows[:6])
+            print(f"{Cin}>{Cout} k{ks}s{s} out{Ho}x{Wo} nt={nt} planned={planned} {us0:.0f}+{rus0:.0f} | {best}", flush=True)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "small":
         for (Cin, Cout, ks, s, Hh) in SHAPES:
             Ho = Hh // s
