@@ -893,6 +893,42 @@ def timed_run(fits, steps, warmup, use_graph, barrier):
     return t, graph is not None, note, ps.summary(t0, t1)
 
 
+def host_issue(fits, n=4):
+    """Host time of ISSUING one iteration (the Python thread, no synchronisation inside the window; the queues are empty at
+    its start and n iterations fit into them): with the engine's command lists (dip_list_run: one foreign call per direction)
+    and, for comparison, launch by launch from Python as rounds 1-5 did.  What N ranks on one host cost it per GPU."""
+    import torch
+    out = {}
+    engs = [f.engine for f in fits]
+    was = [e.use_clist for e in engs]
+    try:
+        for label, flag in (("command_list", True), ("python_loop", False)):
+            for e in engs:
+                e.use_clist, e._clists = flag, {}
+            for f in fits:
+                f.step()                       # (compiles the lists / creates the events)
+            best = None
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    for f in fits:
+                        f.step()
+                t = (time.perf_counter() - t0) / n
+                best = t if best is None else min(best, t)
+            torch.cuda.synchronize()
+            out[label + "_ms_per_iteration"] = round(1e3 * best, 3)
+    finally:
+        for e, w in zip(engs, was):
+            e.use_clist, e._clists = w, {}
+    nl = count_kernels(engs[0])
+    out["launches_per_iteration"] = nl
+    out["us_per_launch"] = {k.replace("_ms_per_iteration", ""): round(1e3 * v / max(nl, 1), 2) for k, v in out.items() if k.endswith("_ms_per_iteration")}
+    out["what"] = ("host wall time of issuing one whole iteration (closure + optimiser step) with nothing waited for: minimum over "
+                   "3 windows of %d iterations; the GPU needs ms_per_step for it" % n)
+    return out
+
+
 def grouped_fits(config, images, dev):
     """The same fits as one dip_group.GroupedFits (ONE launch list for all of them): fresh nets with the seeds of `images`."""
     from dip_group import GroupedFits
@@ -1134,6 +1170,12 @@ def main():
             sustained = {"it_s": round(len(fits) * 300 / ts, 3), "ms_per_step": round(1e3 * ts / 300, 3), "steps": 300,
                          "warmup": 50, "hipgraph": sg, "power": spower,
                          "what": "BASELINE.md section 4 protocol: 50 warm-up + 300 timed iterations, same fit, same mode"}
+        hissue = None
+        if world == 1 and n_inst == 1 and not graphed and os.environ.get("DIP_BENCH_CHILD") is None:
+            try:
+                hissue = host_issue(fits)
+            except Exception as e:          # the headline does not depend on it
+                hissue = {"error": str(e)[:200]}
         cb = None if (args.no_cpu_baseline or world > 1 or args.config != "default") else cpu_baseline()
         its = world * len(fits) * args.steps / tmax
         n_launch = count_kernels(eng)
@@ -1161,7 +1203,7 @@ def main():
             "per_rank_final_loss_hex": [float(v).hex() for v in per_rank_loss],
             "timed_region_power": best.get("power"),
             "roofline": rl, "roofline_wgrad": rw, "roofline_conv3x3_all": r3, "roofline_hbm": rh,
-            "sustained": sustained, "build_id": _N.lib().dip_build_id().decode(),
+            "sustained": sustained, "host_issue": hissue, "build_id": _N.lib().dip_build_id().decode(),
             "cpu_baseline": cb, "eager_notebook": eager, "fp32_mfma_only": fp32_only, "grouped_batch_of_4": batch4,
             "device": device_info(local),
             "host_affinity_rank0": affinity,

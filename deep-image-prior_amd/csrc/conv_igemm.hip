@@ -490,9 +490,23 @@ extern "C" int dip_conv_bf3_n64_plan(int ntiles, int Cin, int Cout);       // co
 
 // Launch plan of one convolution: split-K factor, rows of the BatchNorm partial buffer, and the
 // split-K workspace size in floats (0 when ksplit == 1).
+extern "C" int dip_conv_thin_shape_ok(int Hout, int Wout, int Cin, int Cout, int ks, int stride);      // conv_thin.hip
+static int conv_plan_impl(int Hout, int Wout, int Cin, int Cout, int ks, int stride, int* ksplit, int* stats_rows,
+                          int64_t* ws_floats, bool allow_thin);
 extern "C" int dip_conv_plan(int Hout, int Wout, int Cin, int Cout, int ks, int stride, int* ksplit,
                              int* stats_rows, int64_t* ws_floats) {
+    return conv_plan_impl(Hout, Wout, Cin, Cout, ks, stride, ksplit, stats_rows, ws_floats, true);
+}
+static int conv_plan_impl(int Hout, int Wout, int Cin, int Cout, int ks, int stride, int* ksplit, int* stats_rows,
+                          int64_t* ws_floats, bool allow_thin) {
     const int ntiles = dip_conv_ntiles(Hout, Wout);
+    // thin layers (<= 64 channels in and out, 3x3 / 5x5, above conv_small's range): conv_thin_kernel, always one pass
+    if (allow_thin && dip_conv_thin_shape_ok(Hout, Wout, Cin, Cout, ks, stride)) {
+        *ksplit = 1;
+        *stats_rows = ntiles;
+        *ws_floats = 0;
+        return 0;
+    }
     const int gy = dip_cdiv(dip_round_up(Cout, 32), 128);
     int units = units_of(dip_round_up(Cin, 4), ks, stride);
     if (!units) DIP_FAIL("conv_plan: unsupported kernel size / stride");
@@ -542,7 +556,7 @@ extern "C" int dip_conv_plan_dil2(int Hout, int Wout, int Cin, int Cout, int ks,
                                   int64_t* ws_floats) {
     static const bool off = getenv("DIP_CONV_NO_PHASE") != nullptr || getenv("DIP_CONV_NO_DMA") != nullptr;
     const int CoutP = dip_round_up(Cout, 32);
-    if (off || ks != 3 || (CoutP % 128) != 0) return dip_conv_plan(Hout, Wout, Cin, Cout, ks, 1, ksplit, stats_rows, ws_floats);
+    if (off || ks != 3 || (CoutP % 128) != 0) return conv_plan_impl(Hout, Wout, Cin, Cout, ks, 1, ksplit, stats_rows, ws_floats, false);
     const int ntiles = dip_conv_ntiles((Hout + 1) / 2, (Wout + 1) / 2);
     const int wgs = 4 * ntiles * (CoutP / 128);
     const int nchunks = dip_cdiv(dip_round_up(Cin, 4), 32);
@@ -578,9 +592,13 @@ extern "C" int dip_conv1x1_res(const DipConvDesc* dp, void* stream);
 extern "C" int dip_conv_bf3_eligible(const DipConvDesc* dp);
 extern "C" int dip_conv_bf3_cols(const DipConvDesc* dp, int n_base, int ncols, void* stream);
 
+extern "C" int dip_conv_thin_eligible(const DipConvDesc* dp);
+extern "C" int dip_conv_thin(const DipConvDesc* dp, void* stream);
+
 extern "C" int dip_conv_variant(const DipConvDesc* dp) {
     const DipConvDesc& d = *dp;
     if (dip_conv1x1_res_eligible(dp)) return 6;
+    if (dip_conv_thin_eligible(dp)) return 8;
     static const bool no_dma = getenv("DIP_CONV_NO_DMA") != nullptr;      // A/B switches for profiling
     static const bool no_extra = getenv("DIP_CONV_NO_EXTRA") != nullptr;
     const int CoutP = dip_round_up(d.Cout, 32);
@@ -648,6 +666,7 @@ extern "C" int dip_conv_igemm(const DipConvDesc* dp, void* stream) {
         return dip_conv_igemm_dma_cols(dp, ncols, stream);
     }
     if (variant == 6) return dip_conv1x1_res(dp, stream);
+    if (variant == 8) return dip_conv_thin(dp, stream);
     if (variant == 7) return dip_conv_bf3_cols(dp, 0, dip_round_up(d.Cout, 128), stream);
     if (variant == 1 || variant == 4 || variant == 5) rc = dip_conv_igemm_dma(dp, ksplit, stream);
     else if (d.ks == 1 && d.stride == 1) rc = launch_bn<1, 1, 32>(d, st, ksplit, d.ws);

@@ -5,7 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 
-static char g_err[256] = "";
+static thread_local char g_err[256] = "";      // per thread, like the group context below
 
 extern "C" void dip_set_error(const char* msg) {
     strncpy(g_err, msg ? msg : "", sizeof(g_err) - 1);

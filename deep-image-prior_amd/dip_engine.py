@@ -120,6 +120,10 @@ class SkipEngine:
         # than the ~8 us launch it would overlap)
         self.side_min_pixels = int(os.environ.get("DIP_SIDE_MIN_PIXELS", "0"))
         self._fwd_side, self._deferred, self._entered_defer_scale, self._fused_bnb = set(), [], False, {}
+        # the launch lists are compiled into command lists (dip_native.CmdList -> dip_list_run: one foreign call per direction
+        # and iteration instead of one per launch); DIP_NO_CLIST=1 issues them from Python, launch by launch, as rounds 1-5 did
+        self.use_clist = os.environ.get("DIP_NO_CLIST") is None
+        self._clists = {}
         self._replicate_bufs = set()
         # BatchNorm-backward statistics in the epilogue of the data-gradient launch (DipConvDesc.bnb_*) instead of a pass
         # of their own: 18 launches and one pass over g fewer, but measured (round 3) as a wash -- the epilogue's
@@ -341,6 +345,7 @@ class SkipEngine:
         if min(H, W) < 2 ** self.nscales:
             raise NotImplementedError(f"dip-amd: input {H}x{W} is too small for {self.nscales} scales")
         self.H, self.W, self.Cimg = H, W, Cin_img
+        self._clists = {}
         self._reset_sizing()
         self._alloc = []
         oc = self.out_conv
@@ -971,15 +976,10 @@ class SkipEngine:
         return ops
 
     # ------------------------------------------------------------------ run
-    def _run(self, ops, stream):
-        check = N.check
-        for fn, args, name in ops:
-            rc = fn(*args, stream)
-            if rc:
-                check(rc, name)
-
-    def _run_two_streams(self, ops, main, cls_fn, join_before_fn, key, deps=None):
-        """Launch list on the main HIP stream + two auxiliary streams; cls_fn(name) -> 0 main, 1 side, 2 bulk.
+    def _schedule(self, ops, cls_fn=None, join_before_fn=None, deps=None):
+        """The static schedule of a launch list on the main HIP stream + up to three auxiliary streams:
+        [("launch", k, c) | ("record", tag, c) | ("wait", c, tag)], k = index into ops, c = stream class (cls_fn(name) ->
+        0 main, 1 side, 2 bulk, 3 second bulk; None: everything on the main stream), tag = event name.
         Backward: the weight-gradient kernels (+ their slab reductions) of a layer depend only on that
         layer's dy and the stored activations, and nothing but the optimiser step waits for them: they form the
         BULK stream.  Co-running a big weight gradient with the big data gradient of the same layer buys nothing
@@ -992,58 +992,97 @@ class SkipEngine:
         BatchNorm finalisation) of a scale next to the encoder convs (scratch of its own).
         Fork: before an auxiliary op, its stream waits for an event recorded on the main stream if the main stream
         has advanced since that stream's last fork; join: main waits for the side stream in front of every op
-        `join_before_fn` selects, and for both at the end.  `deps` = {consumer op name: [producer op names]}: the
+        `join_before_fn` selects, and for all of them at the end.  `deps` = {consumer op name: [producer op names]}: the
         consumer's stream waits for an event recorded right after the producer (finer than a join)."""
-        capturing = torch.cuda.is_current_stream_capturing()
-        slot = "cap" if capturing else "eager"      # separate streams / events for captured and eager runs
-        st_ = self._aux.get((slot, self.device))
-        if st_ is None:
-            # (HIP stream priorities for the auxiliary streams were measured in round 4: no effect; default priority)
-            st_ = self._aux[(slot, self.device)] = ([torch.cuda.Stream(self.device) for _ in range(3)], {})
-        aux, events = st_
-        streams = [main, aux[0], aux[1], aux[2]]         # main, side, bulk, second bulk
-        ptrs = [s_.cuda_stream for s_ in streams]
-        check = N.check
+        sched = []
+        if cls_fn is None:
+            return [("launch", k, 0) for k in range(len(ops))]
         deps = deps or {}
         producers = {p for ps in deps.values() for p in ps}
-
-        def event(tag):
-            ev = events.get(tag)
-            if ev is None:
-                ev = events[tag] = torch.cuda.Event()
-            return ev
-
         main_seq = 0                          # main-stream ops issued so far
         forked = [0, -1, -1, -1]              # main_seq at the last fork of each auxiliary stream
         pending = [False, False, False, False]    # auxiliary work the main stream has not joined yet
         for k, (fn, args, name) in enumerate(ops):
             c = cls_fn(name)
             if c and forked[c] != main_seq:
-                ev = event((key, "fork", k))
-                ev.record(main)
-                streams[c].wait_event(ev)
+                sched += [("record", ("fork", k), 0), ("wait", c, ("fork", k))]
                 forked[c] = main_seq
             if c == 0 and pending[1] and join_before_fn(name):
-                ev = event((key, "join", k))
-                ev.record(streams[1])
-                main.wait_event(ev)
+                sched += [("record", ("join", k), 1), ("wait", 0, ("join", k))]
                 pending[1] = False
             for prod in deps.get(name, ()):
-                streams[c].wait_event(event((key, "dep", prod)))
-            rc = fn(*args, ptrs[c])
-            if rc:
-                check(rc, name)
+                sched.append(("wait", c, ("dep", prod)))
+            sched.append(("launch", k, c))
             if name in producers:
-                event((key, "dep", name)).record(streams[c])
+                sched.append(("record", ("dep", name), c))
             if c:
                 pending[c] = True
             else:
                 main_seq += 1
         for c in (1, 2, 3):
             if pending[c]:
-                ev = event((key, "join", -c))
-                ev.record(streams[c])
-                main.wait_event(ev)
+                sched += [("record", ("join", -c), c), ("wait", 0, ("join", -c))]
+        return sched
+
+    def _aux_streams(self):
+        """Auxiliary streams (side, bulk, second bulk) + the Python path's events of the current mode: captured and eager
+        runs own separate sets."""
+        slot = "cap" if torch.cuda.is_current_stream_capturing() else "eager"
+        st_ = self._aux.get((slot, self.device))
+        if st_ is None:
+            # (HIP stream priorities for the auxiliary streams were measured in round 4: no effect; default priority)
+            st_ = self._aux[(slot, self.device)] = ([torch.cuda.Stream(self.device) for _ in range(3)], {})
+        return slot, st_[0], st_[1]
+
+    def _issue(self, ops, main, key, cls_fn=None, join_before_fn=None, deps=None):
+        """Issues a launch list: compiled once per (key, length) into a command list and run by ONE dip_list_run call, or
+        (DIP_NO_CLIST=1) walked in Python with torch events -- the same schedule either way."""
+        multi = cls_fn is not None
+        slot, aux, events = self._aux_streams() if multi else ("one", [], None)
+        ck = (key, len(ops), multi)
+        ent = self._clists.get(ck)
+        if ent is None:
+            sched = self._schedule(ops, cls_fn, join_before_fn, deps)
+            cl = None
+            if self.use_clist:
+                evidx = {}
+                cmds = []
+                for c in sched:
+                    if c[0] == "launch":
+                        fn, args, name = ops[c[1]]
+                        cmds.append(("launch", fn, args, c[2], name))
+                    elif c[0] == "record":
+                        cmds.append(("record", evidx.setdefault(c[1], len(evidx)), c[2]))
+                    else:
+                        cmds.append(("wait", c[1], evidx.setdefault(c[2], len(evidx))))
+                cl = N.CmdList(cmds)
+            ent = self._clists[ck] = (sched, cl)
+        sched, cl = ent
+        if cl is not None:
+            cl.run([main.cuda_stream] + [s_.cuda_stream for s_ in aux], slot)
+            return
+        streams = [main] + aux
+        ptrs = [s_.cuda_stream for s_ in streams]
+        check = N.check
+        for c in sched:
+            if c[0] == "launch":
+                fn, args, name = ops[c[1]]
+                rc = fn(*args, ptrs[c[2]])
+                if rc:
+                    check(rc, name)
+            elif c[0] == "record":
+                ev = events.get((key, c[1]))
+                if ev is None:
+                    ev = events[(key, c[1])] = torch.cuda.Event()
+                ev.record(streams[c[2]])
+            else:
+                streams[c[1]].wait_event(events[(key, c[2])])
+
+    def _run(self, ops, main, key="one"):
+        self._issue(ops, main, key)
+
+    def _run_two_streams(self, ops, main, cls_fn, join_before_fn, key, deps=None):
+        self._issue(ops, main, key, cls_fn, join_before_fn, deps)
 
     # stream class of a backward op: 2 = bulk (weight gradients), 1 = side, 0 = main
     _BWD_SIDE = staticmethod(lambda n: 2 if n.startswith(("wgrad:", "wgred:")) else
@@ -1110,14 +1149,14 @@ class SkipEngine:
         if self.two_streams:
             self._run_forward_two_streams(ops, main)
         else:
-            self._run(ops, stream)
+            self._run(ops, main, "fwd1")
 
     def _launch_backward(self, main):
         """The static backward launch list (dy of the output conv already in self.dy_out)."""
         if self.two_streams:
             self._run_backward_two_streams(self.bwd_ops, main)
         else:
-            self._run(self.bwd_ops, main.cuda_stream)
+            self._run(self.bwd_ops, main, "bwd1")
 
     def forward(self, x: torch.Tensor, head=None):
         """Runs the forward launch list.  head = None: returns the network output [1,C,H,W].
@@ -1214,7 +1253,7 @@ class SkipEngine:
             self._launch_backward(main)
             gx = None
             if need_input_grad:
-                self._run(self.bwd_input_ops, stream)
+                self._run(self.bwd_input_ops, main, "bwdin")
                 gbuf, pad = self.sc[0].gin
                 src = N.DipGradSrc(_ptr(gbuf), pad, 1 if pad > 0 else 0, round_up(self.Cimg, 4), 0)
                 gx = torch.empty((1, self.Cimg, H, W), dtype=torch.float32, device=dev)

@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdip_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 PAD_ZERO, PAD_REFLECT, PAD_REPLICATE = 0, 1, 2
 UP_NEAREST, UP_BILINEAR = 0, 1
@@ -84,6 +84,11 @@ class DipUpcatDesc(C.Structure):
                 ("Hd", C.c_int32), ("Wd", C.c_int32), ("od_y", C.c_int32), ("od_x", C.c_int32)]
 
 
+class DipCmd(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("fn", C.c_int32), ("stream", C.c_int32), ("event", C.c_int32),
+                ("slots", C.POINTER(C.c_uint64)), ("nslots", C.c_int32), ("reserved", C.c_int32)]
+
+
 class DipIterState(C.Structure):
     _fields_ = [("step", C.c_uint64), ("step_size", C.c_float), ("bc2_sqrt", C.c_float)]
 
@@ -100,6 +105,12 @@ _SIGS = {
     "dip_build_id": (C.c_char_p, []),
     "dip_last_error": (C.c_char_p, []),
     "dip_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
+    "dip_list_fn_id": (C.c_int, [C.c_char_p]),
+    "dip_list_fn_nargs": (C.c_int, [C.c_int]),
+    "dip_list_run": (C.c_int, [C.POINTER(DipCmd), C.c_int, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.c_int,
+                               C.POINTER(C.c_int)]),
+    "dip_events_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "dip_events_destroy": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "dip_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "dip_nhwc_to_nchw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "dip_head_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -116,6 +127,9 @@ _SIGS = {
     "dip_conv_bnb_fusable": (C.c_int, [C.POINTER(DipConvDesc)]),
     "dip_conv_thin4_ntiles": (C.c_int, [C.c_int, C.c_int]),
     "dip_conv_splitk_finish": (C.c_int, [C.POINTER(DipConvDesc), C.c_void_p]),
+    "dip_conv_thin": (C.c_int, [C.POINTER(DipConvDesc), C.c_void_p]),
+    "dip_conv_thin_eligible": (C.c_int, [C.POINTER(DipConvDesc)]),
+    "dip_conv_thin_shape_ok": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dip_conv_small": (C.c_int, [C.POINTER(DipConvDesc), C.c_void_p]),
     "dip_conv_small_eligible": (C.c_int, [C.POINTER(DipConvDesc)]),
     "dip_conv_small_rows": (C.c_int, [C.POINTER(DipConvDesc)]),
@@ -279,3 +293,100 @@ def wgrad_plan2(Hout, Wout, Cin, Cout, ks, stride):
     n, g, cb = C.c_int(), C.c_int(), C.c_int()
     check(lib().dip_wgrad_plan2(Hout, Wout, Cin, Cout, ks, stride, C.byref(n), C.byref(g), C.byref(cb)), "wgrad_plan2")
     return n.value, g.value, cb.value
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Command lists (include/dip_hip.h "command lists", csrc/dip_list.hip): a static launch list compiled ONCE into an array of
+# DipCmd and issued by one dip_list_run call per direction and iteration.
+# ------------------------------------------------------------------------------------------------------------------
+CMD_LAUNCH, CMD_RECORD, CMD_WAIT = 0, 1, 2
+_INT_TYPES = (C.c_int, C.c_int32, C.c_int64, C.c_longlong, C.c_uint64, C.c_uint32, C.c_long, C.c_ulong)
+
+
+def _slot(argtype, v) -> int:
+    """One argument as the 64-bit pattern of its slot."""
+    import struct
+    if argtype in _INT_TYPES:
+        return int(v) & 0xFFFFFFFFFFFFFFFF
+    if argtype is C.c_float:
+        return int.from_bytes(struct.pack("<f", float(v)), "little")
+    if argtype is C.c_double:
+        return int.from_bytes(struct.pack("<d", float(v)), "little")
+    # pointers: None, an address, a ctypes.byref(struct) or a ctypes object
+    if v is None:
+        return 0
+    if isinstance(v, int):
+        return v & 0xFFFFFFFFFFFFFFFF
+    obj = getattr(v, "_obj", None)              # ctypes.byref(x)
+    if obj is not None:
+        return C.addressof(obj)
+    if isinstance(v, (C.c_void_p, C.c_char_p)):
+        return int(v.value or 0)
+    return C.addressof(v)
+
+
+class CmdList:
+    """A compiled launch list.  cmds: sequence of ("launch", fn, args, stream_index, name) | ("record", event_index,
+    stream_index) | ("wait", stream_index, event_index); fn = a function of lib(), args WITHOUT the trailing stream.
+    run(stream_ptrs) issues the whole list; one set of HIP events per key (eager / capture runs must not share events)."""
+
+    def __init__(self, cmds):
+        L = lib()
+        self.names = []
+        self._keep = []
+        n = len(cmds)
+        self.arr = (DipCmd * max(n, 1))()
+        self.nevents = 0
+        for i, c in enumerate(cmds):
+            if c[0] == "launch":
+                _, fn, args, st, name = c
+                fname = fn.__name__
+                fid = L.dip_list_fn_id(fname.encode())
+                if fid < 0:
+                    raise RuntimeError(f"dip-amd: {fname} is not a command-list entry point")
+                argtypes = _SIGS[fname][1]
+                if len(args) + 1 != len(argtypes) or L.dip_list_fn_nargs(fid) != len(argtypes):
+                    raise RuntimeError(f"dip-amd: {fname}: {len(args)} arguments for {len(argtypes) - 1} parameters")
+                slots = (C.c_uint64 * len(argtypes))()
+                for k, (t, v) in enumerate(zip(argtypes[:-1], args)):
+                    slots[k] = _slot(t, v)
+                self._keep.append((slots, args))          # the slots point INTO ctypes structs owned by `args`
+                self.arr[i] = DipCmd(CMD_LAUNCH, fid, st, -1, C.cast(slots, C.POINTER(C.c_uint64)), len(argtypes), 0)
+                self.names.append(name)
+            elif c[0] == "record":
+                self.arr[i] = DipCmd(CMD_RECORD, -1, c[2], c[1], None, 0, 0)
+                self.nevents = max(self.nevents, c[1] + 1)
+                self.names.append("record")
+            else:
+                self.arr[i] = DipCmd(CMD_WAIT, -1, c[1], c[2], None, 0, 0)
+                self.nevents = max(self.nevents, c[2] + 1)
+                self.names.append("wait")
+        self.n = n
+        self._events = {}
+        self._failed = C.c_int(-1)
+
+    def _event_set(self, key):
+        ev = self._events.get(key)
+        if ev is None:
+            ev = (C.c_void_p * max(self.nevents, 1))()
+            if self.nevents:
+                check(lib().dip_events_create(ev, self.nevents), "events_create")
+            self._events[key] = ev
+        return ev
+
+    def run(self, stream_ptrs, key="eager"):
+        ns = len(stream_ptrs)
+        st = (C.c_void_p * ns)(*stream_ptrs)
+        ev = self._event_set(key)
+        rc = lib().dip_list_run(self.arr, self.n, st, ns, ev, self.nevents, C.byref(self._failed))
+        if rc:
+            k = self._failed.value
+            check(rc, self.names[k] if 0 <= k < self.n else "list_run")
+
+    def __del__(self):
+        try:
+            for ev in self._events.values():
+                if self.nevents:
+                    lib().dip_events_destroy(ev, self.nevents)
+        except Exception:
+            pass

@@ -13,8 +13,9 @@
  *     (PyTorch caching allocator), every launch goes to the `stream` argument (a hipStream_t),
  *     so the launch sequence is hipGraph-capturable;
  *   - return value: 0 on success, otherwise a hipError_t (or -1 for an unsupported
- *     configuration); dip_last_error() returns a static description of the last failure.
- *   - one process per GPU, calls come from the thread that owns the stream.
+ *     configuration); dip_last_error() returns a description of the CALLING THREAD's last failure (thread-local).
+ *   - one process per GPU, calls come from the thread that owns the stream; the error slot, the open group
+ *     (dip_group_begin) and the native-family mask (dip_group_native) are per thread.
  */
 #ifndef DIP_HIP_H
 #define DIP_HIP_H
@@ -25,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DIP_ABI_VERSION 6
+#define DIP_ABI_VERSION 7
 
 #define DIP_PAD_ZERO 0
 #define DIP_PAD_REFLECT 1
@@ -50,6 +51,32 @@ const char* dip_last_error(void);
 int dip_device_pci_bus_id(int device, char* buf, int len);
 
 
+/* ---------------------------------------------------------------- command lists ------------- */
+/* The static launch list of one direction of the skip-net issued by ONE call (csrc/dip_list.hip) instead of one foreign
+ * call per launch -- the host half of "an iteration is a static launch list".  No reference counterpart: the reference's
+ * launches are issued op by op by PyTorch's dispatcher from nn.Module.forward / autograd (utils/common_utils.py:223-230).
+ * A command is LAUNCH (fn = dip_list_fn_id("dip_conv_igemm") ..., the call's arguments in `slots`: one 8-byte slot per
+ * parameter in declaration order -- ints sign-extended to 64 bits, floats in the low 4 bytes, pointers as addresses --
+ * INCLUDING a last slot for the trailing `stream` parameter, which dip_list_run fills with streams[stream]), RECORD
+ * (hipEventRecord(events[event], streams[stream])) or WAIT (hipStreamWaitEvent(streams[stream], events[event])).
+ * The caller owns slots, streams and events; dip_list_run allocates nothing and never synchronises (hipGraph-capturable).
+ * Returns 0, or the rc of the first failing command with its index in *failed_at (dip_last_error() describes it). */
+#define DIP_CMD_LAUNCH 0
+#define DIP_CMD_RECORD 1
+#define DIP_CMD_WAIT 2
+typedef struct DipCmd {
+    int32_t kind, fn, stream, event;
+    uint64_t* slots;
+    int32_t nslots, reserved;
+} DipCmd;
+int dip_list_fn_id(const char* name);          /* -1: not a stream-launching entry point */
+int dip_list_fn_nargs(int fn);                 /* parameters of that entry point, the trailing stream included */
+int dip_list_run(const DipCmd* cmds, int n, void* const* streams, int nstreams, void* const* events, int nevents,
+                 int* failed_at);
+/* n HIP events without timing (hipEventDisableTiming) for RECORD / WAIT commands */
+int dip_events_create(void** events, int n);
+int dip_events_destroy(void** events, int n);
+
 /* ---------------------------------------------------------------- grouped execution --------- */
 /* B independent fits in ONE launch list: B copies of the skip-net of models/skip.py:45-100 --
  * own weights, own BatchNorm statistics, own Adam state, own input and target -- with identical architecture and sizes.
@@ -60,7 +87,8 @@ int dip_device_pci_bus_id(int device, char* buf, int len);
  * advanced by b * stride_bytes (base / row_bytes = slab of instance 0: a pointer outside it fails the call, rc -1).  Plans,
  * tile walks and summation orders are those of a solo launch, so each instance's results are bit-identical to the same fit
  * run on its own.  Kernels with a grouped form run B instances in one dispatch (gridDim.z x B); the others are dispatched B
- * times by the library (csrc/dip_group.h).  Host-side state: one launching thread; hipGraph-capturable like a solo list.
+ * times by the library (csrc/dip_group.h).  Host-side state, thread-local: a group replicates the launches of the thread
+ * that opened it only; hipGraph-capturable like a solo list.
  * dip_group_native: bit mask of the kernel families whose one-dispatch form is in use (default all; DIP_GROUP_NATIVE);
  * mask < 0 only queries.  Returns the previous mask.  dip_group_size: instances of the open group (1: none). */
 int dip_group_begin(int ninst, long long stride_bytes, const void* base, long long row_bytes);
@@ -221,7 +249,9 @@ int dip_conv_plan_dil2(int Hout, int Wout, int Cin, int Cout, int ks, int* kspli
  * + conv_igemm_dma_kernel (the other 128 columns): 3x3 data gradients towards a 132-channel tensor,
  * 4 = conv_igemm_dma_kernel in phase mode (dil == 2: data gradient of a stride-2 3x3 convolution),
  * 5 = conv_igemm_dma_kernel in strided-forward mode (3x3, stride 2: the input split by pixel parity),
- * 6 = conv1x1_res_kernel (1x1, 128 -> 97..128 channels, >= 256x256 pixels: persistent workgroups, weights in registers) */
+ * 6 = conv1x1_res_kernel (1x1, 128 -> 97..128 channels, >= 256x256 pixels: persistent workgroups, weights in registers),
+ * 7 = conv_bf3_kernel (3x3 stride 1 on the bf16 matrix pipe), 8 = conv_thin_kernel (<= 64 channels in and out, 3x3 / 5x5,
+ * 16x16x4 MFMA tiles, all taps' weights LDS-resident: the high-resolution layers of the narrow nets) */
 int dip_conv_variant(const DipConvDesc* d);
 /* The two launches behind variant 3, exported so that a caller can put them on DIFFERENT streams (they
  * write disjoint columns of the same output): columns [0, ncols) (ncols = Cout - 128 <= 4) of a 3x3
@@ -229,6 +259,14 @@ int dip_conv_variant(const DipConvDesc* d);
  * n_base on the LDS-DMA kernel.  Same descriptor as dip_conv_igemm. */
 int dip_conv_thin4(const DipConvDesc* d, int ncols, void* stream);
 int dip_conv_igemm_dma_cols(const DipConvDesc* d, int n_base, void* stream);
+/* Thin layers (round 6, csrc/conv_thin.hip): 3x3 / 5x5, stride 1 / 2 (forward) or the stride-1 data gradient, <= 64 input
+ * and output channels, more than DIP_THIN_MIN_PIXELS (4625) output pixels -- the 16 / 32 / 64-channel layers of the
+ * 'library' inpainting net (inpainting.ipynb:222-232) and the snail net (denoising.ipynb:143-150) at their high
+ * resolutions; same contract as dip_conv_igemm (which dispatches to it: dip_conv_variant == 8), one pass, stats rows =
+ * dip_conv_ntiles.  dip_conv_thin_shape_ok: the shape part of the eligibility (what dip_conv_plan knows). */
+int dip_conv_thin(const DipConvDesc* d, void* stream);
+int dip_conv_thin_eligible(const DipConvDesc* d);
+int dip_conv_thin_shape_ok(int Hout, int Wout, int Cin, int Cout, int ks, int stride);
 /* Low-resolution layers (models/skip.py:57-91 at depth >= 2: <= 64x64 outputs in the notebooks' nets): ONE launch per
  * convolution instead of conv + split-K finish.  A workgroup computes one 32-pixel x 32-channel tile; its 4 / 8 / 16 waves
  * split K, each with its whole slice of operand loads in flight at once, straight from L2 into the MFMA registers (no LDS

@@ -23,7 +23,7 @@ def test_cabi_exports_every_declared_symbol(built):
     L = ctypes.CDLL(dip_native.LIB_PATH)
     for name in declared:
         assert hasattr(L, name), name
-    assert built.dip_abi_version() == dip_native.ABI_VERSION == 6
+    assert built.dip_abi_version() == dip_native.ABI_VERSION == 7
     # struct layouts agree with the header's field order (sizes on LP64)
     assert ctypes.sizeof(dip_native.DipTransform) == 24
     assert ctypes.sizeof(dip_native.DipGradSrc) == 40     # + the crop window of round 3
@@ -389,8 +389,55 @@ assert g._nbt_all.unique().tolist() == [2]
 print("WALK_OK", len(failed))
 """ % os.path.join(ROOT, "deep-image-prior_amd")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
-                       env=dict(os.environ, DIP_TWO_STREAMS="0"))
+                       env=dict(os.environ, DIP_TWO_STREAMS="0", DIP_NO_CLIST="1"))      # (launch by launch: a command list stops at its first failure)
     assert "WALK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_command_list_thunks_agree_with_the_binding(built):
+    """csrc/dip_list.hip registers every stream-launching entry point with a thunk that unpacks one 8-byte slot per parameter;
+    dip_native.CmdList packs the slots from the ctypes signatures.  The two must agree on the parameter count of every entry
+    point -- and every entry point of the binding that takes a trailing stream must be registered."""
+    import dip_native as N
+    L = built
+    streamy = [n for n, (res, args) in N._SIGS.items() if args and args[-1] is ctypes.c_void_p and res is ctypes.c_int
+               and n not in ("dip_list_run",) and not n.endswith(("_ok", "_eligible"))]
+    host_only = {"dip_events_create", "dip_events_destroy"}
+    missing = [n for n in streamy if L.dip_list_fn_id(n.encode()) < 0 and n not in host_only]
+    # (entry points whose last parameter is a pointer but not a stream)
+    assert set(missing) <= {"dip_conv_plan", "dip_conv_plan_dil2", "dip_wgrad_plan", "dip_wgrad_plan2", "dip_group_begin",
+                            "dip_device_pci_bus_id"}, missing
+    for n in streamy:
+        fid = L.dip_list_fn_id(n.encode())
+        if fid >= 0:
+            assert L.dip_list_fn_nargs(fid) == len(N._SIGS[n][1]), n
+    assert L.dip_list_fn_id(b"dip_conv_plan") == -1 and L.dip_list_fn_id(b"nope") == -1
+    # slot packing: ints sign-extended, floats in the low 4 bytes, byref -> the struct's address
+    d = N.DipGradSrc(0x1234, 1, 1, 4, 0)
+    assert N._slot(ctypes.POINTER(N.DipGradSrc), ctypes.byref(d)) == ctypes.addressof(d)
+    assert N._slot(ctypes.c_int, -1) == 0xFFFFFFFFFFFFFFFF and N._slot(ctypes.c_void_p, None) == 0
+    import struct
+    assert N._slot(ctypes.c_float, 0.2) == struct.unpack("<I", struct.pack("<f", 0.2))[0]
+    assert N._slot(ctypes.c_double, 0.1) == struct.unpack("<Q", struct.pack("<d", 0.1))[0]
+
+
+def test_command_list_reports_the_failing_launch(built):
+    """Without a GPU the first LAUNCH of a list fails inside the library (hipErrorNoDevice, rc 100): dip_list_run stops there
+    and CmdList.run raises with that op's name; RECORD / WAIT indices out of range are refused (rc -1)."""
+    import dip_native as N
+    L = built
+    src = N.DipGradSrc(None, 0, 0, 4, 0)
+    args = (ctypes.byref(src), None, 4, 4, 4, 4, None, 4, 0.2, None, 4, None, 1)
+    cl = N.CmdList([("launch", L.dip_bn_bwd_stats, args, 0, "bnb_stats:probe"), ("launch", L.dip_bn_bwd_stats, args, 0, "second")])
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    with pytest.raises(RuntimeError, match="bnb_stats:probe"):
+        cl.run([None])
+    assert cl._failed.value == 0
+    bad = (N.DipCmd * 1)(N.DipCmd(N.CMD_RECORD, -1, 0, 3, None, 0, 0))
+    st, ev, failed = (ctypes.c_void_p * 1)(), (ctypes.c_void_p * 1)(), ctypes.c_int(-1)
+    assert L.dip_list_run(bad, 1, st, 1, ev, 1, ctypes.byref(failed)) == -1 and failed.value == 0
+    with pytest.raises(RuntimeError, match="arguments"):
+        N.CmdList([("launch", L.dip_bn_bwd_stats, args[:-1], 0, "short")])
 
 
 def test_group_pointer_lists_cover_every_descriptor_pointer():

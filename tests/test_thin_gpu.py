@@ -1,0 +1,83 @@
+"""Parity of conv_thin_kernel (csrc/conv_thin.hip: the <= 64-channel 3x3 / 5x5 layers of the narrow nets at their high
+resolutions, dispatched by dip_conv_igemm) on a real MI355X: forward with the producer's BatchNorm + LeakyReLU in the loader
+and the consumer BatchNorm's partial statistics, and the stride-1 data gradient, against torch-CPU fp64 evaluations of the
+reference ops (nn.ReflectionPad2d + nn.Conv2d, models/common.py:114-124 of the reference; autograd's ConvolutionBackward)
+with the per-op criterion of test_kernels_gpu.py.  The shapes are those of the 'library' inpainting net
+(inpainting.ipynb:222-232) and the snail net (denoising.ipynb:143-150), the first three at the library net's REAL sizes."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import dip_native as N  # noqa: E402
+from dip_native import round_up  # noqa: E402
+import test_kernels_gpu as TK  # noqa: E402
+from test_kernels_gpu import REFLECT, ZERO  # noqa: E402
+
+THIN_CASES = [
+    # Cin, Cout, ks, stride, pad, H, W, transform
+    (16, 16, 5, 1, REFLECT, 224, 352, True),     # library s0.down_b at its real size: one 16-column block, one chunk
+    (16, 32, 5, 2, REFLECT, 224, 352, True),     # library s1.down_a (stride 2) at its real size
+    (32, 64, 5, 2, REFLECT, 112, 176, True),     # library s2.down_a at its real size: 2 chunks of 16 channels, 4 column blocks
+    (32, 32, 5, 1, REFLECT, 72, 88, True),       # library s1.down_b (reduced size): 2 chunks
+    (64, 32, 3, 1, REFLECT, 70, 90, True),       # library s1.up: 64 input channels
+    (32, 16, 3, 1, REFLECT, 80, 96, True),       # library s0.up
+    (12, 16, 5, 2, REFLECT, 160, 144, False),    # 12 input channels: a 16-channel K step with 4 idle lanes
+    (8, 8, 3, 1, ZERO, 75, 70, True),            # snail s0.down_b: zero padding, ragged tiles, half-empty column block
+    (36, 20, 3, 1, REFLECT, 72, 72, False),      # odd channel counts: 3 chunks of 16 (the last one 4 channels), 2 column blocks
+    (64, 64, 5, 1, REFLECT, 70, 70, True),       # 4 chunks x 4 column blocks
+    (16, 48, 3, 2, ZERO, 140, 150, True),        # stride 2, zero padding, 3 column blocks
+]
+
+
+@pytest.fixture(autouse=True)
+def _every_shape(monkeypatch):
+    """The planner's bounds (dip_conv_thin_shape_ok: <= 12800 weights, >= 8 input channels) leave some of the cases above to the
+    older kernels by default; the KERNEL is tested on all of them (DIP_THIN_ALL is read at every call)."""
+    monkeypatch.setenv("DIP_THIN_ALL", "1")
+
+
+def _dims(case):
+    Cin, Cout, ks, stride, pad, Hh, Ww, _ = case
+    P = (ks - 1) // 2
+    return (Hh + 2 * P - ks) // stride + 1, (Ww + 2 * P - ks) // stride + 1
+
+
+@pytest.mark.parametrize("case", THIN_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_thin_forward_and_stats(dev, case):
+    Cin, Cout, ks, stride, pad, Hh, Ww, _ = case
+    Ho, Wo = _dims(case)
+    assert N.lib().dip_conv_thin_shape_ok(Ho, Wo, round_up(Cin, 4), Cout, ks, stride) == 1
+    assert N.conv_plan(Ho, Wo, round_up(Cin, 4), Cout, ks, stride) == (1, N.lib().dip_conv_ntiles(Ho, Wo), 0)
+    TK.test_conv_forward_and_stats(dev, case, True)          # (the planned launch: one pass, rows = 8x16 tiles)
+
+
+@pytest.mark.parametrize("case", [c for c in THIN_CASES if c[3] == 1], ids=lambda c: "x".join(map(str, c)))
+def test_conv_thin_dgrad(dev, case):
+    """Stride-1 data gradient: the same kernel with the flipped, transposed weight pack on the padded domain."""
+    Cin, Cout, ks, stride, pad, Hh, Ww, _ = case
+    assert N.lib().dip_conv_thin_shape_ok(Hh + ks - 1, Ww + ks - 1, round_up(Cout, 4), Cin, ks, 1) == 1 or pad == ZERO
+    TK.test_conv_dgrad(dev, case, True)
+
+
+def test_conv_thin_is_what_runs(dev):
+    """dip_conv_variant reports the thin kernel for these descriptors, the register-staged kernel under DIP_CONV_NO_THIN
+    (read once per process: checked through the shape predicate here) and never for accumulate / row-pitch / dilated launches."""
+    import ctypes as C
+    lib = N.lib()
+    d = N.DipConvDesc(1 << 20, 224, 352, 16, 16, N.DipTransform(None, None, 1.0), 1 << 20, None, 1 << 20, 224, 352, 16, 16, 0,
+                      5, 1, N.PAD_REFLECT, 2, 1, 0, None, 1, None)
+    assert lib.dip_conv_thin_eligible(C.byref(d)) == 1 and lib.dip_conv_variant(C.byref(d)) == 8
+    for field, val in (("accumulate", 1), ("y_pitch", 360), ("dil", 2), ("ksplit", 2)):
+        d2 = N.DipConvDesc.from_buffer_copy(d)
+        setattr(d2, field, val)
+        assert lib.dip_conv_thin_eligible(C.byref(d2)) == 0, field
+    d3 = N.DipConvDesc.from_buffer_copy(d)
+    d3.Hout, d3.Wout = 56, 80                    # 4480 pixels: conv_small's range
+    assert lib.dip_conv_thin_eligible(C.byref(d3)) == 0
+    # the default bounds: one chunk must hold all channels and all taps' weights, >= 8 input channels
+    import os
+    os.environ.pop("DIP_THIN_ALL")
+    ok = lib.dip_conv_thin_shape_ok
+    assert ok(224, 352, 16, 16, 5, 1) == 1 and ok(112, 176, 16, 32, 5, 2) == 1 and ok(448, 704, 32, 16, 3, 1) == 1
+    assert ok(112, 176, 32, 32, 5, 1) == 0 and ok(224, 352, 64, 32, 3, 1) == 0 and ok(224, 352, 4, 16, 5, 2) == 0
