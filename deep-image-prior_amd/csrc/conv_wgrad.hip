@@ -770,8 +770,17 @@ extern "C" int dip_conv_wgrad_ntiles(int Hout, int Wout) { return dip_cdiv(Wout,
 // Number of partial slabs (= nsplit of DipWgradDesc) the weight-gradient kernels should be run
 // with: ~512 workgroups in flight for the MFMA kernels, one slab per block for the thin kernel,
 // and never more than 256 MB of slabs.
+extern "C" int dip_wgrad_thin_shape_ok(int Hout, int Wout, int Cin, int Cout, int ks, int stride);      // wgrad_thin.hip
+extern "C" int dip_wgrad_thin_nsplit(int Hout, int Wout, int Cin, int Cout, int ks, int stride);
+extern "C" int dip_wgrad_thin_eligible(const DipWgradDesc* dp);
+extern "C" int dip_wgrad_thin(const DipWgradDesc* dp, void* stream);
+
 extern "C" int dip_wgrad_plan(int Hout, int Wout, int Cin, int Cout, int ks, int stride, int* nsplit) {
-    (void)stride;
+    // thin layers (8..64 input channels, <= 64 output channels, 3x3 / 5x5): wgrad_thin_kernel, one slab per pixel-tile walker
+    if (dip_wgrad_thin_shape_ok(Hout, Wout, Cin, Cout, ks, stride)) {
+        *nsplit = dip_wgrad_thin_nsplit(Hout, Wout, Cin, Cout, ks, stride);
+        return 0;
+    }
     if (is_thin(ks, Cin, Cout)) {
         int nblk;
         thin_ppb(Hout * Wout, Cin, &nblk);
@@ -823,7 +832,7 @@ extern "C" int dip_wgrad_plan2(int Hout, int Wout, int Cin, int Cout, int ks, in
     *chan_block = (ks == 1) ? 4 : 1;
     int rc = dip_wgrad_plan(Hout, Wout, Cin, Cout, ks, stride, nsplit);
     if (rc) return rc;
-    if (is_thin(ks, Cin, Cout) || is_thin_cin(ks, Cin, Cout)) return 0;
+    if (is_thin(ks, Cin, Cout) || is_thin_cin(ks, Cin, Cout) || dip_wgrad_thin_shape_ok(Hout, Wout, Cin, Cout, ks, stride)) return 0;
     const int nt = dip_conv_wgrad_ntiles(Hout, Wout);
     static const bool off = getenv("DIP_WGRAD_NO_SMALL_PLAN") != nullptr;
     if (ks == 5 && !off) {
@@ -889,6 +898,7 @@ extern "C" int dip_conv_wgrad(const DipWgradDesc* dp, void* stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if ((d.Cx & 3) || (d.Cdy & 3)) DIP_FAIL("conv_wgrad: channel strides must be multiples of 4");
     if (dip_wgrad_bf3_eligible(dp)) return dip_wgrad_bf3(dp, stream);        // big 3x3 stride-1 layers: bf16 matrix pipe
+    if (dip_wgrad_thin_eligible(dp)) return dip_wgrad_thin(dp, stream);      // thin layers: 16x16x4 MFMA tiles (wgrad_thin.hip)
     if (is_thin(d.ks, d.Cin, d.Cout)) {
         int nblk;
         const int ppb = thin_ppb(d.Hout * d.Wout, d.Cin, &nblk);

@@ -146,6 +146,10 @@ _SIGS = {
     "dip_wgrad_bf3": (C.c_int, [C.POINTER(DipWgradDesc), C.c_void_p]),
     "dip_conv_wgrad_tail": (C.c_int, [C.POINTER(DipWgradDesc), C.c_void_p]),
     "dip_conv_wgrad_ntiles": (C.c_int, [C.c_int, C.c_int]),
+    "dip_wgrad_thin": (C.c_int, [C.POINTER(DipWgradDesc), C.c_void_p]),
+    "dip_wgrad_thin_eligible": (C.c_int, [C.POINTER(DipWgradDesc)]),
+    "dip_wgrad_thin_shape_ok": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "dip_wgrad_thin_nsplit": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dip_wgrad_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "dip_wgrad_plan2": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
                                   C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -329,6 +329,15 @@ int dip_conv_wgrad(const DipWgradDesc* d, void* stream);
 int dip_wgrad_bf3_eligible(const DipWgradDesc* d);
 int dip_wgrad_bf3(const DipWgradDesc* d, void* stream);
 int dip_conv_wgrad_tail(const DipWgradDesc* d, void* stream);
+/* Thin layers (round 6, csrc/wgrad_thin.hip): 3x3 / 5x5, stride 1 / 2, 8..64 input channels, <= 64 output channels, >= 4096
+ * output pixels -- the 16 / 32 / 64-channel convs of the 'library' and snail nets (inpainting.ipynb:222-232,
+ * denoising.ipynb:143-150): 16-channel x 16-column x 4-pixel MFMA tiles, the taps spread over the workgroup's waves; same
+ * slabs, same dip_wgrad_reduce.  dip_conv_wgrad dispatches to it; nsplit from dip_wgrad_plan / dip_wgrad_plan2
+ * (= dip_wgrad_thin_nsplit for these shapes). */
+int dip_wgrad_thin(const DipWgradDesc* d, void* stream);
+int dip_wgrad_thin_eligible(const DipWgradDesc* d);
+int dip_wgrad_thin_shape_ok(int Hout, int Wout, int Cin, int Cout, int ks, int stride);
+int dip_wgrad_thin_nsplit(int Hout, int Wout, int Cin, int Cout, int ks, int stride);
 /* number of 4x16 output tiles walked by the wgrad workgroups (upper bound for nsplit) */
 int dip_conv_wgrad_ntiles(int Hout, int Wout);
 /* nsplit (number of partial slabs) to run dip_conv_wgrad with; mandatory for 1x1 convs with

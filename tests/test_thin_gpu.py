@@ -81,3 +81,30 @@ def test_conv_thin_is_what_runs(dev):
     ok = lib.dip_conv_thin_shape_ok
     assert ok(224, 352, 16, 16, 5, 1) == 1 and ok(112, 176, 16, 32, 5, 2) == 1 and ok(448, 704, 32, 16, 3, 1) == 1
     assert ok(112, 176, 32, 32, 5, 1) == 0 and ok(224, 352, 64, 32, 3, 1) == 0 and ok(224, 352, 4, 16, 5, 2) == 0
+
+
+WGRAD_CASES = [
+    (16, 16, 5, 1, REFLECT, 224, 352, True),     # library s0.down_b at its real size: CI = CO = 1, 7 / 6 / 6 / 6 taps per wave
+    (16, 32, 5, 2, REFLECT, 224, 352, True),     # library s1.down_a (stride 2) at its real size: 11 x 35-pixel halo, CO = 2
+    (32, 64, 5, 2, REFLECT, 112, 176, True),     # library s2.down_a at its real size: 2 input x 2 output channel blocks
+    (32, 32, 5, 1, REFLECT, 72, 88, True),       # CI = CO = 2: 112 accumulator registers
+    (64, 32, 3, 1, REFLECT, 70, 90, True),       # library s1.up: two 32-channel input blocks
+    (32, 16, 3, 1, REFLECT, 80, 96, False),      # library s0.up, no transform
+    (8, 8, 3, 1, ZERO, 75, 70, True),            # snail: half-empty blocks, zero padding, ragged tiles
+    (36, 20, 3, 1, REFLECT, 72, 72, True),       # odd channel counts: a 4-channel input block, a 4-column output block
+    (64, 64, 5, 1, REFLECT, 66, 70, True),       # 2 x 2 channel blocks
+    (16, 48, 3, 2, ZERO, 140, 150, True),        # stride 2, zero padding, 2 output blocks (the second half empty)
+]
+
+
+@pytest.mark.parametrize("nsplit", [None, "plan"], ids=["nsplit7", "planned"])
+@pytest.mark.parametrize("case", WGRAD_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_wgrad_thin(dev, case, nsplit):
+    """dW, db of the thin layers through dip_conv_wgrad (which dispatches to wgrad_thin_kernel) + dip_wgrad_reduce against
+    fp64 autograd; 7 slabs and the planned number."""
+    Cin, Cout, ks, stride, pad, Hh, Ww, _ = case
+    Ho, Wo = _dims(case)
+    assert N.lib().dip_wgrad_thin_shape_ok(Ho, Wo, Cin, Cout, ks, stride) == 1
+    n, g, cb = N.wgrad_plan2(Ho, Wo, Cin, Cout, ks, stride)
+    assert n == N.lib().dip_wgrad_thin_nsplit(Ho, Wo, Cin, Cout, ks, stride) == N.wgrad_plan(Ho, Wo, Cin, Cout, ks, stride) and g == 1
+    TK.test_conv_wgrad(dev, case, nsplit)

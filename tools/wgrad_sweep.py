@@ -64,7 +64,14 @@ K5 = ((16, 16, 5, 1, 224, 352), (16, 32, 5, 2, 224, 352), (32, 32, 5, 1, 112, 17
       (64, 128, 5, 2, 56, 88), (128, 128, 5, 1, 28, 44), (128, 128, 5, 2, 28, 44), (128, 128, 5, 1, 14, 22), (128, 128, 5, 2, 14, 22),
       (128, 128, 5, 1, 7, 11))       # the 'library' inpainting net at 448 x 704 (inpainting.ipynb:222-232): Cin, Cout, ks, stride, Hin, Win
 
+LIB3 = ((128, 64, 3, 1, 112, 176), (64, 32, 3, 1, 224, 352), (32, 16, 3, 1, 448, 704))      # the library net's 3x3 decoder convs
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "lib":       # planned launch of every library-net layer (A/B: DIP_WGRAD_NO_THIN=1)
+        for (Cin, Cout, ks, s, Hh, Ww) in K5 + LIB3:
+            plan, us, rus, tf = bench(Cin, Cout, ks, s, Hh, Ww, reps=10)
+            print(f"{Cin}>{Cout} k{ks}s{s} {Hh}x{Ww}: {us:7.1f}us +reduce {rus:5.1f}us {tf:5.1f}TF plan={plan}", flush=True)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "k5":       # (tap_groups, nsplit) sweep of the 5x5 layers (dip_wgrad_plan2's 5x5 table)
         for (Cin, Cout, ks, s, Hh, Ww) in K5:
             Ho, Wo = Hh // s, Ww // s
