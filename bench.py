@@ -532,7 +532,7 @@ def roofline_hbm(eng, per_op_ms):
     untimed = sum(b for k, b in B.items() if k not in timed and ":" not in k)
     pmc = None
     try:
-        pth = [q for q in (os.path.join(ROOT, "profiles", f"{r}_pmc_traffic.json") for r in ("r05", "r04", "r03")) if os.path.exists(q)][0]
+        pth = [q for q in (os.path.join(ROOT, "profiles", f"{r}_pmc_traffic.json") for r in ("r06", "r05", "r04", "r03")) if os.path.exists(q)][0]
         with open(pth) as f:
             pmc = json.load(f).get("memory_bound_group")
     except (OSError, ValueError):
@@ -684,7 +684,7 @@ def pmc_traffic():
     (profiles/r0N_pmc_traffic.json, produced by tools/pmc_traffic.py); None when absent."""
     import dip_native as N
     want = "conv_bf3_kernel<*>" if N.lib().dip_conv_bf3_terms() else DOMINANT
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
         try:
             with open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")) as f:
                 t = json.load(f)
@@ -693,6 +693,23 @@ def pmc_traffic():
                 return t
         except (OSError, ValueError):
             pass
+    return None
+
+
+def ubench_ceiling(terms):
+    """What the bare MFMA loops of tools/ubench reach on this part (mfma_peak.hip: v_mfma_f32_32x32x2_f32; bf16x9.hip: the
+    9-product bf16 inner loop, fp32-equivalent TFLOP/s), read from the committed output of the round's evidence call
+    (profiles/r0N_ubench_ceilings.json) -- not a constant in this file (VERDICT r05 next #8)."""
+    for rnd in ("r06", "r05"):
+        pth = os.path.join(ROOT, "profiles", f"{rnd}_ubench_ceilings.json")
+        try:
+            with open(pth) as f:
+                u = json.load(f)
+            v = u["mfma_f32_tflops"] if not terms else u["bf16x9_fp32_equivalent_tflops"] * 9.0 / terms
+            return {"tflops": round(v, 1), "source": os.path.relpath(pth, ROOT),
+                    "stale": os.environ.get("DIP_BENCH_PMC_SAME_CALL") != "1"}
+        except (OSError, ValueError, KeyError):
+            continue
     return None
 
 
@@ -726,17 +743,21 @@ def roofline(eng, per_op_ms, with_pmc=True):
           "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
           "frac": round(ach / peak, 4),
           "traffic": pmc["traffic_bytes_per_launch"] if pmc else None,
+          # DIP_BENCH_PMC_SAME_CALL=1 is set by the round's evidence script (tools/gpu_round6_final.sh), which takes the counter
+          # passes and this line in ONE gpurun call on ONE box; any other run reads what is committed: stale
+          "traffic_stale": (os.environ.get("DIP_BENCH_PMC_SAME_CALL") != "1") if pmc else None,
           "traffic_source": (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes committed under profiles/ ({pmc.get('round', 'r02')}): "
-                             "another box, another run than this line") if pmc else None,
+                             + ("the same gpurun call and box as this line" if os.environ.get("DIP_BENCH_PMC_SAME_CALL") == "1"
+                                else "STALE: another box, another run than this line")) if pmc else None,
           "launches_per_step": n, "avg_launch_us": round(1e3 * tot_ms / max(n, 1), 1),
           "algorithmic_gflop_per_launch": round(tot_f / 1e9 / max(n, 1), 2),
           "algorithmic_bytes_per_launch": round(alg_bytes / max(n, 1)),
           "splitk_finish_ms_per_step_not_included": round(fin_ms, 3),
-          "measured_mfma_ceiling_tflops": 151.9 if not terms else round(238.0 * 9 / terms, 1),   # tools/ubench/mfma_peak.hip / bf16x9.hip (2 WG/CU)
+          "measured_mfma_ceiling_tflops": ubench_ceiling(terms),
           "all_conv_launches": {"gflop_per_step": round(all_f / 1e9, 1), "ms_per_step_serial": round(all_ms, 3),
                                 "tflops": round(all_f / (all_ms * 1e-3) / 1e12, 2) if all_ms > 0 else None}}
     try:        # matrix-pipe utilisation from the committed counter pass (tools/pmc_mfma.py; another run than this line)
-        pmf = [q for q in (os.path.join(ROOT, "profiles", f"{r}_pmc_mfma.json") for r in ("r05", "r04")) if os.path.exists(q)][0]
+        pmf = [q for q in (os.path.join(ROOT, "profiles", f"{r}_pmc_mfma.json") for r in ("r06", "r05", "r04")) if os.path.exists(q)][0]
         with open(pmf) as f:
             pm = json.load(f)
         key = "conv_bf3_kernel" if terms else "conv_igemm_dma_kernel<3, 128"
@@ -746,6 +767,7 @@ def roofline(eng, per_op_ms, with_pmc=True):
             nl = sum(n for n, _, _ in us)
             util, ghz = sum(n * u for n, u, _ in us) / nl, sum(n * g for n, _, g in us) / nl
             rl["mfma_util_pmc"] = round(util, 4)
+            rl["mfma_util_pmc_stale"] = os.environ.get("DIP_BENCH_PMC_SAME_CALL") != "1"
             rl["clock_ghz_pmc"] = round(ghz, 3)
             # frac prices the kernel against the peak at the nominal 2.4 GHz; the counters count CYCLES: the two meet at
             # utilisation x (clock the kernel ran at) / 2.4 (every executed MFMA of these launches is algorithmic work)
@@ -809,17 +831,17 @@ def host_cpu_model():
     return "unknown"
 
 
-def cpu_baseline(seed=0, timed=5):
-    """The CPU oracle on this box's host cores: same net, same 512x512 workload, same closure;
-    1 warm-up + `timed` timed Adam iterations, median."""
+def cpu_baseline(seed=0, timed=5, warm=2):
+    """The CPU oracle on this box's host cores: same net, same 512x512 workload, same closure; `warm` warm-up + `timed`
+    timed Adam iterations (2 + >= 5), median -- at the best thread count of a short sweep taken in
+    this call (one timed iteration each at 8 / 16 / 32 threads after one warm-up) and recorded in the line."""
     import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import dip_oracle as O
     # torch-CPU conv scaling collapses on many-core hosts: on the 256-thread MI355X host a sweep
     # (tools/cpu_sweep.py, 256x256) gave 3.47 / 2.38 / 1.25 / 0.59 / 0.011 it/s at 16 / 32 / 64 /
-    # 128 / 256 threads, so the baseline uses the best setting, 16 threads, not all of them.
-    cores = min(os.cpu_count() or 1, 16)
-    torch.set_num_threads(cores)
+    # 128 / 256 threads, so the baseline sweeps 8 / 16 / 32 threads and uses the best, not all of them.
+    ncpu = os.cpu_count() or 1
     torch.manual_seed(seed)
     net, _ = build_net("default")
     sd = {k: v.detach().clone() for k, v in net.state_dict().items() if k in O.param_shapes(O.default_spec())}
@@ -837,20 +859,31 @@ def cpu_baseline(seed=0, timed=5):
         return loss
 
     opt = torch.optim.Adam(onet.params, lr=0.01)
-    times = []
-    for it in range(1 + timed):
+
+    def one():
         t0 = time.time()
         opt.zero_grad()
         closure()
         opt.step()
-        times.append(time.time() - t0)
-    tt = times[1:]
+        return time.time() - t0
+
+    sweep = {}
+    for th in sorted({min(ncpu, t) for t in (8, 16, 32)}):
+        torch.set_num_threads(th)
+        one()                                   # (thread pool / oneDNN primitive warm-up at this setting)
+        sweep[th] = one()
+    cores = min(sweep, key=sweep.get)
+    torch.set_num_threads(cores)
+    for _ in range(warm):
+        one()
+    tt = [one() for _ in range(timed)]
     return {"value": round(1.0 / float(np.median(tt)), 4), "unit": "it/s", "cores": cores, "kind": "port",
             "note": "the unmodified reference (/root/reference) does not exist on the GPU box: this is oracle/dip_oracle.py, "
                     "its restatement on torch.nn.functional, verified bitwise against the real reference in the build container",
-            "host": f"{host_cpu_model()} ({os.cpu_count()} hardware threads)",
-            "sample": f"default skip-net 512x512, 1 warm-up + {len(tt)} timed Adam iterations of the CPU oracle "
-                      f"(torch {torch.__version__} CPU, {cores} threads), median; min/max "
+            "host": f"{host_cpu_model()} ({ncpu} hardware threads)",
+            "thread_sweep_it_s": {str(k): round(1.0 / v, 3) for k, v in sweep.items()},
+            "sample": f"default skip-net 512x512, {warm} warm-up + {len(tt)} timed Adam iterations of the CPU oracle "
+                      f"(torch {torch.__version__} CPU, {cores} threads = the best of the sweep), median; min/max "
                       f"{1.0 / max(tt):.3f}/{1.0 / min(tt):.3f} it/s"}
 
 
@@ -1097,6 +1130,18 @@ def main():
     # every rank's first fit: rank r's image index is r * instances, i.e. "rank r == the solo fit with that seed" can be
     # checked bitwise across runs
     per_rank_loss = gather_floats(final_loss)
+    # per-rank power / clock of the reported form's timed region and the host's issue time per iteration: what limits N
+    # ranks on one host (8 x ~1.1 kW, eight launching threads) shows up rank by rank
+    pw = best.get("power") or {}
+    per_rank_power = gather_floats(float(pw.get("power_w_mean") or float("nan")))
+    per_rank_sclk = gather_floats(float(pw.get("sclk_mhz_mean") or float("nan")))
+    rank_issue = None
+    if world > 1 and not best["graphed"] and not best["form"].startswith("grouped"):
+        try:
+            rank_issue = host_issue(fits).get("command_list_ms_per_iteration")
+        except Exception:
+            rank_issue = None
+    per_rank_issue = gather_floats(float(rank_issue) if rank_issue is not None else float("nan")) if world > 1 else None
 
     if rank == 0:
         eng = fits[0].engine
@@ -1204,6 +1249,9 @@ def main():
             "timed_region_power": best.get("power"),
             "roofline": rl, "roofline_wgrad": rw, "roofline_conv3x3_all": r3, "roofline_hbm": rh,
             "sustained": sustained, "host_issue": hissue, "build_id": _N.lib().dip_build_id().decode(),
+            "per_rank_power_w": [None if v != v else round(v, 1) for v in per_rank_power],
+            "per_rank_sclk_mhz": [None if v != v else round(v) for v in per_rank_sclk],
+            "per_rank_host_issue_ms": None if per_rank_issue is None else [None if v != v else round(v, 3) for v in per_rank_issue],
             "cpu_baseline": cb, "eager_notebook": eager, "fp32_mfma_only": fp32_only, "grouped_batch_of_4": batch4,
             "device": device_info(local),
             "host_affinity_rank0": affinity,

@@ -48,12 +48,14 @@ static inline int dip_cdiv(int a, int b) { return (a + b - 1) / b; }
 //   slope in (0, 1]          LeakyReLU(slope): max(t, slope*t); slope == 1 -> identity ('none')
 //   slope == DIP_ACT_SWISH   Swish: t * sigmoid(t)                       (models/common.py:62-73)
 //   slope == DIP_ACT_ELU     nn.ELU(alpha = 1): t > 0 ? t : expm1(t)
+//   slope == DIP_ACT_RELU    nn.ReLU: max(t, 0)        (act_fun given as a module class, models/common.py:90-91)
 // The branch is wave-uniform.  dip_act_leaky is the LeakyReLU-only form for the LDS-DMA conv kernel,
 // whose K loop is scheduled instruction by instruction (other activations take the register-staged kernel).
 __device__ __forceinline__ float dip_act_leaky(float t, float slope) { return fmaxf(t, slope * t); }
 __device__ __forceinline__ float dip_act(float t, float slope) {
     if (slope > 0.f) return fmaxf(t, slope * t);
     if (slope == DIP_ACT_SWISH) return t / (1.f + expf(-t));
+    if (slope == DIP_ACT_RELU) return fmaxf(t, 0.f);
     return t > 0.f ? t : expm1f(t);
 }
 // a * b rounded to fp32 and NOT contractable into a neighbouring add (hipcc fuses across __fmul_rn under its
@@ -70,6 +72,7 @@ __device__ __forceinline__ float dip_act_grad(float t, float slope) {
         const float sg = 1.f / (1.f + expf(-t));
         return sg * (1.f + t * (1.f - sg));
     }
+    if (slope == DIP_ACT_RELU) return t > 0.f ? 1.f : 0.f;
     return t > 0.f ? 1.f : expf(t);
 }
 

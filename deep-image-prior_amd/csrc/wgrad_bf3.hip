@@ -374,7 +374,7 @@ int w3_launch_v1(const DipWgradDesc& d, hipStream_t st) {
 //   * LDS: 2 x (3 x 64 x 208 + 3 x 128 x 80) B = 138 KB + tables.
 template <int NT, int TR>
 __global__ __launch_bounds__(512) void wgrad_bf3_kernel(const DipWgradDesc d, const int ntx, const int ntiles, const int CinP,
-                                                        const int CoutP) {
+                                                        const int CoutP, const int c_end) {
     using C = W3Cfg;
     constexpr int U_PLANE2 = 64 * C::U_CH;                       // 13312: 64 channels per workgroup
     constexpr int BUF = 3 * U_PLANE2 + 3 * C::D_PLANE;           // 70656
@@ -659,7 +659,11 @@ __global__ __launch_bounds__(512) void wgrad_bf3_kernel(const DipWgradDesc d, co
 #endif
 
     // ---- this group's rows c0 .. c0 + 31 of partial slab `walker` ----
-    if (wave_active) {
+    // c_end = channels of the full 32-channel chunks: with an odd number of them in front of a <= 4-channel tail (Cin = 100,
+    // 164) group 1 of the last workgroup has no chunk; it still stages and multiplies (the barriers are workgroup-wide) but
+    // must not write rows that belong to the tail launch (they were right only because dip_conv_wgrad_tail,
+    // issued later on the same stream, overwrote them)
+    if (wave_active && c0 < c_end) {
         const int o = o0 + wq * 32 + l31;
 #pragma unroll
         for (int t = 0; t < 9; ++t)
@@ -701,7 +705,9 @@ int w3_launch(const DipWgradDesc& d, hipStream_t st) {
     const int ntx = dip_cdiv(d.Wout, C::TW), nty = dip_cdiv(d.Hout, C::TH);
     const int CinP = dip_round_up(d.Cin, 32), CoutP = dip_round_up(d.Cout, 32);
     const int nfull = ((d.Cin & 31) >= 1 && (d.Cin & 31) <= 4 && d.Cin > 32) ? (d.Cin >> 5) : dip_cdiv(d.Cin, 32);
-    dip_launch(kern, dim3(d.nsplit, dip_cdiv(nfull, 2), dip_cdiv(CoutP, 128)), dim3(512), LDS2, st, d, ntx, ntx * nty, CinP, CoutP);
+    const bool has_tail = (d.Cin & 31) >= 1 && (d.Cin & 31) <= 4 && d.Cin > 32;
+    dip_launch(kern, dim3(d.nsplit, dip_cdiv(nfull, 2), dip_cdiv(CoutP, 128)), dim3(512), LDS2, st, d, ntx, ntx * nty, CinP, CoutP,
+               has_tail ? nfull * 32 : CinP);
     DIP_CHECK_LAUNCH();
     return 0;
 }

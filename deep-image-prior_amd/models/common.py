@@ -75,7 +75,8 @@ def act(act_fun='LeakyReLU'):
     """Activation factory: 'LeakyReLU' (slope 0.2, in place) | 'Swish' | 'ELU' | 'none', or a
     module class to instantiate (reference: models/common.py:76-92).  All four strings run on the
     gfx950 engine (DipTransform.slope encodes them, csrc/dip_common.h: dip_act / dip_act_grad);
-    a module CLASS builds, but HipSkipNet raises for it -- it has no kernel."""
+    a module CLASS is instantiated as in the reference and runs natively when it builds one of the stateless
+    activations the kernels know (models/skip.py: _act_code_of_module_class); others raise at the first forward."""
     if not isinstance(act_fun, str):
         return act_fun()
     table = {

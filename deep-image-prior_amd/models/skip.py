@@ -68,16 +68,39 @@ def _attach_engine(model, scale_paths, out_path, need_sigmoid, pad, act_fun):
     # DipTransform.slope code of the activation (include/dip_hip.h): LeakyReLU(0.2) | none | Swish | ELU
     act_codes = {'LeakyReLU': 0.2, 'none': 1.0, 'Swish': -1.0, 'ELU': -2.0}
     try:
-        if act_fun not in act_codes:
-            raise NotImplementedError(f"dip-amd: act_fun={act_fun!r} has no gfx950 kernel "
-                                      "(LeakyReLU, Swish, ELU and 'none' do; a module class does not)")
+        if isinstance(act_fun, str) and act_fun not in act_codes:
+            raise NotImplementedError(f"dip-amd: act_fun={act_fun!r} has no gfx950 kernel (the strings LeakyReLU, Swish, ELU and "
+                                      "'none' do, as in the reference's act(); module classes: _act_code_of_module_class)")
+        act_code = act_codes[act_fun] if isinstance(act_fun, str) else _act_code_of_module_class(act_fun)
         for sp in scale_paths:
             if sp['unsupported']:
                 raise NotImplementedError("dip-amd: " + sp['unsupported'])
         model.__dict__['_dip_engine'] = dip_engine.SkipEngine(model, scales, at(out_path), need_sigmoid, pad,
-                                                              act_slope=act_codes[act_fun])
+                                                              act_slope=act_code)
     except NotImplementedError as e:   # surfaces at the first forward(), construction stays cheap
         model.__dict__['_dip_engine'] = e
+
+
+def _act_code_of_module_class(act_fun):
+    """act_fun given as a module class / factory (models/common.py:90-91 of the reference: `return act_fun()`): the stateless
+    element-wise activations that the kernels' loaders know (DipTransform.slope codes, include/dip_hip.h) are recognised by
+    instantiating one -- nn.LeakyReLU (any negative_slope in [0, 1]), nn.ReLU, nn.ELU(alpha=1), nn.SiLU / Swish, nn.Identity /
+    an empty nn.Sequential; anything else has no gfx950 kernel."""
+    import torch.nn as nn
+    from .common import Swish
+    m = act_fun()
+    if isinstance(m, nn.LeakyReLU) and 0.0 < m.negative_slope <= 1.0:
+        return float(m.negative_slope)
+    if isinstance(m, nn.ReLU) or (isinstance(m, nn.LeakyReLU) and m.negative_slope == 0.0):
+        return -3.0                     # DIP_ACT_RELU
+    if isinstance(m, nn.ELU) and m.alpha == 1.0:
+        return -2.0
+    if isinstance(m, (nn.SiLU, Swish)):
+        return -1.0
+    if isinstance(m, nn.Identity) or (isinstance(m, nn.Sequential) and len(m) == 0):
+        return 1.0
+    raise NotImplementedError(f"dip-amd: act_fun={act_fun!r} builds a {type(m).__name__}: no gfx950 kernel (LeakyReLU, ReLU, "
+                              "ELU(alpha=1), SiLU / Swish and Identity have one)")
 
 
 def skip(
@@ -203,5 +226,5 @@ def skip(
             if sp.get(k) is not None:
                 sp[k] = conv_path(sp[k])
     _attach_engine(model, scale_paths, conv_path(out_path), need_sigmoid, pad,
-                   act_fun if isinstance(act_fun, str) else getattr(act_fun, '__name__', 'custom'))
+                   act_fun)
     return model

@@ -35,6 +35,7 @@ extern "C" {
 /* DipTransform.slope codes for activations other than LeakyReLU (act_fun='Swish' | 'ELU') */
 #define DIP_ACT_SWISH (-1.0f)
 #define DIP_ACT_ELU (-2.0f)
+#define DIP_ACT_RELU (-3.0f)  /* act_fun given as the module CLASS nn.ReLU (models/common.py:90-91: `return act_fun()`) */
 
 #define DIP_UP_NEAREST 0
 #define DIP_UP_BILINEAR 1
@@ -98,7 +99,7 @@ int dip_group_native(int mask);
 
 /* Per-channel input transform fused into a consumer's loader:
  *   u = act(t),  t = a[c]*x + b[c];  act = max(t, slope*t) for slope in (0, 1] (slope = 1 -> affine
- *   only), t*sigmoid(t) for slope == DIP_ACT_SWISH, ELU(alpha=1) for slope == DIP_ACT_ELU
+ *   only), t*sigmoid(t) for slope == DIP_ACT_SWISH, ELU(alpha=1) for slope == DIP_ACT_ELU, max(t, 0) for DIP_ACT_RELU
  * This is BatchNorm2d(train)-apply (models/common.py:95-96) + act() (models/common.py:76-92:
  * LeakyReLU(0.2), Swish, ELU, none) with a = gamma*rstd, b = beta - mean*a.  a == NULL -> identity. */
 typedef struct DipTransform {

@@ -64,7 +64,7 @@ class SkipSpec:
     upsample_mode: Sequence[str] | str = "nearest"
     need1x1_up: bool = True
     downsample_mode: Sequence[str] | str = "stride"      # 'stride' | 'avg' | 'max' | 'lanczos2' | 'lanczos3' (models/common.py:99-112)
-    act_fun: str = "LeakyReLU"                           # 'LeakyReLU' | 'Swish' | 'ELU' | 'none' (models/common.py:76-92)
+    act_fun: object = "LeakyReLU"                        # 'LeakyReLU' | 'Swish' | 'ELU' | 'none' | a module class (models/common.py:76-92)
 
     def __post_init__(self):
         n = len(self.num_channels_down)
@@ -219,6 +219,8 @@ def _bn_act(x, sd, key, act=True, eps=1e-5, masks=None, act_fun="LeakyReLU", zre
         zrec[key] = x.detach().float()       # (test-only) the pre-activation: tests/parity.mask_report
     if not act or act_fun == "none":
         return x
+    if not isinstance(act_fun, str):         # a module class / factory: models/common.py:90-91 `return act_fun()`
+        return act_fun()(x)
     if act_fun == "Swish":
         return x * torch.sigmoid(x)
     if act_fun == "ELU":

@@ -14,6 +14,7 @@ Outputs (all float32 unless noted, produced by /root/reference code on torch CPU
                                 RNG order + state_dict naming + forward/backward numerics
 """
 import copy
+import functools
 import json
 import os
 import sys
@@ -68,6 +69,15 @@ NETS = {
                      kw=dict(num_channels_down=[16, 16], num_channels_up=[16, 16], num_channels_skip=[4, 4],
                              upsample_mode="nearest", act_fun="ELU",
                              need_sigmoid=True, need_bias=True, pad="zero")),
+    # act_fun as a module CLASS / factory (models/common.py:90-91: `return act_fun()`; round 6)
+    "tiny_relu": dict(args=(8, 3), hw=(32, 48), seed=21,
+                      kw=dict(num_channels_down=[16, 32], num_channels_up=[16, 32], num_channels_skip=[4, 4],
+                              upsample_mode="bilinear", act_fun=torch.nn.ReLU,
+                              need_sigmoid=True, need_bias=True, pad="reflection")),
+    "tiny_leaky01": dict(args=(8, 3), hw=(32, 32), seed=22,
+                         kw=dict(num_channels_down=[16, 16], num_channels_up=[16, 16], num_channels_skip=[4, 4],
+                                 upsample_mode="nearest", act_fun=functools.partial(torch.nn.LeakyReLU, 0.1),
+                                 need_sigmoid=True, need_bias=True, pad="zero")),
     # filter_skip_size = 3 (models/skip.py:58; every notebook keeps 1)
     "tiny_skip3": dict(args=(8, 3), hw=(32, 48), seed=11,
                        kw=dict(num_channels_down=[16, 32], num_channels_up=[16, 32], num_channels_skip=[4, 4],

@@ -147,6 +147,7 @@ WGRAD_BF3_CASES = [
     (128, 128, REFLECT, 256, 256, True),
     (132, 128, REFLECT, 256, 256, True),      # four full chunks on the bf16 pipe + the 4-channel tail (dip_conv_wgrad_tail)
     (48, 160, ZERO, 250, 280, False),         # a 16-channel partial chunk, two 128-column blocks, ragged tiles, zero padding
+    (100, 128, REFLECT, 256, 256, True),      # THREE full chunks (group 1 of the last workgroup has none) + a 4-channel tail
 ]
 
 
@@ -192,7 +193,8 @@ def test_wgrad_bf3_pingpong_is_bit_identical_to_the_round4_kernel(dev, tmp_path)
     """Round 5: wgrad_bf3_kernel as a ping-pong of two wave groups (one 8-wave workgroup per CU, staging of one group under
     the MFMAs of the other) walks the same tiles in the same order with the same MFMA sequence per accumulator as the
     round-4 kernel (DIP_WGRAD_BF3_V1=1): dW and db must agree BIT FOR BIT on every case, including an odd number of
-    32-channel chunks, a partial chunk, two column blocks and ragged tiles (tests/wgrad_bf3_probe.py)."""
+    32-channel chunks (with and without a 4-channel tail behind them), a partial chunk, two column blocks and ragged tiles
+    (tests/wgrad_bf3_probe.py)."""
     import subprocess
     import sys
     probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "wgrad_bf3_probe.py")
@@ -202,7 +204,7 @@ def test_wgrad_bf3_pingpong_is_bit_identical_to_the_round4_kernel(dev, tmp_path)
         r = subprocess.run([sys.executable, probe, o], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-3000:]
         out[tag] = np.load(o)
-    assert sorted(out["new"].files) == sorted(out["v1"].files) and len(out["new"].files) == 16
+    assert sorted(out["new"].files) == sorted(out["v1"].files) and len(out["new"].files) == 20
     for k in out["new"].files:
         a, b = out["new"][k], out["v1"][k]
         assert np.isfinite(a).all(), k

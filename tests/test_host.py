@@ -570,6 +570,25 @@ def test_bench_gpus_2_starts_two_ranks():
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
 
 
+def test_bench_gpus_8_starts_eight_ranks():
+    """The world size the driver's scaling run uses (1 / 2 / 4 / 8 GPUs of one node): `python bench.py --gpus 8` starts eight
+    worker processes that meet over gloo on 127.0.0.1 (barrier, per-rank gather, max-over-ranks time) and print ONE line with
+    eight per-rank figures; the shards of a batch of 8 x instances images are disjoint and cover it."""
+    import json
+    r = _bench_selftest([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and len(d["per_rank_it_s"]) == 8 and all(v > 0 for v in d["per_rank_it_s"]) and d["value"] > 0
+    sys.path.insert(0, ROOT)
+    import bench
+    for inst in (1, 3):
+        shards = [bench.shard_images(8 * inst, rk, 8) for rk in range(8)]
+        assert sorted(i for sh in shards for i in sh) == list(range(8 * inst)) and all(len(sh) == inst for sh in shards)
+        assert [sh[0] for sh in shards] == list(range(8))        # round-robin: rank r's first image (= seed) is r
+
+
 def test_arena_lbfgs_matches_torch_lbfgs():
     """dip_optim.ArenaLBFGS restates torch.optim.LBFGS (no line search, the reference's settings:
     tolerance -1, utils/common_utils.py:218): same iterates on a small smooth problem, for parameters

@@ -6,6 +6,7 @@ fp64 truth as the reference's own fp32 CPU path (x4 for summation order, + 2e-5 
 Adam on identical grads <= few ulp; trajectories are chaotic, so later iterations are compared on
 end quality only."""
 import copy
+import functools
 import json
 import os
 import sys
@@ -49,6 +50,14 @@ NETS = {
     "tiny_elu": dict(args=(8, 3), kw=dict(num_channels_down=[16, 16], num_channels_up=[16, 16],
                                           num_channels_skip=[4, 4], upsample_mode="nearest", act_fun="ELU",
                                           need_sigmoid=True, need_bias=True, pad="zero")),
+    # act_fun as a module CLASS / factory (models/common.py:90-91 of the reference; round 6): nn.ReLU, LeakyReLU(0.1)
+    "tiny_relu": dict(args=(8, 3), kw=dict(num_channels_down=[16, 32], num_channels_up=[16, 32],
+                                           num_channels_skip=[4, 4], upsample_mode="bilinear", act_fun=torch.nn.ReLU,
+                                           need_sigmoid=True, need_bias=True, pad="reflection")),
+    "tiny_leaky01": dict(args=(8, 3), kw=dict(num_channels_down=[16, 16], num_channels_up=[16, 16],
+                                              num_channels_skip=[4, 4], upsample_mode="nearest",
+                                              act_fun=functools.partial(torch.nn.LeakyReLU, 0.1),
+                                              need_sigmoid=True, need_bias=True, pad="zero")),
     "tiny_skip3": dict(args=(8, 3), kw=dict(num_channels_down=[16, 32], num_channels_up=[16, 32],
                                             num_channels_skip=[4, 4], filter_skip_size=3, upsample_mode="bilinear",
                                             need_sigmoid=True, need_bias=True, pad="reflection")),

@@ -20,7 +20,8 @@ import dip_native as N  # noqa: E402
 import hipops as H  # noqa: E402
 
 CASES = [(128, 128, N.PAD_REFLECT, 256, 256, True), (132, 128, N.PAD_REFLECT, 256, 256, True),
-         (48, 160, N.PAD_ZERO, 250, 280, False), (96, 128, N.PAD_REFLECT, 256, 272, True)]      # (96: an odd number of 32-channel chunks)
+         (48, 160, N.PAD_ZERO, 250, 280, False), (96, 128, N.PAD_REFLECT, 256, 272, True),      # (96: an odd number of 32-channel chunks)
+         (100, 128, N.PAD_REFLECT, 256, 256, True)]      # (100: an odd number of chunks AND a 4-channel tail -- ADVICE r05)
 
 
 def main():
