@@ -144,6 +144,7 @@ class SkipEngine:
         # plane, so statistics -> finalise -> apply needs no grid-wide dependency); the library decides per shape
         # (dip_bn_bwd_one_ok: DIP_BNB_ONE_MAX_PIXELS, 0 = off)
         self.bnb_one = os.environ.get("DIP_BNB_NO_ONE") is None
+        self.tail_inline = self.two_streams and os.environ.get("DIP_TAIL_INLINE", "1") != "0"
         # phase 2 of a BatchNorm backward in the prologue of its apply launch when phase 1 left few partial rows
         # (dip_bn_bwd_apply_src_fin / _apply_fin; the library decides: dip_bn_bwd_fin_rows_ok, DIP_BNB_FIN_MAX_ROWS)
         # MEASURED (profiles/r06_ab_bnb_fin_fuse.txt): -8 launches per iteration of the default net, -10 of the 'library' net,
@@ -934,7 +935,12 @@ class SkipEngine:
             dy_d2 = self._emit_bn_act_bwd(st["d2"], gin, ops)
         else:
             dy_d2 = dy_deep
-        self._emit_wgrad(s.down_b, st["d1"], dy_d2, ops, scale=i)
+        # the LAST batch of weight gradients (scale 0's encoder convs) is not held back: flushed at the end of the scale they
+        # would fork off the main stream behind its last kernel and run as a pure tail (r05 timeline: main ends at +5870 us,
+        # wgrad s0.down_b + s0.down_a + reductions until +6134); issued where their dy appears, the first runs next to the
+        # scale's data gradient and only the second remains behind the main chain (DIP_TAIL_INLINE=0: the round-5 order)
+        inline_tail = i == 0 and self.tail_inline
+        self._emit_wgrad(s.down_b, st["d1"], dy_d2, ops, scale=None if inline_tail else i)
         g = self._emit_dgrad(s.down_b, st["d1"], dy_d2, ops, fuse_bn=True)
         dy_d1 = self._emit_bn_act_bwd(st["d1"], g, ops)
         if s.pool == 'lanczos':             # backward of the Downsampler's dense conv: its weight gradient, then the data
@@ -961,7 +967,7 @@ class SkipEngine:
                                                             s.down_a.Cout, _ptr(dy_full), Cs1),
                                 "poolb:" + s.down_a_bn.name))
             dy_d1 = dy_full
-        self._emit_wgrad(s.down_a, xin, dy_d1, ops, scale=i)
+        self._emit_wgrad(s.down_a, xin, dy_d1, ops, scale=None if inline_tail else i)
         tgt = ops if i > 0 else self.bwd_input_ops
         sk = s.skip_conv if s.ns else None
         sk_pad = sk.P if (sk is not None and sk.P > 0 and sk.pad_mode in (N.PAD_REFLECT, N.PAD_REPLICATE)) else 0
