@@ -1131,9 +1131,13 @@ class SkipEngine:
         if deps is None:
             deps = self._bwd_deps = self._backward_deps(ops)
             self._bwd_deps_for = ops
-        bulk2 = self._bulk2
+        # the second bulk stream is an EAGER form: inside a hipGraph every extra fork / join costs what ROCm 7.2's graph
+        # executor loses on them (tools/ubench/graph_fork_join.hip) -- snail as ONE graph 562 -> 638 it/s with the weight
+        # gradients back on one bulk stream (profiles/r06_ab_bulk2_graph.txt); the scratch sets stay as planned
+        capturing = torch.cuda.is_current_stream_capturing()
+        bulk2 = self._bulk2 if not capturing else ()
         cls = self._BWD_SIDE if not bulk2 else (lambda n: 3 if n in bulk2 else self._BWD_SIDE(n))
-        self._run_two_streams(ops, main, cls, lambda n: False, "bwd", deps)
+        self._run_two_streams(ops, main, cls, lambda n: False, "bwd_cap" if capturing else "bwd", deps)
 
     def _run_forward_two_streams(self, ops, main):
         side = self._fwd_side
