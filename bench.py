@@ -462,6 +462,40 @@ def dominant_ops(eng, fl):
     return out
 
 
+def roofline_thin(eng, per_op_ms, fl):
+    """The thin-layer kernels of round 6 (conv_thin_kernel: dip_conv_variant == 8; wgrad_thin_kernel: dip_wgrad_thin_eligible)
+    as a group: the layers' algorithmic FLOPs / their per-launch HIP-event time against the fp32 MFMA peak (they run
+    v_mfma_f32_16x16x4_f32).  None when the net has no such layer (the default / kate nets)."""
+    import dip_native as N
+    lib = N.lib()
+    groups = {"conv_thin_kernel": [0.0, 0.0, 0], "wgrad_thin_kernel": [0.0, 0.0, 0]}
+    for ops in (eng.fwd_ops, eng.bwd_ops):
+        for fn, args, name in ops:
+            kind = name.partition(":")[0]
+            ms = per_op_ms.get(name)
+            if ms is None:
+                continue
+            if kind in ("conv_fwd", "dgrad") and fn is lib.dip_conv_igemm and lib.dip_conv_variant(args[0]) == 8:
+                g = groups["conv_thin_kernel"]
+            elif kind == "wgrad" and lib.dip_wgrad_thin_eligible(args[0]):
+                g = groups["wgrad_thin_kernel"]
+            else:
+                continue
+            g[0] += fl.get(name, 0.0); g[1] += ms; g[2] += 1
+    if not any(g[2] for g in groups.values()):
+        return None
+    out = {"bound": "mfma", "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "traffic": None}
+    tf, tm = 0.0, 0.0
+    for k, (f, ms, n) in groups.items():
+        if n:
+            out[k] = {"launches_per_step": n, "ms_per_step": round(ms, 3), "algorithmic_gflop_per_step": round(f / 1e9, 2),
+                      "achieved": round(f / (ms * 1e-3) / 1e12, 2), "frac": round(f / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
+            tf += f; tm += ms
+    out["achieved"] = round(tf / (tm * 1e-3) / 1e12, 2)
+    out["frac"] = round(out["achieved"] / PEAK_FP32_MFMA_TFLOPS, 4)
+    return out
+
+
 def hbm_ops(eng):
     """Compulsory HBM bytes of every memory-bound launch of one iteration under THIS engine's fusion plan, as
     {op name: bytes}: each operand tensor of the launch read once, each result written once (4 bytes per float,
@@ -1147,11 +1181,12 @@ def main():
         eng = fits[0].engine
         if not hasattr(eng, "fwd_ops") and grouped is not None:
             eng = grouped.eng                  # --group native without the per-launch profile: the per-fit nets never ran
-        rl = rw = rh = r3 = None
+        rl = rw = rh = r3 = rthin = None
         if not args.no_roofline:
             rl, rw = roofline(eng, per_op, with_pmc=(args.config == "default"))
             rh = roofline_hbm(eng, per_op)
             r3 = conv3x3_all(eng, per_op, conv_flops(eng))
+            rthin = roofline_thin(eng, per_op, conv_flops(eng))
             if args.dump_ops:
                 fl = conv_flops(eng)
                 with open(args.dump_ops, "w") as f:
@@ -1247,7 +1282,7 @@ def main():
             "per_rank_final_loss": [round(v, 6) for v in per_rank_loss],
             "per_rank_final_loss_hex": [float(v).hex() for v in per_rank_loss],
             "timed_region_power": best.get("power"),
-            "roofline": rl, "roofline_wgrad": rw, "roofline_conv3x3_all": r3, "roofline_hbm": rh,
+            "roofline": rl, "roofline_wgrad": rw, "roofline_conv3x3_all": r3, "roofline_thin": rthin, "roofline_hbm": rh,
             "sustained": sustained, "host_issue": hissue, "build_id": _N.lib().dip_build_id().decode(),
             "per_rank_power_w": [None if v != v else round(v, 1) for v in per_rank_power],
             "per_rank_sclk_mhz": [None if v != v else round(v) for v in per_rank_sclk],
