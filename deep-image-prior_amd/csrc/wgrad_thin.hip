@@ -276,7 +276,9 @@ extern "C" int dip_wgrad_thin_nsplit(int Hout, int Wout, int Cin, int Cout, int 
 extern "C" int dip_wgrad_thin_eligible(const DipWgradDesc* dp) {
     const DipWgradDesc& d = *dp;
     if (!wthin_shape_ok(d.Hout, d.Wout, d.Cin, d.Cout, d.ks, d.stride)) return 0;
-    if ((d.Cx & 3) || (d.Cdy & 3) || (d.Cin & 3) || d.Cin > d.Cx || d.Cdy < d.Cout) return 0;
+    // (Cin itself need not be a multiple of 4: the float4 of a ragged last group reads the zero pad channels of x, and the slab
+    // rows c >= Cin it produces are never read by dip_wgrad_reduce)
+    if ((d.Cx & 3) || (d.Cdy & 3) || d.Cin > d.Cx || d.Cdy < d.Cout) return 0;
     return 1;
 }
 

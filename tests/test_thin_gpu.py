@@ -94,6 +94,7 @@ WGRAD_CASES = [
     (36, 20, 3, 1, REFLECT, 72, 72, True),       # odd channel counts: a 4-channel input block, a 4-column output block
     (64, 64, 5, 1, REFLECT, 66, 70, True),       # 2 x 2 channel blocks
     (16, 48, 3, 2, ZERO, 140, 150, True),        # stride 2, zero padding, 2 output blocks (the second half empty)
+    (10, 12, 3, 1, REFLECT, 70, 72, True),       # 10 input channels (a net fed with a 10-plane image): the last float4 is ragged
 ]
 
 
