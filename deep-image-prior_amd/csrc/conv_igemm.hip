@@ -492,13 +492,21 @@ extern "C" int dip_conv_bf3_n64_plan(int ntiles, int Cin, int Cout);       // co
 // split-K workspace size in floats (0 when ksplit == 1).
 extern "C" int dip_conv_thin_shape_ok(int Hout, int Wout, int Cin, int Cout, int ks, int stride);      // conv_thin.hip
 static int conv_plan_impl(int Hout, int Wout, int Cin, int Cout, int ks, int stride, int* ksplit, int* stats_rows,
-                          int64_t* ws_floats, bool allow_thin);
+                          int64_t* ws_floats, bool allow_thin, bool allow_n64 = true);
 extern "C" int dip_conv_plan(int Hout, int Wout, int Cin, int Cout, int ks, int stride, int* ksplit,
                              int* stats_rows, int64_t* ws_floats) {
     return conv_plan_impl(Hout, Wout, Cin, Cout, ks, stride, ksplit, stats_rows, ws_floats, true);
 }
+// the plan of a layer that turned out NOT to be eligible for the bf16-pipe kernel although its shape is (no split weights in
+// the descriptor, a transform over > 512 input channels, fused BatchNorm-backward partials): dip_conv_plan gives a 3x3
+// stride-1 layer with 96..255 tiles ONE pass because the 64-column bf16 form fills the chip there; on the fp32 kernels that
+// pass is 96..255 workgroups, so this plan splits K as it did before round 5 (the engine re-plans with it)
+extern "C" int dip_conv_plan_fp32(int Hout, int Wout, int Cin, int Cout, int ks, int stride, int* ksplit,
+                                  int* stats_rows, int64_t* ws_floats) {
+    return conv_plan_impl(Hout, Wout, Cin, Cout, ks, stride, ksplit, stats_rows, ws_floats, true, false);
+}
 static int conv_plan_impl(int Hout, int Wout, int Cin, int Cout, int ks, int stride, int* ksplit, int* stats_rows,
-                          int64_t* ws_floats, bool allow_thin) {
+                          int64_t* ws_floats, bool allow_thin, bool allow_n64) {
     const int ntiles = dip_conv_ntiles(Hout, Wout);
     // thin layers (<= 64 channels in and out, 3x3 / 5x5, above conv_small's range): conv_thin_kernel, always one pass
     if (allow_thin && dip_conv_thin_shape_ok(Hout, Wout, Cin, Cout, ks, stride)) {
@@ -533,7 +541,7 @@ static int conv_plan_impl(int Hout, int Wout, int Cin, int Cout, int ks, int str
         if (k < kmin) k = kmin;
     }
     // 96..255 tiles: the 64-column bf16-pipe kernel, one pass
-    if (ks == 3 && stride == 1 && dip_conv_bf3_n64_plan(ntiles, dip_round_up(Cin, 4), Cout)) k = 1;
+    if (allow_n64 && ks == 3 && stride == 1 && dip_conv_bf3_n64_plan(ntiles, dip_round_up(Cin, 4), Cout)) k = 1;
     const int Cy = dip_round_up(Cout, 4);
     *ksplit = k;
     if (k > 1) {

@@ -533,7 +533,11 @@ class SkipEngine:
         if small:
             ksplit, ntiles, wsf = 1, self.lib.dip_conv_small_rows(C.byref(d)), 0
         else:
-            ksplit, ntiles, wsf = N.conv_plan(Ho, Wo, round_up(x.C, 4), r.Cout, r.ks, r.stride)
+            # (a layer the bf16-pipe kernel will not take -- no split weights, a transform over > 512 channels -- is planned for
+            # the fp32 kernels: dip_conv_plan's "96..255 tiles in one pass" rule is the 64-column bf16 form's)
+            bf3_ok = self.bf3 and getattr(r, "fwd3_off", -1) >= 0 and not (x.bn is not None and round_up(x.C, 4) > 512)
+            plan = N.conv_plan if bf3_ok else N.conv_plan_fp32
+            ksplit, ntiles, wsf = plan(Ho, Wo, round_up(x.C, 4), r.Cout, r.ks, r.stride)
         # the skip-branch convs run on the side stream next to the encoder convs of their scale
         # (_run_two_streams), so they get scratch of their own
         # (a skip conv below DIP_SIDE_MIN_PIXELS stays on the main stream AND on the main stream's scratch: the side
@@ -694,7 +698,9 @@ class SkipEngine:
         if r.stride == 2:
             ksplit, _, wsf = N.conv_plan_dil2(Hg, Wg, round_up(r.Cout, 4), r.Cin, r.ks)
         else:
-            ksplit, _, wsf = N.conv_plan(Hg, Wg, round_up(r.Cout, 4), r.Cin, r.ks, 1)
+            # (fused BatchNorm-backward partials keep the layer off the bf16-pipe kernel: planned for the fp32 kernels then)
+            bf3_ok = self.bf3 and getattr(r, "dgrad3_off", -1) >= 0 and not (fuse_bn and self.fuse_bnb and not ring and x.bn is not None)
+            ksplit, _, wsf = (N.conv_plan if bf3_ok else N.conv_plan_fp32)(Hg, Wg, round_up(r.Cout, 4), r.Cin, r.ks, 1)
         sizing = self._sizing
         d = N.DipConvDesc(None if sizing else _ptr(dy), Ho, Wo, round_up(r.Cout, 4), round_up(r.Cout, 4),
                           N.DipTransform(None, None, 1.0), None if sizing else _ptr(self.packed, r.dgrad_off), None,

@@ -139,6 +139,8 @@ _SIGS = {
     "dip_conv_igemm_dma_cols": (C.c_int, [C.POINTER(DipConvDesc), C.c_int, C.c_void_p]),
     "dip_conv_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
                                 C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
+    "dip_conv_plan_fp32": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                    C.POINTER(C.c_int64)]),
     "dip_conv_plan_dil2": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
                                      C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "dip_conv_wgrad": (C.c_int, [C.POINTER(DipWgradDesc), C.c_void_p]),
@@ -276,6 +278,13 @@ def conv_plan(Hout, Wout, Cin, Cout, ks, stride):
     """(ksplit, stats_rows, ws_floats) of dip_conv_plan."""
     k, rows, wsf = C.c_int(), C.c_int(), C.c_int64()
     check(lib().dip_conv_plan(Hout, Wout, Cin, Cout, ks, stride, C.byref(k), C.byref(rows), C.byref(wsf)), "conv_plan")
+    return k.value, rows.value, wsf.value
+
+
+def conv_plan_fp32(Hout, Wout, Cin, Cout, ks, stride):
+    """(ksplit, stats_rows, ws_floats) of dip_conv_plan_fp32: the plan of a layer the bf16-pipe kernel does not take."""
+    k, rows, wsf = C.c_int(), C.c_int(), C.c_int64()
+    check(lib().dip_conv_plan_fp32(Hout, Wout, Cin, Cout, ks, stride, C.byref(k), C.byref(rows), C.byref(wsf)), "conv_plan_fp32")
     return k.value, rows.value, wsf.value
 
 

@@ -237,6 +237,11 @@ int dip_conv_bnb_fusable(const DipConvDesc* d);
  * split-K workspace size in floats (0 when *ksplit == 1) */
 int dip_conv_plan(int Hout, int Wout, int Cin, int Cout, int ks, int stride, int* ksplit, int* stats_rows,
                   int64_t* ws_floats);
+/* the same for a layer that is NOT taken by the bf16-pipe kernel although its shape is (no DipConvDesc.wp3, a transform over
+ * more than 512 input channels, fused bnb_* partials): without the "96..255 tiles run the 64-column bf16 form in one pass"
+ * rule, i.e. split-K as the fp32 kernels want it.  The engine re-plans with it when dip_conv_bf3_eligible(d) == 0. */
+int dip_conv_plan_fp32(int Hout, int Wout, int Cin, int Cout, int ks, int stride, int* ksplit, int* stats_rows,
+                       int64_t* ws_floats);
 /* launch plan of the data gradient of a stride-2 3x3 convolution (a dil == 2 descriptor; Hout x Wout is
  * the gradient's domain, Cin/Cout the descriptor's): the LDS-DMA kernel's phase mode evaluates it as 4
  * dense sub-filter convolutions, one per output-pixel parity (9 taps per 4 pixels instead of 36), with its

@@ -90,6 +90,11 @@ def test_launch_plans_of_the_round2_kernels(built):
     # the 64-column form of the bf16-pipe kernel in ONE pass (two workgroups per pixel tile)
     assert N.conv_plan(128, 128, 128, 128, 3, 1)[0] == 1 and N.conv_plan(128, 128, 128, 128, 3, 2)[0] == 4
     assert N.conv_plan(128, 128, 128, 64, 3, 1)[0] == 4             # < 128 columns: the fp32 split-K kernel as before
+    # ... and a layer of that shape the bf16-pipe kernel will NOT take (no split weights, fused bnb partials, a transform over
+    # > 512 channels) keeps the fp32 kernels' split-K: the engine plans it with dip_conv_plan_fp32
+    assert N.conv_plan_fp32(128, 128, 128, 128, 3, 1)[0] == 4
+    for shape in ((512, 512, 128, 128, 3, 1), (128, 128, 128, 64, 3, 1), (64, 64, 128, 128, 3, 1), (224, 352, 16, 16, 5, 1)):
+        assert N.conv_plan_fp32(*shape) == N.conv_plan(*shape)      # everywhere else the two planners agree
     # weight gradient: nsplit counts SLABS; narrow layers write 4 / 2 per workgroup (waves split the K steps)
     n16 = N.wgrad_plan2(224, 352, 16, 16, 3, 1)[0]
     n64 = N.wgrad_plan2(224, 352, 16, 64, 3, 1)[0]
@@ -100,6 +105,36 @@ def test_launch_plans_of_the_round2_kernels(built):
     for args in ((224, 352, 1, 16, 5, 2), (128, 192, 3, 8, 3, 2), (512, 512, 2, 128, 7, 1)):
         n, g, cb = N.wgrad_plan2(*args)
         assert 1 <= n <= 512 and n == N.wgrad_plan(*args)
+
+
+def test_one_pass_plans_of_the_n64_range_are_bf16_pipe_eligible(built, monkeypatch):
+    """dip_conv_plan gives a 3x3 stride-1 layer with 96..255 tiles ONE pass because the 64-column bf16-pipe kernel fills
+    the chip with it; a descriptor that kernel refuses (fused BatchNorm-backward partials, no split weights) must not be left with
+    that plan.  Planned on CPU memory for the default arithmetic and with DIP_BNB_FUSE=1."""
+    import ctypes as C
+    from models.skip import skip
+    import dip_native as N
+    if not built.dip_conv_bf3_terms():
+        pytest.skip("DIP_CONV_BF3=0 in the environment")
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("DIP_BNB_FUSE", fuse)
+        net = skip(32, 3, [128] * 3, [128] * 3, [4] * 3, pad="reflection")
+        eng = net.__dict__["_dip_engine"]
+        assert eng.fuse_bnb == (fuse == "1")
+        eng._build_arenas(torch.device("cpu"))
+        eng._build_plan(256, 256, 32)
+        seen = 0
+        for d in eng.keep:
+            if not isinstance(d, N.DipConvDesc) or d.ks != 3 or d.stride != 1 or d.dil != 1 or d.Cout < 128 or d.Cin < 16:
+                continue
+            if not 96 <= built.dip_conv_ntiles(d.Hout, d.Wout) < 256:
+                continue
+            seen += 1
+            if d.ksplit <= 1:
+                assert built.dip_conv_bf3_eligible(C.byref(d)), (fuse, d.Hout, d.Wout, d.Cin, d.Cout)
+            else:
+                assert not built.dip_conv_bf3_eligible(C.byref(d))
+        assert seen >= 2, seen
 
 
 def test_planner_builds_launch_lists_for_every_option(built):
