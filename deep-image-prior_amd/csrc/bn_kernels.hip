@@ -161,6 +161,7 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const DipGradSrc src_
         const int npix = H * W;
         const int p0 = blockIdx.x * ppb;
         const int p1 = min(p0 + ppb, npix);
+        const GradSrcThin tw = grad_src_thin(src, ch);
         auto one = [&](int p, const f32x4& du, const f32x4& yv) {
             f32x4 g;
 #pragma unroll
@@ -178,8 +179,8 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const DipGradSrc src_
         for (; p + L.rpi < p1; p += 2 * L.rpi) {
             const int q = p + L.rpi;
             const int r0 = p / W, c0 = p - r0 * W, r1 = q / W, c1 = q - r1 * W;
-            const f32x4 du0 = grad_src4(src, r0, c0, H, W, ch);
-            const f32x4 du1 = grad_src4(src, r1, c1, H, W, ch);
+            const f32x4 du0 = grad_src4(src, tw, r0, c0, H, W, ch);
+            const f32x4 du1 = grad_src4(src, tw, r1, c1, H, W, ch);
             const f32x4 y0 = ld4(y + (size_t)p * Cy + ch);
             const f32x4 y1 = ld4(y + (size_t)q * Cy + ch);
             one(p, du0, y0);
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const DipGradSrc src_
         }
         if (p < p1) {
             const int r = p / W, c = p - r * W;
-            one(p, grad_src4(src, r, c, H, W, ch), ld4(y + (size_t)p * Cy + ch));
+            one(p, grad_src4(src, tw, r, c, H, W, ch), ld4(y + (size_t)p * Cy + ch));
         }
     }
     if (fin.coef == nullptr) {
@@ -380,6 +381,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_src_kernel(const DipGradSrc 
     const int npix = H * W;
     const int p0 = blockIdx.x * ppb;
     const int p1 = min(p0 + ppb, npix);
+    const GradSrcThin tw = grad_src_thin(src, ch);
     auto one = [&](int p, const f32x4& du, const f32x4& yv) {
         f32x4 g;
 #pragma unroll
@@ -395,8 +397,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_src_kernel(const DipGradSrc 
     for (; p + L.rpi < p1; p += 2 * L.rpi) {            // two pixels per iteration (see bn_bwd_stats_kernel)
         const int q = p + L.rpi;
         const int r0 = p / W, c0 = p - r0 * W, r1 = q / W, c1 = q - r1 * W;
-        const f32x4 du0 = grad_src4(src, r0, c0, H, W, ch);
-        const f32x4 du1 = grad_src4(src, r1, c1, H, W, ch);
+        const f32x4 du0 = grad_src4(src, tw, r0, c0, H, W, ch);
+        const f32x4 du1 = grad_src4(src, tw, r1, c1, H, W, ch);
         const f32x4 y0 = ld4(y + (size_t)p * Cy + ch);
         const f32x4 y1 = ld4(y + (size_t)q * Cy + ch);
         one(p, du0, y0);
@@ -404,7 +406,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_src_kernel(const DipGradSrc 
     }
     if (p < p1) {
         const int r = p / W, c = p - r * W;
-        one(p, grad_src4(src, r, c, H, W, ch), ld4(y + (size_t)p * Cy + ch));
+        one(p, grad_src4(src, tw, r, c, H, W, ch), ld4(y + (size_t)p * Cy + ch));
     }
 }
 

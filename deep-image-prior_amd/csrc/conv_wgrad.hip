@@ -805,6 +805,15 @@ extern "C" int dip_wgrad_plan(int Hout, int Wout, int Cin, int Cout, int ks, int
     int n = 512 / per_split;
     if (n > nt / 4) n = nt / 4;        // >= 4 pixel tiles per workgroup: amortise its slab write + the reduce
     if (n < 1) n = 1;
+    // the layers wgrad_bf3_kernel takes (3x3 stride 1, >= 512 tiles of 2 x 16 pixels): ONE 8-wave workgroup per CU that fills its
+    // register file, resident for the whole launch -- 256 of them leave no CU to the dependent chain of the main stream, which then
+    // waits for the launch to end (profiles/r06_timeline_three_streams.txt: a 6 us bn_bwd_finalize "runs" 450 us beside the 512^2
+    // weight gradient).  DIP_WGRAD_BF3_WGS caps the grid so that 256 - cap CUs stay free for the chain.
+    static const int bf3_wgs = [] { const char* e = getenv("DIP_WGRAD_BF3_WGS"); return e ? atoi(e) : 0; }();
+    if (bf3_wgs > 0 && ks == 3 && stride == 1 && Cin >= 32 && Cout >= 97 && dip_cdiv(Wout, 16) * dip_cdiv(Hout, 2) >= 512) {
+        const int cap = bf3_wgs / (dip_cdiv(chunks, 2) * dip_cdiv(CoutP, 128));
+        if (cap >= 1 && n > cap) n = cap;
+    }
     const long long slab = (long long)ks * ks * CinP * CoutP;
     while (n > 1 && (long long)n * slab > (64ll << 20)) n /= 2;
     *nsplit = n * wgrad_kw(CoutP);         // narrow layers: kw slabs per workgroup

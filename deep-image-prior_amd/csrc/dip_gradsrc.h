@@ -6,8 +6,31 @@
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
+// The thin 1x1 conv in front of the activation (DipGradSrc.tw): its <= 4 weight rows for channels [ch, ch+4), loaded once per
+// thread (the streaming kernels keep `ch` for their whole pixel range), and du for one pixel from the conv's output gradient --
+// a fixed chain of fused multiply-adds, j = 0 .. tn-1, per channel.
+struct GradSrcThin {
+    f32x4 w[4];
+};
+__device__ __forceinline__ GradSrcThin grad_src_thin(const DipGradSrc& s, int ch) {
+    GradSrcThin t;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t.w[j] = (s.tw != nullptr && j < s.tn) ? ld4(s.tw + (size_t)j * s.tcw + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
+    return t;
+}
+__device__ __forceinline__ f32x4 grad_src_thin4(const DipGradSrc& s, const GradSrcThin& t, int r, int c, int W) {
+    f32x4 gv = ld4(s.g + ((size_t)r * W + c) * s.Cg);
+#pragma unroll
+    for (int j = 1; j < 4; ++j) gv[j] = j < s.tn ? gv[j] : 0.f;          // (the pad channels of g are not part of the sum)
+    f32x4 du;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) du[e] = fmaf(gv[3], t.w[3][e], fmaf(gv[2], t.w[2][e], fmaf(gv[1], t.w[1][e], gv[0] * t.w[0][e])));
+    return du;
+}
+
 // incoming gradient for pixel (r,c), channels [ch, ch+4): padded source with optional reflection fold
 __device__ __forceinline__ f32x4 grad_src4(const DipGradSrc& s, int r, int c, int H, int W, int ch) {
+    if (s.tw != nullptr) return grad_src_thin4(s, grad_src_thin(s, ch), r, c, W);
     const int P = s.pad;
     const float* base = s.g + s.choff + ch;
     if (s.win_h > 0) {                       // adjoint of a centre crop: zero outside the window
@@ -92,4 +115,10 @@ __device__ __forceinline__ f32x4 up_adj_du4(const float* base, int Cs_cat, int H
             for (int e = 0; e < 4; ++e) du[e] = fmaf(w, gw[tr * 4 + tc][e], du[e]);
         }
     return du;
+}
+
+// the same with the thin conv's weights hoisted by the caller (t = grad_src_thin(s, ch) in front of its pixel loop)
+__device__ __forceinline__ f32x4 grad_src4(const DipGradSrc& s, const GradSrcThin& t, int r, int c, int H, int W, int ch) {
+    if (s.tw != nullptr) return grad_src_thin4(s, t, r, c, W);
+    return grad_src4(s, r, c, H, W, ch);
 }

@@ -68,7 +68,7 @@ template <class F> __host__ __device__ inline void dip_ptrs(DipConvDesc& d, F& f
 template <class F> __host__ __device__ inline void dip_ptrs(DipWgradDesc& d, F& f) {
     f(d.x); dip_ptrs(d.tr, f); f(d.dy); f(d.partial); f(d.bias_partial);
 }
-template <class F> __host__ __device__ inline void dip_ptrs(DipGradSrc& s, F& f) { f(s.g); }
+template <class F> __host__ __device__ inline void dip_ptrs(DipGradSrc& s, F& f) { f(s.g); f(s.tw); }
 template <class F> __host__ __device__ inline void dip_ptrs(DipBnFin& b, F& f) {
     f(b.gamma); f(b.beta); f(b.state); f(b.running_mean); f(b.running_var); f(b.ticket);
 }

@@ -130,6 +130,7 @@ class SkipEngine:
         # per-lane reads of y cost the big launches 35..75 us each, as much as the streaming statistics kernels they
         # replace (+0.5 % on a fast-class box, -1.5 % on a slow-class one) -- so it is opt-in
         self.fuse_bnb = os.environ.get("DIP_BNB_FUSE", "0") == "1"
+        self.thin_src = os.environ.get("DIP_NO_THIN_SRC") is None
         # low-resolution layers (<= DIP_SMALL_MAX_PIXELS output pixels): ONE dip_conv_small launch per convolution
         # (conv + in-workgroup split-K + BatchNorm partials; dip_bn_finalize follows) instead of conv + split-K finish +
         # bn_finalize, and data gradient + BatchNorm-backward partials (+ dip_bn_bwd_finalize2) instead of four launches
@@ -402,7 +403,12 @@ class SkipEngine:
             self.dy_out = self._buf(last.H * last.W * round_up(oc.Cout, 4))
             pre = []
             self._emit_wgrad(oc, last, self.dy_out, pre, scale=0)
-            du_last = self._emit_dgrad(oc, last, self.dy_out, pre, fuse_bn=True)
+            if self._thin_src_ok(oc, last):
+                # the 1x1 output conv's data gradient is not a launch: the BatchNorm backward of `last` evaluates
+                # du = W^T dy_out per pixel where it reads it (DipGradSrc.tw) -- three passes over a [H][W][C] tensor less
+                du_last = (self.dy_out, 0, oc)
+            else:
+                du_last = self._emit_dgrad(oc, last, self.dy_out, pre, fuse_bn=True)
             dy_last = self._emit_bn_act_bwd(last, du_last, pre)
             self.dbg_top = {"du_last": du_last, "dy_last": dy_last, "last": last}
             self.last_act = last                         # input of the output conv (utils/loss_head.MSEHead)
@@ -771,7 +777,20 @@ class SkipEngine:
             ops.append((self.lib.dip_conv_dgrad_ring, (C.byref(dr),), "dgring:" + r.name))
         return (gbuf, pad)
 
+    def _thin_src_ok(self, oc: ConvRec, last: Act) -> bool:
+        """The net's last conv (models/skip.py:98) as a gradient source of the BatchNorm in front of it: 1x1, <= 4 output
+        channels, a whole number of float4 channel groups in, and an activation above the one-launch BatchNorm backward's range
+        (DIP_NO_THIN_SRC=1: the data-gradient launch as before round 6's second session)."""
+        return (self.thin_src and oc.ks == 1 and oc.stride == 1 and oc.Cout <= 4 and oc.Cin % 4 == 0 and last.bn is not None
+                and not self.fuse_bnb and not self._bnb_one_ok(last))
+
     def _gradsrc(self, g, Cg, choff=0, window=None):
+        if len(g) == 3:                           # (dy of the thin 1x1 conv, 0, its ConvRec): _thin_src_ok
+            buf, _, oc = g
+            d = N.DipGradSrc(_ptr(buf), 0, 0, round_up(oc.Cout, 4), 0)
+            d.tw, d.tn, d.tcw = _ptr(self.params, oc.w_off), oc.Cout, oc.Cin
+            self.keep.append(d)
+            return d
         buf, pad = g
         fold = 0 if pad == 0 else (2 if buf.data_ptr() in self._replicate_bufs else 1)
         d = N.DipGradSrc(_ptr(buf), pad, fold, Cg, choff)

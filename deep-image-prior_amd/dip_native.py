@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdip_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 PAD_ZERO, PAD_REFLECT, PAD_REPLICATE = 0, 1, 2
 UP_NEAREST, UP_BILINEAR = 0, 1
@@ -71,7 +71,8 @@ class DipWgradDesc(C.Structure):
 
 class DipGradSrc(C.Structure):
     _fields_ = [("g", C.c_void_p), ("pad", C.c_int32), ("fold", C.c_int32), ("Cg", C.c_int32), ("choff", C.c_int32),
-                ("win_y", C.c_int32), ("win_x", C.c_int32), ("win_h", C.c_int32), ("win_w", C.c_int32)]
+                ("win_y", C.c_int32), ("win_x", C.c_int32), ("win_h", C.c_int32), ("win_w", C.c_int32),
+                ("tw", C.c_void_p), ("tn", C.c_int32), ("tcw", C.c_int32)]      # thin 1x1 conv in front (round 6), or None
 
 
 class DipUpcatDesc(C.Structure):

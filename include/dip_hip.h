@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DIP_ABI_VERSION 7
+#define DIP_ABI_VERSION 8
 
 #define DIP_PAD_ZERO 0
 #define DIP_PAD_REFLECT 1
@@ -379,6 +379,14 @@ typedef struct DipGradSrc {
      * columns win_x..win_x+win_w-1 of the [H][W] activation; du = 0 outside (adjoint of Concat's centre crop,
      * models/common.py:29-37, for the branch that was cropped). */
     int32_t win_y, win_x, win_h, win_w;
+    /* Optional thin 1x1 convolution in front of the activation (tw != NULL; then pad == 0, no window, choff == 0): g is the
+     * gradient [H][W][Cg] of the OUTPUT of a bias + 1x1 conv with tn <= 4 output channels (the net's last nn.Conv2d,
+     * models/skip.py:98: num_channels_up[0] -> num_output_channels) and
+     *   du[ch] = sum_{j < tn} g[(r*W + c) * Cg + j] * tw[j * tcw + ch]          (tw = that conv's OIHW weight, tcw = its Cin)
+     * is evaluated where it is consumed -- the conv's data gradient (autograd ConvolutionBackward, input part) is never
+     * written to memory: one launch and three passes over an activation-sized tensor less per iteration. */
+    const float* tw;
+    int32_t tn, tcw;
 } DipGradSrc;
 
 /* BatchNorm+LeakyReLU backward, phase 1:  dz = du * (a*y+b > 0 ? 1 : slope); writes dz (unless

@@ -23,10 +23,10 @@ def test_cabi_exports_every_declared_symbol(built):
     L = ctypes.CDLL(dip_native.LIB_PATH)
     for name in declared:
         assert hasattr(L, name), name
-    assert built.dip_abi_version() == dip_native.ABI_VERSION == 7
+    assert built.dip_abi_version() == dip_native.ABI_VERSION == 8
     # struct layouts agree with the header's field order (sizes on LP64)
     assert ctypes.sizeof(dip_native.DipTransform) == 24
-    assert ctypes.sizeof(dip_native.DipGradSrc) == 40     # + the crop window of round 3
+    assert ctypes.sizeof(dip_native.DipGradSrc) == 56     # + the crop window of round 3, the thin 1x1 conv of round 6
     assert ctypes.sizeof(dip_native.DipPackRec) == 56
 
 

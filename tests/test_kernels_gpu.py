@@ -352,6 +352,76 @@ def test_bn_forward_backward_chain(dev, Cc, Hh, Ww, P, slope):
     _check("bn_bwd.dbeta", dbet, r64[2], r32[2], floor=5e-6)
 
 
+@pytest.mark.parametrize("Cc,Co,Hh,Ww,slope", [(128, 3, 40, 72, 0.2), (16, 1, 33, 47, 0.2), (64, 4, 128, 128, 1.0)])
+def test_bn_backward_from_the_thin_output_conv(dev, Cc, Co, Hh, Ww, slope):
+    """DipGradSrc.tw: conv-output y -> BN(train)+LeakyReLU -> the net's last 1x1 conv (Co <= 4 channels, models/skip.py:98)
+    -> random linear functional.  The BatchNorm backward evaluates du = W^T dout per pixel instead of reading a data
+    gradient from memory; dy, dgamma, dbeta against autograd in fp64 (tolerance: the fp32 reference's own distance)."""
+    lib = N.lib()
+    g = torch.Generator().manual_seed(5)
+    y = torch.randn(1, Cc, Hh, Ww, generator=g) * 2.0 + torch.randn(1, Cc, 1, 1, generator=g) * 3.0
+    gamma = torch.rand(Cc, generator=g) + 0.5
+    beta = torch.randn(Cc, generator=g)
+    w = torch.randn(Co, Cc, 1, 1, generator=g) / Cc ** 0.5
+    G = torch.randn(1, Co, Hh, Ww, generator=g)
+
+    def ref(dt):
+        yy = y.to(dt).requires_grad_(True)
+        ga, be = gamma.to(dt).requires_grad_(True), beta.to(dt).requires_grad_(True)
+        u = F.batch_norm(yy, None, None, ga, be, True, 0.1, 1e-5)
+        u = torch.maximum(u, slope * u)
+        (F.conv2d(u, w.to(dt)) * G.to(dt)).sum().backward()
+        return yy.grad, ga.grad, be.grad
+
+    r64, r32 = ref(torch.float64), ref(torch.float32)
+    Cs = round_up(Cc, 4)
+    y64 = y.double()[0].reshape(Cc, -1)
+    mean, rstd = y64.mean(1), 1 / torch.sqrt(y64.var(1, unbiased=False) + 1e-5)
+    a = gamma.double() * rstd
+    state = torch.zeros(4, Cs, dtype=torch.float64)
+    state[0, :Cc], state[1, :Cc], state[2, :Cc], state[3, :Cc] = mean, rstd, a, beta.double() - mean * a
+    state = state.float().to(dev).contiguous()
+    st = H.stream(dev)
+    yb = H.to_nhwc(y.to(dev))
+    Gb = H.to_nhwc(G.to(dev))                        # [H*W][4], pad channels zero
+    if Co < 4:
+        Gb.view(-1, 4)[:, Co:] = float("nan")        # ... or anything else: they are not part of the sum
+    wd = w.to(dev).contiguous()
+    src = N.DipGradSrc(Gb.data_ptr(), 0, 0, 4, 0)
+    src.tw, src.tn, src.tcw = wd.data_ptr(), Co, Cc
+    nblk = lib.dip_bn_bwd_nblk(Hh, Ww, Cc)
+    part = torch.full((nblk * 2 * Cs,), float("nan"), device=dev)
+    N.check(lib.dip_bn_bwd_stats(C.byref(src), yb.data_ptr(), Hh, Ww, Cs, Cc, state.data_ptr(), Cs, slope,
+                                 None, Cs, part.data_ptr(), nblk, st))
+    dgam, dbet = torch.zeros(Cc, device=dev), torch.zeros(Cc, device=dev)
+    coef = torch.zeros(2 * Cs, device=dev)
+    N.check(lib.dip_bn_bwd_finalize(part.data_ptr(), nblk, Cs, Cc, Hh * Ww, dgam.data_ptr(), dbet.data_ptr(),
+                                    coef.data_ptr(), st))
+    dy = torch.full((Hh * Ww * Cs,), float("nan"), device=dev)
+    N.check(lib.dip_bn_bwd_apply_src(C.byref(src), yb.data_ptr(), Hh, Ww, Cs, Cc, state.data_ptr(), Cs, slope,
+                                     coef.data_ptr(), dy.data_ptr(), Cs, st))
+    torch.cuda.synchronize()
+    _check("thin_src.dy", H.from_nhwc(dy, Cc, Hh, Ww), r64[0], r32[0], floor=5e-6)
+    _check("thin_src.dgamma", dgam, r64[1], r32[1], floor=5e-6)
+    _check("thin_src.dbeta", dbet, r64[2], r32[2], floor=5e-6)
+    # the explicit form (du written by the conv's data gradient, then read) gives the same dy to rounding
+    du = H.conv_dgrad(G.to(dev), wd, 1, REFLECT, Hh, Ww)
+    dub = H.to_nhwc(du)
+    src2 = N.DipGradSrc(dub.data_ptr(), 0, 0, Cs, 0)
+    dy2 = torch.full((Hh * Ww * Cs,), float("nan"), device=dev)
+    part2 = torch.full((nblk * 2 * Cs,), float("nan"), device=dev)
+    coef2 = torch.zeros(2 * Cs, device=dev)
+    N.check(lib.dip_bn_bwd_stats(C.byref(src2), yb.data_ptr(), Hh, Ww, Cs, Cc, state.data_ptr(), Cs, slope,
+                                 None, Cs, part2.data_ptr(), nblk, st))
+    N.check(lib.dip_bn_bwd_finalize(part2.data_ptr(), nblk, Cs, Cc, Hh * Ww, dgam.data_ptr(), dbet.data_ptr(),
+                                    coef2.data_ptr(), st))
+    N.check(lib.dip_bn_bwd_apply_src(C.byref(src2), yb.data_ptr(), Hh, Ww, Cs, Cc, state.data_ptr(), Cs, slope,
+                                     coef2.data_ptr(), dy2.data_ptr(), Cs, st))
+    torch.cuda.synchronize()
+    d1, d2 = H.from_nhwc(dy, Cc, Hh, Ww).double(), H.from_nhwc(dy2, Cc, Hh, Ww).double()
+    assert (d1 - d2).norm() <= 2e-6 * d2.norm()
+
+
 @pytest.mark.parametrize("Cin,Cout,ks,Hh,Ww,slope,mode", [
     (128, 128, 3, 24, 40, 0.2, "reflect"),      # LDS-DMA kernel, padded domain with a reflected ring, ragged tiles
     (132, 128, 3, 16, 32, 1.0, "reflect"),      # 132 columns: conv_thin4 (4 columns) + 128 columns, no activation (concat BN)
