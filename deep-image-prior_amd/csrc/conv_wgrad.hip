@@ -898,7 +898,10 @@ extern "C" int dip_wgrad_plan2(int Hout, int Wout, int Cin, int Cout, int ks, in
 extern "C" int dip_wgrad_bf3_eligible(const DipWgradDesc* dp);
 extern "C" int dip_wgrad_bf3(const DipWgradDesc* dp, void* stream);
 
+extern "C" int dip_wgrad_tail_stream_ok(const DipWgradDesc* dp);            // wgrad_tail.hip
+extern "C" int dip_wgrad_tail_stream(const DipWgradDesc* dp, void* stream);
 extern "C" int dip_conv_wgrad_tail(const DipWgradDesc* dp, void* stream) {
+    if (dip_wgrad_tail_stream_ok(dp)) return dip_wgrad_tail_stream(dp, stream);      // round 6: the streaming form
     return launch_tail(*dp, reinterpret_cast<hipStream_t>(stream));
 }
 

@@ -43,7 +43,7 @@ const Entry g_fns[] = {
     DIP_REG(dip_pack_weights), DIP_REG(dip_pack_weights_bf3),
     DIP_REG(dip_conv_igemm), DIP_REG(dip_conv_thin4), DIP_REG(dip_conv_igemm_dma_cols), DIP_REG(dip_conv_small), DIP_REG(dip_conv_thin),
     DIP_REG(dip_conv_dgrad_ring), DIP_REG(dip_conv_bf3_cols), DIP_REG(dip_conv_splitk_finish),
-    DIP_REG(dip_conv_wgrad), DIP_REG(dip_wgrad_bf3), DIP_REG(dip_wgrad_thin), DIP_REG(dip_conv_wgrad_tail), DIP_REG(dip_wgrad_reduce),
+    DIP_REG(dip_conv_wgrad), DIP_REG(dip_wgrad_bf3), DIP_REG(dip_wgrad_thin), DIP_REG(dip_conv_wgrad_tail), DIP_REG(dip_wgrad_tail_stream), DIP_REG(dip_wgrad_reduce),
     DIP_REG(dip_bn_finalize), DIP_REG(dip_bn_bwd_stats), DIP_REG(dip_bn_bwd_stats_fin), DIP_REG(dip_bn_bwd_finalize),
     DIP_REG(dip_bn_bwd_finalize2), DIP_REG(dip_bn_bwd_apply), DIP_REG(dip_bn_bwd_apply_src), DIP_REG(dip_bn_bwd_apply_fin),
     DIP_REG(dip_bn_bwd_apply_src_fin), DIP_REG(dip_bn_bwd_one), DIP_REG(dip_fold_to_nchw), DIP_REG(dip_fold_to_nhwc),

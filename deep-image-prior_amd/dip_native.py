@@ -148,6 +148,8 @@ _SIGS = {
     "dip_wgrad_bf3_eligible": (C.c_int, [C.POINTER(DipWgradDesc)]),
     "dip_wgrad_bf3": (C.c_int, [C.POINTER(DipWgradDesc), C.c_void_p]),
     "dip_conv_wgrad_tail": (C.c_int, [C.POINTER(DipWgradDesc), C.c_void_p]),
+    "dip_wgrad_tail_stream_ok": (C.c_int, [C.POINTER(DipWgradDesc)]),
+    "dip_wgrad_tail_stream": (C.c_int, [C.POINTER(DipWgradDesc), C.c_void_p]),
     "dip_conv_wgrad_ntiles": (C.c_int, [C.c_int, C.c_int]),
     "dip_wgrad_thin": (C.c_int, [C.POINTER(DipWgradDesc), C.c_void_p]),
     "dip_wgrad_thin_eligible": (C.c_int, [C.POINTER(DipWgradDesc)]),

@@ -335,6 +335,12 @@ int dip_conv_wgrad(const DipWgradDesc* d, void* stream);
 int dip_wgrad_bf3_eligible(const DipWgradDesc* d);
 int dip_wgrad_bf3(const DipWgradDesc* d, void* stream);
 int dip_conv_wgrad_tail(const DipWgradDesc* d, void* stream);
+/* The same rows as a streaming kernel (round 6, wgrad_tail.hip; dip_conv_wgrad_tail dispatches to it): (tap, channel) packed
+ * into the rows of the fp32 MFMA, K = pairs of output pixels straight from global memory, one pass over dy, the slabs of
+ * `d->nsplit` walkers written like the bf16-pipe kernel's.  _ok: 3x3, stride 1, 1..4 channels behind whole 32-channel chunks
+ * (DIP_WGRAD_TAIL_OLD=1 switches it off). */
+int dip_wgrad_tail_stream_ok(const DipWgradDesc* d);
+int dip_wgrad_tail_stream(const DipWgradDesc* d, void* stream);
 /* Thin layers (round 6, csrc/wgrad_thin.hip): 3x3 / 5x5, stride 1 / 2, 8..64 input channels, <= 64 output channels, >= 4096
  * output pixels -- the 16 / 32 / 64-channel convs of the 'library' and snail nets (inpainting.ipynb:222-232,
  * denoising.ipynb:143-150): 16-channel x 16-column x 4-pixel MFMA tiles, the taps spread over the workgroup's waves; same

@@ -148,6 +148,8 @@ WGRAD_BF3_CASES = [
     (132, 128, REFLECT, 256, 256, True),      # four full chunks on the bf16 pipe + the 4-channel tail (dip_conv_wgrad_tail)
     (48, 160, ZERO, 250, 280, False),         # a 16-channel partial chunk, two 128-column blocks, ragged tiles, zero padding
     (100, 128, REFLECT, 256, 256, True),      # THREE full chunks (group 1 of the last workgroup has none) + a 4-channel tail
+    (129, 160, ZERO, 250, 281, False),        # round 6, wgrad_tail_kernel: a ONE-channel tail, zero padding, odd width, two column blocks
+    (66, 128, REFLECT, 130, 136, True),       # ... a two-channel tail behind two chunks, 64 slabs
 ]
 
 
