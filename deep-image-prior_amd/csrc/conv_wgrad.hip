@@ -803,7 +803,11 @@ extern "C" int dip_wgrad_plan(int Hout, int Wout, int Cin, int Cout, int ks, int
     if (ks == 3 && chunks > 1 && Cin - (chunks - 1) * 32 <= 4) chunks -= 1;
     const int per_split = chunks * groups * dip_cdiv(CoutP, 128);
     int n = 512 / per_split;
-    if (n > nt / 4) n = nt / 4;        // >= 4 pixel tiles per workgroup: amortise its slab write + the reduce
+    // >= 4 pixel tiles per workgroup: amortise its slab write + the reduce.  3x3 stride 2: >= 2 -- a tile stages a 9 x 33-pixel
+    // halo, and 512 workgroups with 2 tiles each beat 256 with 4 (tools/s2_time.py on MI355X, kernel + reduce:
+    // 32 > 128 @ 256 x 256 out: 97 + 8 -> 74 + 13 us, 128 > 128 @ 128 x 128 out: 92 + 8 -> 72 + 14 us; twice as many again: slower)
+    const int min_tiles = (ks == 3 && stride == 2) ? 2 : 4;
+    if (n > nt / min_tiles) n = nt / min_tiles;
     if (n < 1) n = 1;
     // the layers wgrad_bf3_kernel takes (3x3 stride 1, >= 512 tiles of 2 x 16 pixels): ONE 8-wave workgroup per CU that fills its
     // register file, resident for the whole launch -- 256 of them leave no CU to the dependent chain of the main stream, which then

@@ -38,10 +38,13 @@ template <> struct WtVec<4> { typedef f32x4 T; };
 template <int NCB> __device__ __forceinline__ float wt_get(const typename WtVec<NCB>::T& v, int e) { return v[e]; }
 template <> __device__ __forceinline__ float wt_get<1>(const float& v, int) { return v; }
 
+// source index of v under the padding rule, -1 outside (zero padding); selects, not a wave-uniform switch per call
 __device__ __forceinline__ int wt_map(int v, int n, int pad_mode) {
-    if (pad_mode == DIP_PAD_REFLECT) v = dip_reflect(v, n);
-    else if (pad_mode == DIP_PAD_REPLICATE) v = min(max(v, 0), n - 1);
-    return (v < 0 || v >= n) ? -1 : v;
+    const int a = v < 0 ? -v : v;
+    const int refl = a >= n ? 2 * (n - 1) - a : a;
+    const int repl = min(max(v, 0), n - 1);
+    const int m = pad_mode == DIP_PAD_REFLECT ? refl : (pad_mode == DIP_PAD_REPLICATE ? repl : v);
+    return (m < 0 || m >= n) ? -1 : m;
 }
 
 constexpr int WT_RUN = 2 * WT_UNROLL;                 // output pixels of a run: WT_UNROLL K steps of the MFMA
