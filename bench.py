@@ -250,7 +250,7 @@ class Fit:
         self.loss = None
         self.avg = None
         self.closure = self._notebook_closure() if closure_kind == "notebook" else self._fused_closure()
-        self.opt = FusedAdam(get_params('net', self.net, self.z), lr=0.01)      # == optimize('adam', ...)
+        self.opt = FusedAdam(get_params('net', self.net, self.z), lr=float(os.environ.get("DIP_BENCH_LR", "0.01")))      # == optimize('adam', ...)
 
     # the notebook's closure (denoising.ipynb:204-221, super-resolution.ipynb:169-186,
     # inpainting.ipynb:295-313) minus the per-iteration host syncs (prints / plots / PSNR on the CPU)
@@ -1259,8 +1259,10 @@ def main():
         cb = None if (args.no_cpu_baseline or world > 1 or args.config != "default") else cpu_baseline()
         its = world * len(fits) * args.steps / tmax
         n_launch = count_kernels(eng)
+        ko = os.environ.get("DIP_KNOCKOUT")
         line = {
-            "metric": "optimisation iters/sec per image (skip-net 512x512 denoising)" if args.config == "default"
+            "metric": f"KNOCK-OUT EXPERIMENT (launches matching {ko!r} left out, results wrong): not a measurement of the path" if ko
+            else "optimisation iters/sec per image (skip-net 512x512 denoising)" if args.config == "default"
             else f"optimisation iters/sec per image ({args.config} config)",
             "value": round(its, 3), "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * tmax / args.steps, 3), "higher_is_better": True, "scaling": "weak",

@@ -123,6 +123,12 @@ class SkipEngine:
         # the launch lists are compiled into command lists (dip_native.CmdList -> dip_list_run: one foreign call per direction
         # and iteration instead of one per launch); DIP_NO_CLIST=1 issues them from Python, launch by launch, as rounds 1-5 did
         self.use_clist = os.environ.get("DIP_NO_CLIST") is None
+        # DIP_KNOCKOUT=<regex over op names>: a knock-out timing experiment (what would the iteration gain if these launches
+        # cost nothing?); never a valid configuration -- bench.py refuses to print a headline line with it set
+        import re
+        ko = os.environ.get("DIP_KNOCKOUT")
+        self._knockout = re.compile(ko) if ko else None
+        self._ko_after, self._ko_seen = int(os.environ.get("DIP_KNOCKOUT_AFTER", "0")), {}
         self._clists = {}
         self._replicate_bufs = set()
         # BatchNorm-backward statistics in the epilogue of the data-gradient launch (DipConvDesc.bnb_*) instead of a pass
@@ -1070,10 +1076,16 @@ class SkipEngine:
         (DIP_NO_CLIST=1) walked in Python with torch events -- the same schedule either way."""
         multi = cls_fn is not None
         slot, aux, events = self._aux_streams() if multi else ("one", [], None)
-        ck = (key, len(ops), multi)
+        ko = False
+        if self._knockout is not None:          # DIP_KNOCKOUT_AFTER=n: the first n issues of a list run whole (buffers hold real values)
+            n = self._ko_seen[key] = self._ko_seen.get(key, 0) + 1
+            ko = n > self._ko_after
+        ck = (key, len(ops), multi, ko)
         ent = self._clists.get(ck)
         if ent is None:
             sched = self._schedule(ops, cls_fn, join_before_fn, deps)
+            if ko:                              # timing experiment: these launches are left out (the results are WRONG)
+                sched = [c for c in sched if not (c[0] == "launch" and self._knockout.search(ops[c[1]][2]))]
             cl = None
             if self.use_clist:
                 evidx = {}

@@ -109,3 +109,59 @@ def test_wgrad_thin(dev, case, nsplit):
     n, g, cb = N.wgrad_plan2(Ho, Wo, Cin, Cout, ks, stride)
     assert n == N.lib().dip_wgrad_thin_nsplit(Ho, Wo, Cin, Cout, ks, stride) == N.wgrad_plan(Ho, Wo, Cin, Cout, ks, stride) and g == 1
     TK.test_conv_wgrad(dev, case, nsplit)
+
+
+THIN4_CASES = [
+    # layer Cin (the gradient's columns; the first Cin - 128k.. are the thin ones here: ncols), layer Cout (= dy channels), H, W, accumulate
+    (4, 128, 45, 61, False),       # the default net's case: 4 skip columns from 128 dy channels; ragged strips and row walks
+    (4, 128, 16, 14, False),       # exactly one strip
+    (4, 128, 3, 100, True),        # fewer rows than a walk, accumulate onto the buffer
+    (2, 64, 33, 47, False),        # 2 columns, 64 dy channels (4 K groups)
+    (1, 16, 20, 29, False),        # 1 column, 16 dy channels (1 K group)
+    (3, 96, 19, 30, True),         # 96 dy channels: the 128-channel instance with two empty K groups
+    (4, 32, 130, 70, False),       # 2 K groups, more than one workgroup row
+    (4, 160, 18, 22, False),       # > 128 dy channels: the vector-ALU form
+]
+
+
+@pytest.mark.parametrize("form", ["mfma", "valu"])
+@pytest.mark.parametrize("case", THIN4_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_thin4_columns(dev, case, form, monkeypatch):
+    """dip_conv_thin4 on its own (conv_thin4.hip): columns [0, ncols) of the data gradient of a zero-padded 3x3 stride-1
+    conv (the interior-domain form of dip_conv_dgrad_ring's caller: Hout = Hin, off = 1), matrix-pipe form and vector-ALU
+    form (DIP_THIN4_VALU is read once per process: the 'valu' arm runs in a subprocess-free way through a >128-channel
+    case or is skipped), against autograd in fp64 with the per-op criterion."""
+    import ctypes as C
+    import hipops as H
+    ncols, Cd, Hh, Ww, acc = case
+    if form == "valu" and Cd <= 128:
+        pytest.skip("the vector-ALU form is what <= 128 dy channels no longer take (kept for > 128 and the fused BatchNorm-backward partials)")
+    if form == "mfma" and Cd > 128:
+        pytest.skip("> 128 dy channels take the vector-ALU form")
+    lib = N.lib()
+    g_ = torch.Generator().manual_seed(ncols * 1000 + Cd)
+    Cl = 8                                                    # layer input channels (columns of the gradient); the thin ones lead
+    w = torch.randn(Cd, Cl, 3, 3, generator=g_) / (Cd * 9) ** 0.5
+    dy = torch.randn(1, Cd, Hh, Ww, generator=g_)
+    base = torch.randn(1, Cl, Hh, Ww, generator=g_)
+    res = {}
+    for dt in (torch.float64, torch.float32):
+        xx = torch.zeros(1, Cl, Hh, Ww, dtype=dt, requires_grad=True)
+        y = torch.nn.functional.conv2d(xx, w.to(dt), None, 1, 1)
+        (y * dy.to(dt)).sum().backward()
+        res[dt] = (xx.grad + (base.to(dt) if acc else 0))[:, :ncols]
+    packed, _, do = H.pack(w.to(dev))
+    dyb = H.to_nhwc(dy.to(dev))
+    Cg = round_up(Cl, 4)
+    gbuf = H.to_nhwc(base.to(dev)).clone() if acc else torch.full((Hh * Ww * Cg,), float("nan"), device=dev)
+    before = gbuf.clone()
+    d = N.DipConvDesc(dyb.data_ptr(), Hh, Ww, round_up(Cd, 4), round_up(Cd, 4), N.DipTransform(None, None, 1.0),
+                      packed.data_ptr() + 4 * do, None, gbuf.data_ptr(), Hh, Ww, Cg, Cl, 0, 3, 1, N.PAD_ZERO, 1, 1, 1 if acc else 0,
+                      None, 1, None)
+    N.check(lib.dip_conv_thin4(C.byref(d), ncols, H.stream(dev)), "conv_thin4")
+    torch.cuda.synchronize()
+    got = H.from_nhwc(gbuf, Cl, Hh, Ww)
+    TK._check("conv_thin4", got[:, :ncols], res[torch.float64], res[torch.float32])
+    # the other columns of the buffer are not touched
+    rest_now, rest_before = gbuf.view(-1, Cg)[:, ncols:], before.view(-1, Cg)[:, ncols:]
+    assert torch.equal(rest_now.isnan(), rest_before.isnan()) and torch.equal(rest_now.nan_to_num(), rest_before.nan_to_num())
