@@ -45,9 +45,9 @@ constexpr int B3_CCH = 16;
 // BN_ = 128: the form of the big layers (a wave owns 64 pixels x 64 columns).  BN_ = 64: the same tile with 32 columns per wave,
 // i.e. two workgroups per pixel tile -- for layers with < 256 tiles, which 128-column workgroups cannot spread over 256 CUs
 // (round 5: 128^2 layers 66-85 us on the fp32 split-K kernels -> this form, +1.9 % per iteration; profiles/r05_ab_n64.txt)
-template <int BN_ = 128>
+template <int BN_ = 128, int KS_ = 3>
 struct B3Cfg {
-    static constexpr int TH = 8, TW = 16, KS = 3;
+    static constexpr int TH = 8, TW = 16, KS = KS_;
     static constexpr int HTH = TH - 1 + KS, HTW = TW - 1 + KS, NPIX = HTH * HTW;      // 10 x 18 = 180
     static constexpr int BN = BN_;
     static constexpr int WN = 2, WM = 2, MS = 2, NS = BN_ / 64;
@@ -335,6 +335,209 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(const DipConvDesc d, c
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// The 1x1 form (round 6): the need1x1_up convs of models/skip.py:88-91 at the high resolutions, forward and data gradient, on
+// the same arithmetic.  A 1x1 layer has ONE unit per 16-channel chunk, so the kernel above -- which hides a chunk's staging
+// under nine units of MFMAs and meets at a barrier once per chunk -- has nothing to hide under; the pipeline here is per
+// chunk: in unit ch a wave issues the weights of chunk ch + 1 and the fp32 pixels of chunk ch + 2 (two register sets take
+// turns), splits chunk ch + 1 out of the other register set into the other A buffer, runs the MFMAs of chunk ch out of
+// fragments it read at the end of the previous unit, meets the workgroup, and reads the fragments of chunk ch + 1.  Every
+// load is unconditional (a chunk past the end re-reads the last one), so the vmcnt values below are exact: 8 = the 6 weight
+// loads + 2 pixel loads issued behind the pixel loads being waited for (5 in the 64-column form), 2 = the pixel loads behind
+// the weights.  Tile, accumulator layout and epilogue are the 3x3 kernel's (8 x 16 pixels, no halo).
+// MEASURED, NOT THE DEFAULT (DIP_CONV_BF3_1X1=1 switches it on).  Against the fp32 form (conv1x1_res.hip, weights-resident,
+// persistent, LDS-DMA: 102 us forward / 85 us data gradient at 512^2 under rocprofv3) this kernel takes 98 / 85 us -- eight
+// units per tile do not amortise a tile's prologue and epilogue, which the persistent fp32 kernel hides under the next tile --
+// and the ITERATION loses 3.3 % with it (186.5 -> 180.3 it/s, interleaved A/B): every other kernel runs 1 - 4 % slower behind
+// two more launches on the bf16 pipe (the chip is power-managed: DESIGN 3.6).  profiles/r06_conv_bf3_1x1_dead_end.txt.
+template <int NT, int TR, int BN = 128>
+__global__ __launch_bounds__(256, 2) void conv_bf3_k1_kernel(const DipConvDesc d, const int ntx, const int ntiles,
+                                                              const int CoutP, const int n_base) {
+    using C = B3Cfg<BN, 1>;
+    constexpr int NS = C::NS;
+    static_assert(C::A_SLOTS == 2 && C::NPIX == 128, "one float4 pair per thread and chunk");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Abuf = smem;
+    int* srcoff = reinterpret_cast<int*>(smem + 2 * C::A_BYTES);
+    float* tra = reinterpret_cast<float*>(srcoff + C::NPIX_PAD);
+    float* trb = tra + B3_TR_MAX;
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 1, wm = wave >> 1;
+    const int tile = dip_xcd_remap(blockIdx.x, ntiles);
+    const int ty = tile / ntx, tx = tile - ty * ntx;
+    const int n0 = n_base + blockIdx.y * BN;
+
+    if (tid < C::NPIX) {
+        const int hr = tid / C::HTW, hc = tid - hr * C::HTW;
+        const int sr = b3_map_src(ty * C::TH + hr - d.off, d.Hin, d.pad_mode);
+        const int sc = b3_map_src(tx * C::TW + hc - d.off, d.Win, d.pad_mode);
+        srcoff[tid] = (sr < 0 || sc < 0) ? -1 : (sr * d.Win + sc);
+    }
+    const float slope = d.tr.slope;
+    if (TR) {
+        for (int c = tid; c < d.Cin; c += 256) { tra[c] = d.tr.a[c]; trb[c] = d.tr.b[c]; }
+    }
+    const int nch = (d.Cin + B3_CCH - 1) / B3_CCH;
+
+    f32x16 acc[2][NS];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NS; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    int a_pix[2];
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) a_pix[ms] = (2 * (wm * 2 + ms) + (l31 >> 4)) * C::HTW + (l31 & 15);
+
+    __syncthreads();                    // srcoff / tr tables
+    // this thread's two staging slots: float4 f = tid + 256 i -> pixel f / 4, channels 4 (f % 4) .. + 3 of the chunk
+    int so[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) so[i] = srcoff[(tid + i * 256) >> 2];
+    const int c4 = tid & 3;
+    typedef f32x4 (&AReg)[2];
+    f32x4 av[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) av[0][i] = av[1][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto loadA = [&](AReg a, int ch) {
+        const int c = min(ch, nch - 1) * B3_CCH + c4 * 4;
+        const bool cv = c < d.Cin;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float* src = d.x + (size_t)(so[i] >= 0 ? so[i] : 0) * d.Cx + (cv ? c : 0);      // clamped: storeA zeroes the padding
+            asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(a[i]) : "v"(src));
+        }
+    };
+    auto storeA = [&](AReg a, int ch, int buf) {
+        const int c = ch * B3_CCH + c4 * 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int hp = (tid + i * 256) >> 2;
+            const bool valid = c < d.Cin && so[i] >= 0;
+            f32x4 o = a[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = valid ? o[e] : 0.f;
+            if (TR && valid) {
+                const f32x4 a4 = *reinterpret_cast<const f32x4*>(tra + c), b4 = *reinterpret_cast<const f32x4*>(trb + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float tv = fmaf(a4[e], o[e], b4[e]);
+                    o[e] = TR == 1 ? dip_act_leaky(tv, slope) : dip_act(tv, slope);
+                }
+            }
+            unsigned h[4], m[4], l[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b3_split(o[e], h[e], m[e], l[e]);
+            unsigned char* base = Abuf + buf * C::A_BYTES + hp * 32 + ((((c4 >> 1) ^ (hp >> 3)) & 1) << 4) + ((c4 & 1) << 3);
+            *reinterpret_cast<u32x2*>(base) = u32x2{(h[0] >> 16) | h[1], (h[2] >> 16) | h[3]};
+            *reinterpret_cast<u32x2*>(base + C::A_PLANE) = u32x2{(m[0] >> 16) | m[1], (m[2] >> 16) | m[3]};
+            *reinterpret_cast<u32x2*>(base + 2 * C::A_PLANE) = u32x2{(l[0] >> 16) | l[1], (l[2] >> 16) | l[3]};
+        }
+    };
+    bf16x8 bq[2][NS][3];
+#pragma unroll
+    for (int sidx = 0; sidx < 2; ++sidx)
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bq[sidx][ns][p] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned b_voff[NS];
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) {
+        const int nn = min(n0 + (wn * NS + ns) * 32 + l31, CoutP - 1);
+        b_voff[ns] = (unsigned)(nn * 32 + half * 16);
+    }
+    const unsigned char* w3 = reinterpret_cast<const unsigned char*>(d.wp3);
+    const size_t plane_bytes = (size_t)CoutP * 32;
+    typedef bf16x8 (&BSet)[NS][3];
+    auto loadB = [&](BSet bs, int ch) {
+        const unsigned char* ub = w3 + (size_t)min(ch, nch - 1) * 3 * plane_bytes;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const unsigned long long b64 = (unsigned long long)(ub + p * plane_bytes);
+            const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)b64);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(b64 >> 32));
+            const void* sb = (const void*)(((unsigned long long)hi << 32) | lo);
+#pragma unroll
+            for (int ns = 0; ns < NS; ++ns)
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(bs[ns][p]) : "v"(b_voff[ns]), "s"(sb));
+        }
+    };
+    auto waitA = [&](AReg a) {          // the pixel loads of `a` have landed; the 3 NS weight + 2 pixel loads behind them stay in flight
+        asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a[0]), "+v"(a[1]) : "n"(3 * NS + 2));
+    };
+    auto waitB = [&](BSet bs) {         // the weight loads of `bs` have landed; the 2 pixel loads behind them stay in flight
+        if constexpr (NS == 2)
+            asm volatile("s_waitcnt vmcnt(2)" : "+v"(bs[0][0]), "+v"(bs[0][1]), "+v"(bs[0][2]), "+v"(bs[1][0]), "+v"(bs[1][1]), "+v"(bs[1][2]));
+        else
+            asm volatile("s_waitcnt vmcnt(2)" : "+v"(bs[0][0]), "+v"(bs[0][1]), "+v"(bs[0][2]));
+    };
+    typedef bf16x8 (&ASet)[2][3];
+    bf16x8 aq[2][2][3];
+    auto readA = [&](ASet as, int abuf) {
+        const unsigned char* Ab = Abuf + abuf * C::A_BYTES;
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms) {
+            const int hp = a_pix[ms];
+            const unsigned char* pa = Ab + hp * 32 + (((half ^ (hp >> 3)) & 1) << 4);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) as[ms][p] = *reinterpret_cast<const bf16x8*>(pa + p * C::A_PLANE);
+        }
+    };
+    auto compute = [&](BSet bs, ASet as) {
+#pragma unroll
+        for (int sm = 4; sm >= 0; --sm) {          // smallest partial products first
+            if ((NT == 6 && sm > 2) || (NT == 8 && sm > 3)) continue;
+#pragma unroll
+            for (int pa = 0; pa < 3; ++pa) {
+                const int pb = sm - pa;
+                if (pb < 0 || pb > 2) continue;
+#pragma unroll
+                for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+                    for (int ns = 0; ns < NS; ++ns)
+                        acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[ms][pa], bs[ns][pb], acc[ms][ns], 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- prologue: chunk 0 staged and its fragments read, chunk 1's pixels in flight ----
+    loadA(av[0], 0);
+    loadB(bq[0], 0);
+    loadA(av[1], 1);
+    waitA(av[0]);
+    storeA(av[0], 0, 0);
+    waitB(bq[0]);
+    __syncthreads();
+    readA(aq[0], 0);
+
+    // unit ch: register sets / buffers of chunk ch are `cur`, of chunk ch + 1 `nxt`
+    auto unit = [&](int ch, BSet bcur, BSet bnxt, ASet acur, ASet anxt, AReg vcur, AReg vnxt, int nbuf) {
+        loadB(bnxt, ch + 1);
+        loadA(vcur, ch + 2);                       // (chunk ch left this set in unit ch - 1)
+        waitA(vnxt);                               // chunk ch + 1, issued a unit ago
+        storeA(vnxt, min(ch + 1, nch - 1), nbuf);  // buffer nbuf was last read before the previous barrier
+        compute(bcur, acur);
+        __builtin_amdgcn_sched_barrier(0);
+        waitB(bnxt);
+        __syncthreads();
+        readA(anxt, nbuf);
+    };
+    for (int ch = 0; ch < nch; ch += 2) {
+        unit(ch, bq[0], bq[1], aq[0], aq[1], av[0], av[1], 1);
+        if (ch + 1 < nch) unit(ch + 1, bq[1], bq[0], aq[1], aq[0], av[1], av[0], 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)");             // the loads issued past the last chunk
+
+    // ---- epilogue (conv_epilogue.h) ----
+    __syncthreads();
+    const DipEpi epi = dip_epi_make(d, ty, tx, C::TH, C::TW);
+    dip_conv_epilogue<C, BN>(d, acc, epi, n0, wn, wm, l31, half, tid, tile, CoutP, reinterpret_cast<float*>(smem));
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // weights -> three bf16 planes, [tap][chunk][plane][n][16 k]; forward: k = input channel, n = output channel;
 // data gradient: k = output channel, n = input channel, flipped taps
 template <bool GRP = false>
@@ -400,11 +603,16 @@ int bf3_terms() {
 // layers with 96..255 tiles (the 128^2 layers of the default net) run the 64-column form of the kernel -- two workgroups per
 // pixel tile -- instead of the fp32 split-K kernels
 constexpr int B3_N64_MIN_TILES = 96;
+// 1x1 layers: from 256 tiles (the 128-column form; below, conv_small / the split-K kernels keep them)
+constexpr int B3_K1_MIN_TILES = 256;
 
-template <int NT, int TR, int BN>
+template <int NT, int TR, int BN, int KS = 3>
 int bf3_launch_bn(const DipConvDesc& d, int n_base, int ncols, hipStream_t st) {
-    using C = B3Cfg<BN>;
-    auto kern = conv_bf3_kernel<NT, TR, BN>;
+    using C = B3Cfg<BN, KS>;
+    auto kern = [] {
+        if constexpr (KS == 1) return conv_bf3_k1_kernel<NT, TR, BN>;
+        else return conv_bf3_kernel<NT, TR, BN>;
+    }();
     static bool attr_set[16] = {};
     if (dip_once_per_device(attr_set)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
@@ -419,6 +627,10 @@ int bf3_launch_bn(const DipConvDesc& d, int n_base, int ncols, hipStream_t st) {
 
 template <int NT, int TR>
 int bf3_launch(const DipConvDesc& d, int n_base, int ncols, hipStream_t st) {
+    if (d.ks == 1) {
+        if (dip_cdiv(d.Wout, 16) * dip_cdiv(d.Hout, 8) < 256) return bf3_launch_bn<NT, TR, 64, 1>(d, n_base, ncols, st);
+        return bf3_launch_bn<NT, TR, 128, 1>(d, n_base, ncols, st);
+    }
     if (dip_cdiv(d.Wout, 16) * dip_cdiv(d.Hout, 8) < 256) return bf3_launch_bn<NT, TR, 64>(d, n_base, ncols, st);
     return bf3_launch_bn<NT, TR, 128>(d, n_base, ncols, st);
 }
@@ -436,7 +648,12 @@ extern "C" int dip_b3_prof_read(unsigned long long* host, int n) {
 extern "C" int dip_conv_bf3_eligible(const DipConvDesc* dp) {
     const DipConvDesc& d = *dp;
     if (bf3_terms() == 0 || d.wp3 == nullptr) return 0;
-    if (d.ks != 3 || d.stride != 1 || d.dil != 1 || d.ksplit > 1 || d.accumulate || d.y_pitch > 0) return 0;
+    // the 1x1 form is opt-in (DIP_CONV_BF3_1X1=1, read at every call so that a test can switch it): measured no faster than the
+    // fp32 weights-resident kernel per launch and 3.3 % SLOWER per iteration (profiles/r06_conv_bf3_1x1_dead_end.txt)
+    const char* k1e = getenv("DIP_CONV_BF3_1X1");
+    const bool k1 = k1e != nullptr && k1e[0] == '1';
+    if ((d.ks != 3 && !(d.ks == 1 && k1)) || d.stride != 1 || d.dil != 1 || d.ksplit > 1 || d.accumulate || d.y_pitch > 0) return 0;
+    if (d.ks == 1 && ((d.Cin & 15) || dip_cdiv(d.Wout, 16) * dip_cdiv(d.Hout, 8) < B3_K1_MIN_TILES)) return 0;
     if ((d.Cin & 3) || (d.Cx & 3) || (d.Cy & 3) || d.Cin > d.Cx || d.Cin < 16) return 0;
     if (d.tr.a != nullptr && d.Cin > B3_TR_MAX) return 0;
     if (d.Cout < 128 || d.bnb_y != nullptr) return 0;

@@ -605,6 +605,8 @@ extern "C" int dip_conv_thin(const DipConvDesc* dp, void* stream);
 
 extern "C" int dip_conv_variant(const DipConvDesc* dp) {
     const DipConvDesc& d = *dp;
+    // 1x1 layers with >= 256 tiles and split weights: the bf16 matrix pipe (conv_bf3_k1_kernel) before the fp32 weights-resident kernel
+    if (d.ks == 1 && dip_conv_bf3_eligible(dp)) return 7;
     if (dip_conv1x1_res_eligible(dp)) return 6;
     if (dip_conv_thin_eligible(dp)) return 8;
     static const bool no_dma = getenv("DIP_CONV_NO_DMA") != nullptr;      // A/B switches for profiling

@@ -311,12 +311,17 @@ class SkipEngine:
                 r.fwd3_off = r.dgrad3_off = -1
                 nchF, nchD = (round_up(r.Cin, 4) + 15) // 16, (round_up(r.Cout, 4) + 15) // 16
                 CoutP, CinP = round_up(r.Cout, 32), round_up(r.Cin, 32)
-                if r.ks == 3 and r.stride == 1 and not r.name.endswith(".down_ds"):
+                # (1x1 layers, round 6, opt-in -- measured slower per iteration: conv_bf3_k1_kernel takes them from 256 tiles,
+                # whole 16-channel chunks on both sides)
+                k1 = (os.environ.get("DIP_CONV_BF3_1X1") == "1" and r.ks == 1 and r.Cin % 16 == 0 and r.Cout % 16 == 0
+                      and min(r.Cin, r.Cout) >= 128)
+                if (r.ks == 3 or k1) and r.stride == 1 and not r.name.endswith(".down_ds"):
+                    kk = r.ks * r.ks
                     r.fwd3_off = off3
-                    off3 += 9 * nchF * 3 * CoutP * 16
+                    off3 += kk * nchF * 3 * CoutP * 16
                     r.dgrad3_off = off3
-                    off3 += 9 * nchD * 3 * CinP * 16
-                    max3 = max(max3, 9 * 16 * (nchF * CoutP + nchD * CinP))
+                    off3 += kk * nchD * 3 * CinP * 16
+                    max3 = max(max3, kk * 16 * (nchF * CoutP + nchD * CinP))
                 recs3[k] = N.DipPackRec3(r.w_off, r.fwd3_off, r.dgrad3_off, r.Cout, r.Cin, r.ks, nchF, CoutP, nchD, CinP)
             self.packed3 = self._dalloc(max(off3, 8), torch.int16, zero=True)
             self.pack_recs3 = self._dcopy(bytes(recs3))

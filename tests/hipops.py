@@ -304,8 +304,8 @@ def pack_bf3(w):
 
 
 def conv_bf3(x, w, bias, pad_mode, tr=(None, None, 1.0), terms=9, dgrad_of=None):
-    """3x3 stride-1 convolution (forward with BatchNorm partials, or -- dgrad_of=(Hin, Win) with x = dy -- the data gradient,
-    folded) on the bf16 matrix pipe: dip_conv_igemm with DipConvDesc.wp3 set and dip_conv_bf3_set_terms(terms)."""
+    """3x3 (or 1x1) stride-1 convolution (forward with BatchNorm partials, or -- dgrad_of=(Hin, Win) with x = dy -- the data
+    gradient, folded) on the bf16 matrix pipe: dip_conv_igemm with DipConvDesc.wp3 set and dip_conv_bf3_set_terms(terms)."""
     lib = N.lib()
     dev = x.device
     N.check(lib.dip_conv_bf3_set_terms(terms))
@@ -323,23 +323,23 @@ def conv_bf3(x, w, bias, pad_mode, tr=(None, None, 1.0), terms=9, dgrad_of=None)
             stats = torch.full((ntiles * 3 * CoutP,), float("nan"), dtype=torch.float32, device=dev)
             bb = bias.contiguous().float() if bias is not None else None
             d = N.DipConvDesc(xb.data_ptr(), H, W, round_up(Cin, 4), round_up(Cin, 4), trd, packed.data_ptr() + 4 * fo,
-                              bb.data_ptr() if bb is not None else None, y.data_ptr(), H, W, Cy, Cout, 0, 3, 1, pad_mode, 1, 1, 0,
-                              stats.data_ptr(), 1, None)
+                              bb.data_ptr() if bb is not None else None, y.data_ptr(), H, W, Cy, Cout, 0, ks, 1,
+                              pad_mode if ks == 3 else N.PAD_ZERO, (ks - 1) // 2, 1, 0, stats.data_ptr(), 1, None)
             d.wp3 = p3.data_ptr() + 2 * fo3
             assert lib.dip_conv_variant(C.byref(d)) == 7, "descriptor not taken by the bf16-pipe kernel"
             N.check(lib.dip_conv_igemm(C.byref(d), stream(dev)), "conv_igemm(bf3)")
             torch.cuda.synchronize()
             return from_nhwc(y, Cout, H, W), stats.view(ntiles, 3, CoutP)
         Hin, Win = dgrad_of
-        reflect = pad_mode in (N.PAD_REFLECT, N.PAD_REPLICATE)
+        reflect = pad_mode in (N.PAD_REFLECT, N.PAD_REPLICATE) and ks == 3
         pad = 1 if reflect else 0
         Hg, Wg = Hin + 2 * pad, Win + 2 * pad
-        off = 2 if reflect else 1
+        off = (2 if reflect else 1) if ks == 3 else 0
         dyb = to_nhwc(x)
         Cg = round_up(Cin, 4)
         g = torch.full((Hg * Wg * Cg,), float("nan"), dtype=torch.float32, device=dev)
         d = N.DipConvDesc(dyb.data_ptr(), Hin, Win, round_up(Cout, 4), round_up(Cout, 4), N.DipTransform(None, None, 1.0),
-                          packed.data_ptr() + 4 * do, None, g.data_ptr(), Hg, Wg, Cg, Cin, 0, 3, 1, N.PAD_ZERO, off, 1, 0, None,
+                          packed.data_ptr() + 4 * do, None, g.data_ptr(), Hg, Wg, Cg, Cin, 0, ks, 1, N.PAD_ZERO, off, 1, 0, None,
                           1, None)
         d.wp3 = p3.data_ptr() + 2 * do3
         assert lib.dip_conv_variant(C.byref(d)) in (3, 7)

@@ -88,6 +88,68 @@ def test_eight_products_are_as_accurate_as_nine(dev):
     assert abs(e8 - e9) <= 0.03 * e9, (e8, e9)
 
 
+K1_CASES = [
+    # Cin, Cout, H, W, transform   (1x1 layers from 256 tiles: conv_bf3_k1_kernel, csrc/conv_bf3.hip)
+    (128, 128, 256, 256, True),       # s1.up1 of the default net (need1x1_up, models/skip.py:88-91 of the reference)
+    (128, 128, 136, 248, False),      # ragged tiles
+    (256, 128, 128, 256, True),       # 16 chunks
+    (144, 160, 128, 256, False),      # an odd number of chunks (9); a partial second column block
+    (16, 128, 200, 176, True),        # a single chunk: prologue + one unit
+]
+
+
+@pytest.fixture
+def _k1_on(monkeypatch):
+    """The 1x1 form is opt-in (measured slower per iteration: profiles/r06_conv_bf3_1x1_dead_end.txt); the switch is read at every call."""
+    monkeypatch.setenv("DIP_CONV_BF3_1X1", "1")
+
+
+@pytest.mark.parametrize("terms", [9, 8, 6])
+@pytest.mark.parametrize("case", K1_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_bf3_1x1_forward_and_stats(dev, case, terms, _k1_on):
+    """The 1x1 form of the bf16-pipe kernel (one unit per 16-channel chunk, pipelined per chunk) against torch-CPU fp64 with the
+    per-op criterion, its error held to 1.5 x the fp32-MFMA kernel's (conv1x1_res / the LDS-DMA kernel) on the same inputs,
+    and the consumer BatchNorm's partial statistics."""
+    Cin, Cout, Hh, Ww, use_tr = case
+    full = (Cin, Cout, 1, 1, REFLECT, Hh, Ww, use_tr)
+    x, w, b, a, bb = _mk(full)
+    slope = 0.2
+    ref64 = _ref_conv(_apply_tr(x, a, bb, slope, torch.float64), w, b, 1, REFLECT, torch.float64)
+    ref32 = _ref_conv(_apply_tr(x, a, bb, slope, torch.float32), w, b, 1, REFLECT, torch.float32)
+    tr = (a.to(dev), bb.to(dev), slope) if use_tr else (None, None, 1.0)
+    y, stats = H.conv_bf3(x.to(dev), w.to(dev), b.to(dev), REFLECT, tr, terms=terms)
+    _check(f"conv_bf3_1x1[{terms}]", y, ref64, ref32)
+    y32 = H.conv_fwd(x.to(dev), w.to(dev), b.to(dev), 1, REFLECT, tr)             # wp3 is not set: an fp32-MFMA kernel
+    e3 = (y.cpu().double() - ref64).pow(2).sum().sqrt().item()
+    e32 = (y32.cpu().double() - ref64).pow(2).sum().sqrt().item()
+    assert e3 <= 1.5 * e32, f"bf16-pipe error {e3:.3e} vs fp32-MFMA error {e32:.3e}"
+    st = stats.cpu().double().numpy()
+    n = st[:, 0, :Cout]; m = st[:, 1, :Cout]; M2 = st[:, 2, :Cout]
+    N_ = n.sum(0)
+    mean = (n * m).sum(0) / N_
+    var = (M2.sum(0) + (n * (m - mean) ** 2).sum(0)) / N_
+    r = ref64[0].reshape(Cout, -1)
+    assert np.allclose(N_, r.shape[1])
+    assert np.allclose(mean, r.mean(1).numpy(), rtol=1e-5, atol=1e-5 * float(r.std()))
+    assert np.allclose(var, r.var(1, unbiased=False).numpy(), rtol=2e-5)
+
+
+@pytest.mark.parametrize("terms", [9, 8])
+@pytest.mark.parametrize("case", [K1_CASES[0], K1_CASES[1], K1_CASES[3]], ids=lambda c: "x".join(map(str, c)))
+def test_conv_bf3_1x1_dgrad(dev, case, terms, _k1_on):
+    Cin, Cout, Hh, Ww, _ = case
+    x, w, b, _, _ = _mk((Cin, Cout, 1, 1, REFLECT, Hh, Ww, False), 1)
+    res = {}
+    for dt in (torch.float64, torch.float32):
+        xx = x.to(dt).requires_grad_(True)
+        y = _ref_conv(xx, w, None, 1, REFLECT, dt)
+        dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(7))
+        (y * dy.to(dt)).sum().backward()
+        res[dt] = xx.grad
+    gx = H.conv_bf3(dy.to(dev), w.to(dev), None, REFLECT, terms=terms, dgrad_of=(Hh, Ww))
+    _check(f"conv_bf3_1x1_dgrad[{terms}]", gx, res[torch.float64], res[torch.float32])
+
+
 N64_CASES = [
     # Cin, Cout, pad, H, W, transform   (96..255 tiles of 8 x 16 pixels: the 64-column form, two workgroups per pixel tile)
     (128, 128, REFLECT, 128, 128, True),      # the 128^2 layers of the default net
