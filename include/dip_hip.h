@@ -251,17 +251,20 @@ int dip_conv_plan_dil2(int Hout, int Wout, int Cin, int Cout, int ks, int* kspli
 /* which kernel dip_conv_igemm launches for `d` (diagnostic; bench.py attributes its HIP-event times
  * with it): 0 = conv_igemm_kernel (operands staged through registers: stride 2, 5x5),
  * 1 = conv_igemm_dma_kernel (LDS-DMA staging: stride-1 1x1 / 3x3), 2 = conv_igemm_kernel N=160 variant
- * (3x3, 129..160 output channels, split-K), 3 = conv_thin4_kernel (columns 0..Cout-129 on the vector ALU)
- * + conv_igemm_dma_kernel (the other 128 columns): 3x3 data gradients towards a 132-channel tensor,
+ * (3x3, 129..160 output channels, split-K), 3 = conv_thin4_mfma_kernel (columns 0..Cout-129: the tap sum pulled out of the
+ * contraction, v_mfma_f32_16x16x4_f32 fed straight from global memory; the vector-ALU conv_thin4_kernel above 128 input channels
+ * and with fused BatchNorm-backward partials) + conv_igemm_dma_kernel (the other 128 columns): 3x3 data gradients towards a
+ * 132-channel tensor,
  * 4 = conv_igemm_dma_kernel in phase mode (dil == 2: data gradient of a stride-2 3x3 convolution),
  * 5 = conv_igemm_dma_kernel in strided-forward mode (3x3, stride 2: the input split by pixel parity),
  * 6 = conv1x1_res_kernel (1x1, 128 -> 97..128 channels, >= 256x256 pixels: persistent workgroups, weights in registers),
- * 7 = conv_bf3_kernel (3x3 stride 1 on the bf16 matrix pipe), 8 = conv_thin_kernel (<= 64 channels in and out, 3x3 / 5x5,
+ * 7 = conv_bf3_kernel (3x3 stride 1 on the bf16 matrix pipe; with DIP_CONV_BF3_1X1=1 also 1x1 layers from 256 tiles:
+ * conv_bf3_k1_kernel, measured slower per iteration and off by default), 8 = conv_thin_kernel (<= 64 channels in and out, 3x3 / 5x5,
  * 16x16x4 MFMA tiles, all taps' weights LDS-resident: the high-resolution layers of the narrow nets) */
 int dip_conv_variant(const DipConvDesc* d);
 /* The two launches behind variant 3, exported so that a caller can put them on DIFFERENT streams (they
  * write disjoint columns of the same output): columns [0, ncols) (ncols = Cout - 128 <= 4) of a 3x3
- * stride-1 transform-free convolution on the vector ALU, and one 128-column block starting at column
+ * stride-1 transform-free convolution (matrix-pipe form up to 128 input channels, vector ALU beyond), and one 128-column block starting at column
  * n_base on the LDS-DMA kernel.  Same descriptor as dip_conv_igemm. */
 int dip_conv_thin4(const DipConvDesc* d, int ncols, void* stream);
 int dip_conv_igemm_dma_cols(const DipConvDesc* d, int n_base, void* stream);
