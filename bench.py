@@ -1259,9 +1259,9 @@ def main():
         cb = None if (args.no_cpu_baseline or world > 1 or args.config != "default") else cpu_baseline()
         its = world * len(fits) * args.steps / tmax
         n_launch = count_kernels(eng)
-        ko = os.environ.get("DIP_KNOCKOUT")
+        ko = os.environ.get("DIP_KNOCKOUT") or (("learning rate " + os.environ["DIP_BENCH_LR"]) if "DIP_BENCH_LR" in os.environ else None)
         line = {
-            "metric": f"KNOCK-OUT EXPERIMENT (launches matching {ko!r} left out, results wrong): not a measurement of the path" if ko
+            "metric": f"KNOCK-OUT EXPERIMENT ({ko!r}: launches left out / parameters frozen, results wrong): not a measurement of the path" if ko
             else "optimisation iters/sec per image (skip-net 512x512 denoising)" if args.config == "default"
             else f"optimisation iters/sec per image ({args.config} config)",
             "value": round(its, 3), "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -119,6 +119,7 @@ THIN4_CASES = [
     (2, 64, 33, 47, False),        # 2 columns, 64 dy channels (4 K groups)
     (1, 16, 20, 29, False),        # 1 column, 16 dy channels (1 K group)
     (3, 96, 19, 30, True),         # 96 dy channels: the 128-channel instance with two empty K groups
+    (4, 100, 21, 33, False),       # 100 dy channels: a K group with one of its four lane slots past the end
     (4, 32, 130, 70, False),       # 2 K groups, more than one workgroup row
     (4, 160, 18, 22, False),       # > 128 dy channels: the vector-ALU form
 ]
