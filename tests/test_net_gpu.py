@@ -339,6 +339,9 @@ AB_SWITCH_SETS = [
     dict(DIP_CONV_BF3="6", DIP_TICKET_FIN="1"),
     dict(DIP_CONV_NO_SMALL="1", DIP_CONV_NO_RING="1"),
     dict(DIP_CONV_BF3="9"),               # all nine partial products (the default leaves lo x lo out)
+    # round 6: the vector-ALU form of the thin data-gradient columns (the matrix-pipe form is the default up to 128 dy
+    # channels); the opt-in 1x1 form of the bf16-pipe kernel (256 x 256 = 256 tiles: eligible)
+    dict(DIP_THIN4_VALU="1", DIP_CONV_BF3_1X1="1"),
 ]
 
 
