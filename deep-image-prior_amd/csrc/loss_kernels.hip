@@ -120,7 +120,14 @@ __global__ __launch_bounds__(256) void loss_head_fwd_coal_kernel(const DipLossHe
 #pragma unroll
         for (int o = 0; o < 4; ++o) w[o][e] = (o < d.Cout && c < d.Cin) ? d.w[(size_t)o * d.Cin + c] : 0.f;
     }
-    const float mybias = (d.bias != nullptr && cg < d.Cout) ? d.bias[cg] : 0.f;
+    // the lane group's sums are formed by a PACKED butterfly: the first two exchanges (distances NC4 / 2, NC4 / 4) also halve
+    // the number of values a lane carries (4 -> 2 -> 1: a lane sends the half it will not finish), the others add one value:
+    // log2(NC4) + 1 cross-lane moves per pixel step instead of 4 log2(NC4) -- with 32 lanes per pixel 6 instead of 20, which
+    // had the LDS crossbar (ds_bpermute), not HBM, pace this kernel (48 us for 134 MB).  Output channel of a lane: 2 bA + bB.
+    const bool bA = (cg & (NC4 / 2)) != 0, bB = (cg & (NC4 / 4)) != 0;
+    const int myo = 2 * (bA ? 1 : 0) + (bB ? 1 : 0);
+    const bool writer = (cg & (NC4 / 4 - 1)) == 0 && myo < d.Cout;
+    const float mybias = (d.bias != nullptr && myo < d.Cout) ? d.bias[myo] : 0.f;
     const int p0 = blockIdx.x * ppb, p1 = min(p0 + ppb, d.HW);
     float lsum = 0.f;
     constexpr int UN = 4;                        // independent loads in flight per thread
@@ -146,19 +153,19 @@ __global__ __launch_bounds__(256) void loss_head_fwd_coal_kernel(const DipLossHe
             float part[4];
 #pragma unroll
             for (int o = 0; o < 4; ++o) part[o] = (w[o][0] * v[0] + w[o][1] * v[1]) + (w[o][2] * v[2] + w[o][3] * v[3]);
+            const float k0 = (bA ? part[2] : part[0]) + __shfl_xor(bA ? part[0] : part[2], NC4 / 2);
+            const float k1 = (bA ? part[3] : part[1]) + __shfl_xor(bA ? part[1] : part[3], NC4 / 2);
+            float mine = (bB ? k1 : k0) + __shfl_xor(bB ? k0 : k1, NC4 / 4);
 #pragma unroll
-            for (int sft = NC4 / 2; sft >= 1; sft >>= 1)
-#pragma unroll
-                for (int o = 0; o < 4; ++o) part[o] += __shfl_xor(part[o], sft);
-            const float mine = cg == 0 ? part[0] : (cg == 1 ? part[1] : (cg == 2 ? part[2] : part[3]));
-            if (p < p1 && cg < d.Cout) {
+            for (int sft = NC4 / 8; sft >= 1; sft >>= 1) mine += __shfl_xor(mine, sft);
+            if (p < p1 && writer) {
                 float y = mine + mybias;
                 if (d.sigmoid) y = sigmoidf_(y);
-                d.out[(size_t)cg * d.HW + p] = y;
-                const float t = d.target[(size_t)cg * d.HW + p];
+                d.out[(size_t)myo * d.HW + p] = y;
+                const float t = d.target[(size_t)myo * d.HW + p];
                 float a = y, b = t;
                 if (d.mask != nullptr) {
-                    const float m = d.mask[(size_t)(d.mask_c == 1 ? 0 : cg) * d.HW + p];
+                    const float m = d.mask[(size_t)(d.mask_c == 1 ? 0 : myo) * d.HW + p];
                     a = y * m;                                     // mse(out * mask, img * mask)
                     b = t * m;
                 }
