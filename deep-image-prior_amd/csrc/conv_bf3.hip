@@ -33,6 +33,7 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #ifdef DIP_W3_PROFILE
 // clock probe of the profile build (tools/w3_profile.py): per workgroup {s_memtime cycles, s_memrealtime ticks (100 MHz)} of wave 0
@@ -92,7 +93,7 @@ __device__ __forceinline__ void b3_split(float a, unsigned& h, unsigned& m, unsi
 // A fragments are read from LDS one unit ahead as well (the A buffer of a chunk does not change while it is walked).
 template <int NT, int TR, int BN = 128>
 __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(const DipConvDesc d, const int ntx, const int ntiles,
-                                                           const int CoutP, const int n_base) {
+                                                           const int CoutP, const int n_base, const int tailk) {
     using C = B3Cfg<BN>;
     constexpr int KK = 9;
     constexpr int NS = C::NS;
@@ -123,7 +124,13 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(const DipConvDesc d, c
         for (int c = tid; c < d.Cin; c += 256) { tra[c] = d.tr.a[c]; trb[c] = d.tr.b[c]; }
     }
     const int nch = (d.Cin + B3_CCH - 1) / B3_CCH;
-    const int nunits = nch * KK;
+    // A 4-channel last chunk (132 = 8 x 16 + 4 input channels: the decoder convs on [4 skip | 128] channels) would spend nine
+    // units on 4 real k of 16.  Its K is PACKED instead: k = (tap, channel), three units of 4 taps x 4 channels (the 36 real
+    // products in 48 slots instead of 144); a lane's eight k are two taps of its pixel = two 8-byte reads at two halo offsets;
+    // dip_pack_weights_bf3 stores the matching B rows in the unit slots (tap 0..2, last chunk) of the ordinary layout, so the
+    // weight loads do not change.  Six units of 81 less: 482 -> ~450 us on the 512^2 layer.
+    const bool tail = tailk && nch > 1 && (d.Cin & 15) == 4;
+    const int nunits = tail ? (nch - 1) * KK + 3 : nch * KK;
 
     f32x16 acc[2][NS];
 #pragma unroll
@@ -251,9 +258,25 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(const DipConvDesc d, c
     // chunk does not change while the chunk is walked, so this needs no synchronisation beyond the chunk boundary's)
     typedef bf16x8 (&ASet)[2][3];
     bf16x8 aq[2][2][3];
-    auto readA = [&](ASet as, int tapn, int abuf) {
-        const int ky = tapn / 3, kx = tapn - 3 * ky;
+    auto readA = [&](ASet as, int tapn, int abuf, bool packed) {
         const unsigned char* Ab = Abuf + abuf * C::A_BYTES;
+        if (packed) {                   // (wave-uniform) packed unit tapn of the 4-channel chunk: this lane's k = taps tA, tA + 1
+            const int tA = 4 * tapn + 2 * half, tB = tA + 1;
+            const int oA = tA < KK ? (tA / 3) * C::HTW + tA % 3 : 0, oB = tB < KK ? (tB / 3) * C::HTW + tB % 3 : 0;   // (taps >= 9: zero weights)
+#pragma unroll
+            for (int ms = 0; ms < 2; ++ms) {
+                const int hA = a_pix[ms] + oA, hB = a_pix[ms] + oB;
+                const unsigned char* pA = Ab + hA * 32 + (((hA >> 3) & 1) << 4);      // channels 0..3 of the chunk: k 0..3 of the pixel's slot
+                const unsigned char* pB = Ab + hB * 32 + (((hB >> 3) & 1) << 4);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    const u32x2 vA = *reinterpret_cast<const u32x2*>(pA + p * C::A_PLANE), vB = *reinterpret_cast<const u32x2*>(pB + p * C::A_PLANE);
+                    as[ms][p] = __builtin_bit_cast(bf16x8, u32x4{vA[0], vA[1], vB[0], vB[1]});
+                }
+            }
+            return;
+        }
+        const int ky = tapn / 3, kx = tapn - 3 * ky;
 #pragma unroll
         for (int ms = 0; ms < 2; ++ms) {
             const int hp = a_pix[ms] + ky * C::HTW + kx;
@@ -288,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(const DipConvDesc d, c
     storeA(0, 0);
     waitB(bq[0], false);
     __syncthreads();
-    readA(aq[0], 0, 0);
+    readA(aq[0], 0, 0, false);
 
     int u = 0, ch = 0, tap = 0;
     auto unit = [&](BSet cur, BSet nxt, ASet acur, ASet anxt) {
@@ -305,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(const DipConvDesc d, c
         loadB(nxt, tapn, chn);
         const bool ld = tap == 0 && next_chunk;
         loadA(ch + 1, ld);                                       // AFTER this unit's B loads: they can be waited for alone
-        readA(anxt, tapn, chn & 1);                              // next unit's A fragments, under this unit's MFMAs
+        readA(anxt, tapn, chn & 1, tail && chn == nch - 1);      // next unit's A fragments, under this unit's MFMAs
         compute(cur, acur);
         __builtin_amdgcn_sched_barrier(0);          // (hipcc hoisted the wait to the 4th MFMA: a full L2 latency exposed per unit)
         waitB(nxt, ld);
@@ -351,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(const DipConvDesc d, c
 // two more launches on the bf16 pipe (the chip is power-managed: DESIGN 3.6).  profiles/r06_conv_bf3_1x1_dead_end.txt.
 template <int NT, int TR, int BN = 128>
 __global__ __launch_bounds__(256, 2) void conv_bf3_k1_kernel(const DipConvDesc d, const int ntx, const int ntiles,
-                                                              const int CoutP, const int n_base) {
+                                                              const int CoutP, const int n_base, const int /*tailk*/) {
     using C = B3Cfg<BN, 1>;
     constexpr int NS = C::NS;
     static_assert(C::A_SLOTS == 2 && C::NPIX == 128, "one float4 pair per thread and chunk");
@@ -542,7 +565,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_k1_kernel(const DipConvDesc d
 // data gradient: k = output channel, n = input channel, flipped taps
 template <bool GRP = false>
 __global__ __launch_bounds__(256) void pack_weights_bf3_kernel(const float* __restrict__ params_, unsigned short* __restrict__ out_,
-                                                               const DipPackRec3* __restrict__ recs_, const DipGrpArg<GRP> grp) {
+                                                               const DipPackRec3* __restrict__ recs_, const int tailk,
+                                                               const DipGrpArg<GRP> grp) {
     DIP_GRP_PTR(const float*, params);
     DIP_GRP_PTR(unsigned short*, out);
     DIP_GRP_PTR(const DipPackRec3*, recs);
@@ -551,6 +575,10 @@ __global__ __launch_bounds__(256) void pack_weights_bf3_kernel(const float* __re
     const long long nf = r.fwd_off >= 0 ? (long long)KK * r.nchF * r.CoutP32 * 16 : 0;
     const long long nd = r.dgrad_off >= 0 ? (long long)KK * r.nchD * r.CinP32 * 16 : 0;
     const float* w = params + r.w_off;
+    // a last chunk of 4 channels is stored with its K packed as (tap, channel) -- conv_bf3_kernel's `tail` (same rule: the
+    // contraction length rounded up to 4 is 16 m + 4, m >= 1; 3x3 only)
+    const bool tailF = tailk && r.KS == 3 && r.nchF > 1 && (((r.Cin + 3) & ~3) & 15) == 4;
+    const bool tailD = tailk && r.KS == 3 && r.nchD > 1 && (((r.Cout + 3) & ~3) & 15) == 4;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nf + nd; i += (long long)gridDim.x * 256) {
         float v = 0.f;
         unsigned short* o;
@@ -561,7 +589,10 @@ __global__ __launch_bounds__(256) void pack_weights_bf3_kernel(const float* __re
             const long long rest = (i >> 4) / r.CoutP32;
             const int ch = (int)(rest % r.nchF), tap = (int)(rest / r.nchF);
             const int c = ch * 16 + kk;
-            if (n < r.Cout && c < r.Cin) v = w[((size_t)n * r.Cin + c) * KK + tap];
+            if (tailF && ch == r.nchF - 1) {        // packed K of the 4-channel chunk: unit slot `tap` < 3 holds taps 4 tap .. 4 tap + 3 x 4 channels
+                const int t = 4 * tap + (kk >> 2), cc = ch * 16 + (kk & 3);
+                if (tap < 3 && t < KK && n < r.Cout && cc < r.Cin) v = w[((size_t)n * r.Cin + cc) * KK + t];
+            } else if (n < r.Cout && c < r.Cin) v = w[((size_t)n * r.Cin + c) * KK + tap];
             plane = (long long)r.CoutP32 * 16;
             o = out + r.fwd_off + ((long long)(tap * r.nchF + ch) * 3) * plane + (long long)n * 16 + kk;
         } else {
@@ -571,7 +602,10 @@ __global__ __launch_bounds__(256) void pack_weights_bf3_kernel(const float* __re
             const long long rest = (j >> 4) / r.CinP32;
             const int ch = (int)(rest % r.nchD), tap = (int)(rest / r.nchD);
             const int oc = ch * 16 + kk;
-            if (oc < r.Cout && n < r.Cin) v = w[((size_t)oc * r.Cin + n) * KK + (KK - 1 - tap)];
+            if (tailD && ch == r.nchD - 1) {
+                const int t = 4 * tap + (kk >> 2), occ = ch * 16 + (kk & 3);
+                if (tap < 3 && t < KK && occ < r.Cout && n < r.Cin) v = w[((size_t)occ * r.Cin + n) * KK + (KK - 1 - t)];
+            } else if (oc < r.Cout && n < r.Cin) v = w[((size_t)oc * r.Cin + n) * KK + (KK - 1 - tap)];
             plane = (long long)r.CinP32 * 16;
             o = out + r.dgrad_off + ((long long)(tap * r.nchD + ch) * 3) * plane + (long long)n * 16 + kk;
         }
@@ -586,6 +620,13 @@ __global__ __launch_bounds__(256) void pack_weights_bf3_kernel(const float* __re
 }
 
 int g_bf3_override = -1;             // dip_conv_bf3_set_terms
+
+// DIP_CONV_BF3_NO_TAILK=1: a 4-channel last chunk walks nine zero-padded units as before round 6 (A/B switch; the weight pack
+// and the kernel read the same answer)
+bool bf3_tailk() {
+    static const bool on = getenv("DIP_CONV_BF3_NO_TAILK") == nullptr;
+    return on;
+}
 
 int bf3_terms() {
     // default: eight cross products -- all but lo x lo, which is < 2^-32 of a product (2^-8 of the rounding error of one fp32
@@ -620,7 +661,8 @@ int bf3_launch_bn(const DipConvDesc& d, int n_base, int ncols, hipStream_t st) {
     }
     const int ntx = dip_cdiv(d.Wout, C::TW), nty = dip_cdiv(d.Hout, C::TH);
     const int ntiles = ntx * nty;
-    dip_launch(kern, dim3(ntiles, dip_cdiv(ncols, BN)), dim3(256), C::LDS_BYTES, st, d, ntx, ntiles, dip_round_up(d.Cout, 32), n_base);
+    dip_launch(kern, dim3(ntiles, dip_cdiv(ncols, BN)), dim3(256), C::LDS_BYTES, st, d, ntx, ntiles, dip_round_up(d.Cout, 32), n_base,
+               bf3_tailk() ? 1 : 0);
     DIP_CHECK_LAUNCH();
     return 0;
 }
@@ -703,7 +745,7 @@ extern "C" int dip_pack_weights_bf3(const float* params, void* packed3, const Di
     if (gx < 1) gx = 1;
     if (gx > 512) gx = 512;
     dip_launch_pair<DIP_FAM_MISC>(pack_weights_bf3_kernel<false>, pack_weights_bf3_kernel<true>, dim3((unsigned)gx, nrec), dim3(256), 0, (hipStream_t)stream, params,
-                       reinterpret_cast<unsigned short*>(packed3), recs_dev);
+                       reinterpret_cast<unsigned short*>(packed3), recs_dev, bf3_tailk() ? 1 : 0);
     DIP_CHECK_LAUNCH();
     return 0;
 }

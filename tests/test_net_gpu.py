@@ -342,6 +342,7 @@ AB_SWITCH_SETS = [
     # round 6: the vector-ALU form of the thin data-gradient columns (the matrix-pipe form is the default up to 128 dy
     # channels); the opt-in 1x1 form of the bf16-pipe kernel (256 x 256 = 256 tiles: eligible)
     dict(DIP_THIN4_VALU="1", DIP_CONV_BF3_1X1="1"),
+    dict(DIP_CONV_BF3_NO_TAILK="1"),      # the 4-channel last chunk of the 132-channel layers as nine zero-padded units
 ]
 
 
