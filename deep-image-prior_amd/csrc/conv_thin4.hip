@@ -202,8 +202,8 @@ __global__ __launch_bounds__(256) void conv_thin4_mfma_kernel(const DipConvDesc 
     }
     const int sc = t4_map_src(x0 + p - d.off, d.Win, d.pad_mode);     // this lane's source column
     // The A loads are inline asm, unconditional straight-line code (a clamped address; a padding pixel's value is replaced by
-    // zero when the row is consumed), and a row is waited for with an explicit vmcnt(2 NJ) whose operands are its registers:
-    // the two rows behind it stay in flight under its MFMAs.  (Left to hipcc, a branch around a load or the conditional store
+    // zero when the row is consumed), and a row is waited for with an explicit vmcnt(NJ) whose operands are its registers:
+    // the row behind it stays in flight under its MFMAs (see waitA for why not two).  (Left to hipcc, a branch around a load or the conditional store
     // of the output phase makes it lose count and wait with vmcnt(0) before every row: no overlap at all, 85 us at 512 x 512.
     // Its own waits only see its own loads and stores; with ours in flight as well they wait longer than needed, never
     // shorter.)  Channel groups beyond Cin re-read group 0: their B registers are zero.
@@ -220,7 +220,13 @@ __global__ __launch_bounds__(256) void conv_thin4_mfma_kernel(const DipConvDesc 
         for (int j = 0; j < NJ; ++j) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(a[j]) : "v"(q + coff[j]));
     };
     auto waitA = [&](f32x4 (&a)[NJ], bool ok) {
-        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a[0]) : "n"(2 * NJ));
+        // vmcnt(NJ), not vmcnt(2 NJ): ONE row stays in flight behind the row being consumed.  With two (the count the issue
+        // order gives: the loads of rows hr + 1 and hr + 2 are the only vector-memory loads younger than row hr's) 3 % of the
+        // backward passes of a 256 x 256 net came out with wrong thin columns WHEN a chip-filling wgrad_bf3 launch ran beside
+        // this kernel (DIP_DEFER_WGRAD=-1; tools/race_loop.py: 48 of 1500 passes, differences 1e-7 .. garbage), none without
+        // one (3000 of 3000 bit-identical), none with vmcnt(0) (2000) and none with this form (4000).  Not explained -- the ISA
+        // shows the expected order and tools/isa_inflight_check.py finds nothing -- so the margin is kept; it costs nothing measurable (53 us at 512^2, 28 us per launch on average, as before).
+        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a[0]) : "n"(NJ));
 #pragma unroll
         for (int j = 1; j < NJ; ++j) asm volatile("" : "+v"(a[j]));
         if (!ok) {

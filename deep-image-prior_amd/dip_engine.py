@@ -136,6 +136,9 @@ class SkipEngine:
         # per-lane reads of y cost the big launches 35..75 us each, as much as the streaming statistics kernels they
         # replace (+0.5 % on a fast-class box, -1.5 % on a slow-class one) -- so it is opt-in
         self.fuse_bnb = os.environ.get("DIP_BNB_FUSE", "0") == "1"
+        # DIP_BNB_FUSE=2: only in the epilogue of the 1x1 data gradients (conv1x1_res_kernel: a lane owns a channel, so its reads of
+        # y are whole lines) -- an experiment of round 6's last session
+        self.fuse_bnb_1x1 = os.environ.get("DIP_BNB_FUSE", "0") == "2"
         self.thin_src = os.environ.get("DIP_NO_THIN_SRC") is None
         # low-resolution layers (<= DIP_SMALL_MAX_PIXELS output pixels): ONE dip_conv_small launch per convolution
         # (conv + in-workgroup split-K + BatchNorm partials; dip_bn_finalize follows) instead of conv + split-K finish +
@@ -716,7 +719,8 @@ class SkipEngine:
             ksplit, _, wsf = N.conv_plan_dil2(Hg, Wg, round_up(r.Cout, 4), r.Cin, r.ks)
         else:
             # (fused BatchNorm-backward partials keep the layer off the bf16-pipe kernel: planned for the fp32 kernels then)
-            bf3_ok = self.bf3 and getattr(r, "dgrad3_off", -1) >= 0 and not (fuse_bn and self.fuse_bnb and not ring and x.bn is not None)
+            fuse_here = self.fuse_bnb or (self.fuse_bnb_1x1 and r.ks == 1 and r.stride == 1)
+            bf3_ok = self.bf3 and getattr(r, "dgrad3_off", -1) >= 0 and not (fuse_bn and fuse_here and not ring and x.bn is not None)
             ksplit, _, wsf = (N.conv_plan if bf3_ok else N.conv_plan_fp32)(Hg, Wg, round_up(r.Cout, 4), r.Cin, r.ks, 1)
         sizing = self._sizing
         d = N.DipConvDesc(None if sizing else _ptr(dy), Ho, Wo, round_up(r.Cout, 4), round_up(r.Cout, 4),
@@ -749,7 +753,8 @@ class SkipEngine:
             return (gbuf, pad)
         variant = self.lib.dip_conv_variant(C.byref(d))
         fused = None
-        if fuse_bn and self.fuse_bnb and not ring and x.bn is not None and self.lib.dip_conv_bnb_fusable(C.byref(d)):
+        fuse_here = self.fuse_bnb or (self.fuse_bnb_1x1 and r.ks == 1 and r.stride == 1)
+        if fuse_bn and fuse_here and not ring and x.bn is not None and self.lib.dip_conv_bnb_fusable(C.byref(d)):
             bn = x.bn
             rows = self.lib.dip_conv_ntiles(Hg, Wg)
             c_lo = (r.Cin - 128) if variant == 3 else 0          # columns of the conv_thin4 launch (always 4 here: % 4)

@@ -22,6 +22,10 @@ def main():
     from models.skip import skip
     from utils.loss_head import MSEHead
     dev = torch.device("cuda:0")
+    if os.environ.get("PROBE_POISON"):           # debugging aid: fresh allocations of this process hold 1e30 instead of zeros
+        junk = [torch.full((1 << 26,), 1e30, device=dev) for _ in range(8)]      # 2 GiB
+        torch.cuda.synchronize()
+        del junk
     hw = (256, 256)     # >= 65536 pixels: one-pass launches, the weights-resident 1x1 kernel, 132-column data gradients
     kw = dict(num_channels_down=[128, 128], num_channels_up=[128, 128], num_channels_skip=[4, 4],
               upsample_mode="bilinear", need_sigmoid=True, need_bias=True, pad="reflection")
