@@ -15,10 +15,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("switches", [{}, {"DIP_DEFER_WGRAD": "-1"}, {"DIP_DEFER_WGRAD": "0", "DIP_TAIL_INLINE": "0"}],
-                         ids=["default", "no_deferral", "defer0"])
+@pytest.mark.parametrize("switches", [{}, {"DIP_DEFER_WGRAD": "-1"}, {"DIP_DEFER_WGRAD": "0", "DIP_TAIL_INLINE": "0"},
+                                      {"RACE_NET": "deep"}, {"RACE_NET": "deep", "DIP_DEFER_WGRAD": "-1"}],
+                         ids=["default", "no_deferral", "defer0", "five_scales", "five_scales_no_deferral"])
 def test_backward_passes_are_bit_identical(dev, switches):
-    env = {k: v for k, v in os.environ.items() if not k.startswith("DIP_")}
+    env = {k: v for k, v in os.environ.items() if not k.startswith(("DIP_", "RACE_"))}
     env.update(switches)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "race_loop.py"), "800"], env=env, capture_output=True, text=True,
                        timeout=600)

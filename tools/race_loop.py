@@ -19,7 +19,8 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     dev = torch.device("cuda:0")
     hw = (256, 256)
-    kw = dict(num_channels_down=[128, 128], num_channels_up=[128, 128], num_channels_skip=[4, 4],
+    nsc = 5 if os.environ.get("RACE_NET") == "deep" else 2       # deep: the default net's five scales (conv_small, bn_bwd_one, ...)
+    kw = dict(num_channels_down=[128] * nsc, num_channels_up=[128] * nsc, num_channels_skip=[4] * nsc,
               upsample_mode="bilinear", need_sigmoid=True, need_bias=True, pad="reflection")
     torch.manual_seed(5)
     z = (torch.rand(1, 4, *hw) * 0.1).to(dev)
