@@ -14,10 +14,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // buf[i] = i.  A "row" = 8 loads of 1 KB (64 lanes x 16 B), 64 KB apart (8 different DRAM pages), rows 1 MB apart
 template <int WAIT>
-__global__ __launch_bounds__(256) void probe(const unsigned* __restrict__ buf, size_t ndw, int nrows, unsigned long long* bad, int mfma) {
+__global__ __launch_bounds__(256) void probe(const unsigned* __restrict__ buf, size_t ndw, int nrows, unsigned long long* bad, int mfma, int share) {
     const int lane = threadIdx.x & 63, gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
     auto addr = [&](int row, int j) -> const unsigned* {
-        const size_t base = ((size_t)(gw + (size_t)row * nw) * 262144 + (size_t)j * 16384 + (size_t)lane * 4) % (ndw - 4);
+        // share > 1: `share` neighbouring waves read the SAME lines (a mix of L1 hits and misses inside one wave's queue, as the
+        // overlapping strips of conv_thin4 produce); odd rows are skewed by j so that the sharers do not arrive in step
+        const size_t wv = share > 1 ? (size_t)(gw / share) : (size_t)gw;
+        const size_t base = ((wv + (size_t)row * nw) * 262144 + (size_t)((j + (share > 1 ? (gw % share) * row : 0)) & 7) * 16384 + (size_t)lane * 4) % (ndw - 4);
         return buf + (base & ~(size_t)3);
     };
     u32x4 a0[8], a1[8], a2[8];
@@ -67,6 +70,7 @@ int main() {
     fill<<<4096, 256>>>(buf, ndw);
     hipMemset(s, 0, (size_t)1 << 30);
     hipStream_t st1, st2; hipStreamCreate(&st1); hipStreamCreate(&st2);
+    for (int share = 1; share <= 4; share *= 2)
     for (int contention = 0; contention < 2; ++contention)
         for (int mf = 0; mf <= 24; mf += 24)
             for (int wait = 16; wait >= 8; wait -= 8) {
@@ -75,14 +79,14 @@ int main() {
                 hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, st1);
                 for (int rep = 0; rep < 20; ++rep) {
                     if (contention) hog<<<2048, 256, 0, st2>>>(s, d, ((size_t)1 << 30) / 16, 1);
-                    if (wait == 16) probe<16><<<256, 256, 0, st1>>>(buf, ndw, 600, bad, mf);
-                    else probe<8><<<256, 256, 0, st1>>>(buf, ndw, 600, bad, mf);
+                    if (wait == 16) probe<16><<<256, 256, 0, st1>>>(buf, ndw, 600, bad, mf, share);
+                    else probe<8><<<256, 256, 0, st1>>>(buf, ndw, 600, bad, mf, share);
                 }
                 hipError_t e = hipDeviceSynchronize();
                 if (e != hipSuccess) { printf("HIP error %s\n", hipGetErrorString(e)); return 1; }
                 unsigned long long h = 0; hipMemcpy(&h, bad, 8, hipMemcpyDeviceToHost);
                 hipEventRecord(e1, st1); hipEventSynchronize(e1); float ms = 0; hipEventElapsedTime(&ms, e0, e1);
-                printf("contention %d, %2d MFMAs per row, vmcnt(%2d): %llu wrong dwords of %llu   (%.1f ms per probe launch)\n", contention, mf, wait, h,
+                printf("share %d, contention %d, %2d MFMAs per row, vmcnt(%2d): %llu wrong dwords of %llu   (%.1f ms per probe launch)\n", share, contention, mf, wait, h,
                        20ull * 256 * 256 * 600 * 32, ms / 20);
             }
     return 0;
