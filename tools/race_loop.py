@@ -18,7 +18,7 @@ def main():
     from utils.loss_head import MSEHead
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     dev = torch.device("cuda:0")
-    hw = (256, 256)
+    hw = (int(os.environ.get("RACE_HW", "256")),) * 2          # RACE_HW=512 RACE_NET=deep: the headline net
     nsc = 5 if os.environ.get("RACE_NET") == "deep" else 2       # deep: the default net's five scales (conv_small, bn_bwd_one, ...)
     kw = dict(num_channels_down=[128] * nsc, num_channels_up=[128] * nsc, num_channels_skip=[4] * nsc,
               upsample_mode="bilinear", need_sigmoid=True, need_bias=True, pad="reflection")
